@@ -1,0 +1,101 @@
+"""ctypes binding of libdiffhandles_hip.so (the C ABI declared in include/diffhandles_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is visible
+when a compute entry point is called, the caller gets a RuntimeError.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffhandles_hip.so")
+_LIB = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_d = ctypes.c_double
+c_sz = ctypes.c_size_t
+
+
+class UNetConfig(ctypes.Structure):
+    _fields_ = [("in_channels", c_i), ("out_channels", c_i), ("n_levels", c_i),
+                ("block_out_channels", c_i * 4), ("layers_per_block", c_i), ("heads", c_i * 4),
+                ("cross_attention_dim", c_i), ("norm_groups", c_i), ("sample_size", c_i),
+                ("text_len", c_i), ("max_batch", c_i), ("dtype", c_i)]
+
+
+# name -> (restype, argtypes); mirrors include/diffhandles_hip.h one to one
+SIGNATURES = {
+    "dh_last_error": (ctypes.c_char_p, []),
+    "dh_version": (c_i, []),
+    "dh_device_count": (c_i, []),
+    "dh_reproject_workspace_bytes": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_sz)]),
+    "dh_fg_pixel_list": (c_i, [c_p, c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "dh_reproject_edits": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_f, c_f, c_d, c_d, c_i,
+                                 ctypes.POINTER(c_d), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "dh_unproject": (c_i, [c_p, c_i, c_p, c_p, c_f, c_f, c_p, c_p]),
+    "dh_masked_centroid": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p]),
+    "dh_cells_workspace_bytes": (c_i, [c_i, c_i, ctypes.POINTER(c_sz)]),
+    "dh_cells_from_correspondences": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "dh_energy_workspace_bytes": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_sz)]),
+    "dh_energy_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i,
+                                c_f, c_f, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_sz, c_p]),
+    "dh_unet_create": (c_i, [ctypes.POINTER(UNetConfig), ctypes.POINTER(c_p)]),
+    "dh_unet_destroy": (None, [c_p]),
+    "dh_unet_num_params": (c_i, [c_p]),
+    "dh_unet_param_info": (c_i, [c_p, c_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i),
+                                 ctypes.POINTER(ctypes.c_int64)]),
+    "dh_unet_load_param": (c_i, [c_p, c_i, c_p, c_p]),
+    "dh_unet_weight_bytes": (c_sz, [c_p]),
+    "dh_unet_workspace_bytes": (c_sz, [c_p]),
+    "dh_unet_forward": (c_i, [c_p, c_p, c_f, c_p, c_i, c_i, c_p, ctypes.POINTER(c_p), c_p]),
+    "dh_unet_backward": (c_i, [c_p, ctypes.POINTER(c_p), c_p, c_p, c_p, c_p]),
+    "dh_unet_stats": (c_i, [c_p, ctypes.POINTER(c_d), ctypes.POINTER(c_d), ctypes.POINTER(ctypes.c_int64)]),
+    "dh_ddim_cfg_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_p]),
+    "dh_latent_update": (c_i, [c_p, c_p, c_p, c_f, c_f, c_i, c_p]),
+    "dh_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_p]),
+    "dh_mse_fwd_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
+}
+
+
+def lib():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"native HIP library not found at {LIB_PATH}; build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().dh_last_error().decode()}")
+
+
+def require_gpu(t=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("diffusionhandles_amd needs a HIP device (MI355X); there is no CPU fallback")
+    if t is not None and not t.is_cuda:
+        raise RuntimeError("expected a device tensor")
+
+
+def ptr(t):
+    return c_p(t.data_ptr()) if t is not None else c_p(0)
+
+
+def stream_ptr():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+DTYPE_CODE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}

@@ -1,0 +1,373 @@
+// Guidance energy + its gradient w.r.t. the current activations (losses.py:4-84), on
+// channels-last maps [cell][C] so that a cell gather is one coalesced row read.
+//
+//   fg term   = mean_c mean_n | A1[c, o_n] - A2[c, t_n] |          (pairs, duplicates kept)
+//   bg global = mean_c | mean_{BGo} F1[c] - mean_{BGt} F2[c] |
+//   bg local  = fg-style term over the identity pairs of BG_both
+//   A = pool_p(w F) / (pool_p(w) + 1e-10), w = indicator of the cells named by the index lists
+//
+// The gradient is accumulated per target cell from a CSR (target cell -> source cells)
+// built by a counting sort: every output element has exactly one writer, sign sums are
+// integers, so the gradient is bit-deterministic with no float atomics.  Loss values are
+// accumulated in float64 (segment order is the only order dependence).
+#include "common.h"
+
+namespace dh {
+
+// ---- map load / store (with optional bilinear resize, align_corners = False) ----------
+__device__ __forceinline__ void bilinear_src(int dst, int n_in, float scale, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <class T>
+__global__ void k_load_map(const T* src, float* dst, int C, int hin, int win, int grid) {
+  const int cell = blockIdx.x;
+  const int y = cell / grid, x = cell - y * grid;
+  if (hin == grid && win == grid) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dst[(size_t)cell * C + c] = to_f32<T>(src[(size_t)cell * C + c]);
+    return;
+  }
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+  bilinear_src(y, hin, (float)hin / (float)grid, y0, y1, ly0, ly1);
+  bilinear_src(x, win, (float)win / (float)grid, x0, x1, lx0, lx1);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float v00 = to_f32<T>(src[((size_t)y0 * win + x0) * C + c]);
+    float v01 = to_f32<T>(src[((size_t)y0 * win + x1) * C + c]);
+    float v10 = to_f32<T>(src[((size_t)y1 * win + x0) * C + c]);
+    float v11 = to_f32<T>(src[((size_t)y1 * win + x1) * C + c]);
+    dst[(size_t)cell * C + c] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  }
+}
+
+// transpose of k_load_map: one block per INPUT cell, gathers from the grid cells that read it
+template <class T>
+__global__ void k_store_grad(const float* g, T* out, int C, int hin, int win, int grid, float scale) {
+  const int cell = blockIdx.x;
+  if (hin == grid && win == grid) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+      out[(size_t)cell * C + c] = from_f32<T>(g[(size_t)cell * C + c] * scale);
+    return;
+  }
+  const int yi = cell / win, xi = cell - yi * win;
+  const float sy = (float)hin / (float)grid, sx = (float)win / (float)grid;
+  int ylo = (int)floorf(((float)yi - 1.f) / sy) - 1, yhi = (int)ceilf(((float)yi + 1.f) / sy) + 1;
+  int xlo = (int)floorf(((float)xi - 1.f) / sx) - 1, xhi = (int)ceilf(((float)xi + 1.f) / sx) + 1;
+  ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
+  yhi = yhi > grid - 1 ? grid - 1 : yhi; xhi = xhi > grid - 1 ? grid - 1 : xhi;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+      int y0, y1; float ly0, ly1;
+      bilinear_src(y, hin, sy, y0, y1, ly0, ly1);
+      float wy = (y0 == yi ? ly0 : 0.f) + (y1 == yi ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int x = xlo; x <= xhi; ++x) {
+        int x0, x1; float lx0, lx1;
+        bilinear_src(x, win, sx, x0, x1, lx0, lx1);
+        float wx = (x0 == xi ? lx0 : 0.f) + (x1 == xi ? lx1 : 0.f);
+        if (wx == 0.f) continue;
+        acc += wy * wx * g[((size_t)y * grid + x) * C + c];
+      }
+    }
+    out[(size_t)cell * C + c] = from_f32<T>(acc * scale);
+  }
+}
+
+// ---- CSR: target cell -> list of source cells -----------------------------------------
+__global__ void k_hist(const int* pairs, int n, int* cnt, uint8_t* w1, uint8_t* w2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int o = pairs[2 * (size_t)i], t = pairs[2 * (size_t)i + 1];
+  atomicAdd(&cnt[t], 1);
+  w1[o] = 1;
+  w2[t] = 1;
+}
+
+__global__ void k_identity_pairs(const int* list, int n, int* pairs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pairs[2 * (size_t)i] = list[i];
+  pairs[2 * (size_t)i + 1] = list[i];
+}
+
+// exclusive scan of cnt[0..n) into off[0..n], cursor copy; single workgroup of 1024
+__global__ void __launch_bounds__(1024) k_scan_cells(const int* cnt, int n, int* off, int* cursor) {
+  __shared__ int sm[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < n ? cnt[i] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int excl = sm[threadIdx.x] - v + carry;
+    if (i < n) { off[i] = excl; cursor[i] = excl; }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sm[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[n] = carry;
+}
+
+__global__ void k_fill(const int* pairs, int n, int* cursor, int* src) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int o = pairs[2 * (size_t)i], t = pairs[2 * (size_t)i + 1];
+  src[atomicAdd(&cursor[t], 1)] = o;
+}
+
+// ---- pooling --------------------------------------------------------------------------
+// out[cell][c] = sum_window(w * X) / (sum_window(w) + p*p*1e-10); den[cell] = that denominator
+__global__ void k_pool(const float* X, const uint8_t* w, int C, int grid, int p, float* out, float* den) {
+  const int cell = blockIdx.x, y = cell / grid, x = cell - y * grid, r = p / 2;
+  float wn = 0.f;
+  for (int dy = -r; dy <= r; ++dy)
+    for (int dx = -r; dx <= r; ++dx) {
+      int yy = y + dy, xx = x + dx;
+      if (yy >= 0 && yy < grid && xx >= 0 && xx < grid && w[yy * grid + xx]) wn += 1.f;
+    }
+  const float d = wn + (float)(p * p) * 1e-10f;
+  if (threadIdx.x == 0) den[cell] = d;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+      for (int dx = -r; dx <= r; ++dx) {
+        int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < grid && xx >= 0 && xx < grid && w[yy * grid + xx]) s += X[((size_t)yy * grid + xx) * C + c];
+      }
+    out[(size_t)cell * C + c] = s / d;
+  }
+}
+
+// acc[cell][c] += w[cell] * sum_window(G / den)
+__global__ void k_spread(const float* G, const uint8_t* w, const float* den, int C, int grid, int p, float* acc) {
+  const int cell = blockIdx.x, y = cell / grid, x = cell - y * grid, r = p / 2;
+  if (!w[cell]) return;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+      for (int dx = -r; dx <= r; ++dx) {
+        int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < grid && xx >= 0 && xx < grid) s += G[((size_t)yy * grid + xx) * C + c] / den[yy * grid + xx];
+      }
+    acc[(size_t)cell * C + c] += s;
+  }
+}
+
+// ---- pair term --------------------------------------------------------------------------
+// one block per target cell t: G[t][c] (+)= -coef * sum_{k in seg(t)} sign(X1[src_k][c] - X2[t][c])
+__global__ void k_pair_term(const float* X1, const float* X2, const int* off, const int* src, int C, float coef,
+                            float* G, int accumulate, double* loss_part) {
+  __shared__ double sm[4];
+  const int t = blockIdx.x;
+  const int b = off[t], e = off[t + 1];
+  double l = 0.0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float a = X2[(size_t)t * C + c];
+    int s = 0;
+    double la = 0.0;
+    for (int k = b; k < e; ++k) {
+      float d = X1[(size_t)src[k] * C + c] - a;
+      la += (double)fabsf(d);
+      s += (d > 0.f) - (d < 0.f);
+    }
+    float g = -coef * (float)s;
+    if (accumulate) G[(size_t)t * C + c] += g; else G[(size_t)t * C + c] = g;
+    l += la;
+  }
+  l = block_sum(l, sm);
+  if (threadIdx.x == 0) loss_part[t] = l;
+}
+
+// ---- global-average term ----------------------------------------------------------------
+// part[s][c] = sum over the s-th slice of `list` of X[cell][c]
+__global__ void k_colsum(const float* X, const int* list, int n, int C, int S, float* part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (c >= C) return;
+  const int per = (n + S - 1) / S, b = s * per, e = b + per < n ? b + per : n;
+  float acc = 0.f;
+  for (int k = b; k < e; ++k) acc += X[(size_t)list[k] * C + c];
+  part[(size_t)s * C + c] = acc;
+}
+
+// sgn[c] = sign(m1 - m2), loss_c = |m1 - m2|
+__global__ void k_global_diff(const float* p1, const float* p2, int S, int C, int n1, int n2, float* sgn,
+                              double* loss_part) {
+  __shared__ double sm[4];
+  double l = 0.0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < S; ++s) { a += p1[(size_t)s * C + c]; b += p2[(size_t)s * C + c]; }
+    float d = a / (float)n1 - b / (float)n2;
+    sgn[c] = (float)((d > 0.f) - (d < 0.f));
+    l += (double)fabsf(d);
+  }
+  l = block_sum(l, sm);
+  if (threadIdx.x == 0) loss_part[0] = l;
+}
+
+__global__ void k_global_apply(const int* list, int n, const float* sgn, int C, float coef, float* acc) {
+  const int cell = list[blockIdx.x];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) acc[(size_t)cell * C + c] += -coef * sgn[c];
+}
+
+__global__ void k_final_loss(const double* fg_part, int n_fg_part, float fg_norm, const double* bg_part, int n_bg_part,
+                             float bg_norm, float fg_w, float bg_w, float* out) {
+  __shared__ double sm[4];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n_fg_part; i += blockDim.x) a += fg_part[i];
+  for (int i = threadIdx.x; i < n_bg_part; i += blockDim.x) b += bg_part[i];
+  a = block_sum(a, sm);
+  b = block_sum(b, sm);
+  if (threadIdx.x == 0) {
+    float fg = (float)(a * (double)fg_norm), bg = (float)(b * (double)bg_norm);
+    out[0] = fg_w * fg + bg_w * bg;
+    out[1] = fg;
+    out[2] = bg;
+  }
+}
+
+struct EnergyWs {
+  float *cur, *orig, *acc, *A1, *A2, *G, *den1, *den2, *part1, *part2, *sgn;
+  int *cnt, *off, *cursor, *src, *idpairs;
+  uint8_t *w1, *w2;
+  double *fg_part, *bg_part;
+};
+constexpr int COLSUM_S = 32;
+
+static bool carve_energy(Arena& a, int C, int grid, int n_pairs, EnergyWs& w) {
+  const size_t G2 = (size_t)grid * grid, M = G2 * C;
+  const size_t np = (size_t)(n_pairs > (int)G2 ? n_pairs : (int)G2);
+  w.cur = a.take<float>(M); w.orig = a.take<float>(M); w.acc = a.take<float>(M);
+  w.A1 = a.take<float>(M); w.A2 = a.take<float>(M); w.G = a.take<float>(M);
+  w.den1 = a.take<float>(G2); w.den2 = a.take<float>(G2);
+  w.part1 = a.take<float>((size_t)COLSUM_S * C); w.part2 = a.take<float>((size_t)COLSUM_S * C);
+  w.sgn = a.take<float>(C);
+  w.cnt = a.take<int>(G2 + 1); w.off = a.take<int>(G2 + 1); w.cursor = a.take<int>(G2 + 1);
+  w.src = a.take<int>(np); w.idpairs = a.take<int>(2 * G2);
+  w.w1 = a.take<uint8_t>(G2); w.w2 = a.take<uint8_t>(G2);
+  w.fg_part = a.take<double>(G2); w.bg_part = a.take<double>(G2);
+  return a.ok();
+}
+
+template <class T>
+static void launch_load(const void* src, float* dst, int C, int hin, int win, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((k_load_map<T>), dim3(grid * grid), dim3(256), 0, st, (const T*)src, dst, C, hin, win, grid);
+}
+template <class T>
+static void launch_store(const float* g, void* out, int C, int hin, int win, int grid, float scale, hipStream_t st) {
+  hipLaunchKernelGGL((k_store_grad<T>), dim3(hin * win), dim3(256), 0, st, g, (T*)out, C, hin, win, grid, scale);
+}
+
+// one pair-type term: CSR build, optional pooling, gradient into acc, loss partials into part
+static void pair_term(const EnergyWs& w, const int* pairs, int n, int C, int grid, int patch, float coef,
+                      double* part, hipStream_t st) {
+  const int G2 = grid * grid;
+  (void)hipMemsetAsync(w.cnt, 0, (G2 + 1) * sizeof(int), st);
+  (void)hipMemsetAsync(w.w1, 0, G2, st);
+  (void)hipMemsetAsync(w.w2, 0, G2, st);
+  hipLaunchKernelGGL(k_hist, dim3(cdiv(n, 256)), dim3(256), 0, st, pairs, n, w.cnt, w.w1, w.w2);
+  hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, w.cnt, G2, w.off, w.cursor);
+  hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, pairs, n, w.cursor, w.src);
+  if (patch <= 1) {
+    hipLaunchKernelGGL(k_pair_term, dim3(G2), dim3(256), 0, st, w.orig, w.cur, w.off, w.src, C, coef, w.acc, 1, part);
+  } else {
+    hipLaunchKernelGGL(k_pool, dim3(G2), dim3(256), 0, st, w.orig, w.w1, C, grid, patch, w.A1, w.den1);
+    hipLaunchKernelGGL(k_pool, dim3(G2), dim3(256), 0, st, w.cur, w.w2, C, grid, patch, w.A2, w.den2);
+    hipLaunchKernelGGL(k_pair_term, dim3(G2), dim3(256), 0, st, w.A1, w.A2, w.off, w.src, C, coef, w.G, 0, part);
+    hipLaunchKernelGGL(k_spread, dim3(G2), dim3(256), 0, st, w.G, w.w2, w.den2, C, grid, patch, w.acc);
+  }
+}
+
+}  // namespace dh
+
+using namespace dh;
+
+extern "C" int dh_energy_workspace_bytes(int C, int grid, int n_pairs, size_t* bytes) {
+  DH_REQUIRE(C >= 1 && grid >= 1 && n_pairs >= 0 && bytes, "bad arguments");
+  Arena a(nullptr, (size_t)-1);
+  EnergyWs w;
+  carve_energy(a, C, grid, n_pairs, w);
+  *bytes = a.off + 256;
+  return DH_OK;
+}
+
+extern "C" int dh_energy_fwd_bwd(const void* cur, const void* orig, int dtype, int C, int h_in, int w_in, int grid,
+                                 const int32_t* pairs, int n_pairs, const int32_t* bg_both, int n_bg_both,
+                                 const int32_t* bg_orig, int n_bg_orig, const int32_t* bg_trans, int n_bg_trans,
+                                 float fg_w, float bg_w, int fg_patch, int bg_patch, int bg_mode, float grad_scale,
+                                 float* loss_out, void* grad, int grad_dtype, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  DH_REQUIRE(cur && orig && loss_out && grad && workspace, "null pointer");
+  DH_REQUIRE(C >= 1 && h_in >= 1 && w_in >= 1 && grid >= 1, "bad sizes");
+  DH_REQUIRE(fg_patch >= 1 && (fg_patch & 1) && bg_patch >= 1 && (bg_patch & 1), "patch sizes must be odd");
+  DH_REQUIRE(bg_mode == 0 || bg_mode == 1, "unknown background loss type");
+  DH_REQUIRE(dtype >= 0 && dtype <= 2 && grad_dtype >= 0 && grad_dtype <= 2, "bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const int G2 = grid * grid;
+  Arena a(workspace, workspace_bytes);
+  EnergyWs w;
+  DH_REQUIRE(carve_energy(a, C, grid, n_pairs, w), "workspace too small");
+
+  switch (dtype) {
+    case DH_DTYPE_F16: launch_load<f16>(cur, w.cur, C, h_in, w_in, grid, st); launch_load<f16>(orig, w.orig, C, h_in, w_in, grid, st); break;
+    case DH_DTYPE_BF16: launch_load<bf16>(cur, w.cur, C, h_in, w_in, grid, st); launch_load<bf16>(orig, w.orig, C, h_in, w_in, grid, st); break;
+    default: launch_load<float>(cur, w.cur, C, h_in, w_in, grid, st); launch_load<float>(orig, w.orig, C, h_in, w_in, grid, st); break;
+  }
+  DH_CHECK_HIP(hipMemsetAsync(w.acc, 0, (size_t)G2 * C * sizeof(float), st));
+  DH_CHECK_HIP(hipMemsetAsync(w.fg_part, 0, G2 * sizeof(double), st));
+  DH_CHECK_HIP(hipMemsetAsync(w.bg_part, 0, G2 * sizeof(double), st));
+
+  float fg_norm = 0.f, bg_norm = 0.f;
+  int n_fg_part = 0, n_bg_part = 0;
+  if (n_pairs > 0) {   // n == 0 would be NaN in the reference (mean over an empty axis): skipped here
+    DH_REQUIRE(pairs, "null pairs");
+    fg_norm = 1.f / ((float)C * (float)n_pairs);
+    pair_term(w, pairs, n_pairs, C, grid, fg_patch, fg_w * fg_norm, w.fg_part, st);
+    n_fg_part = G2;
+  }
+  if (bg_mode == 0) {
+    if (n_bg_orig > 0 && n_bg_trans > 0) {
+      DH_REQUIRE(bg_orig && bg_trans, "null bg list");
+      hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 256), COLSUM_S), dim3(256), 0, st, w.orig, bg_orig, n_bg_orig, C,
+                         COLSUM_S, w.part1);
+      hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 256), COLSUM_S), dim3(256), 0, st, w.cur, bg_trans, n_bg_trans, C,
+                         COLSUM_S, w.part2);
+      hipLaunchKernelGGL(k_global_diff, dim3(1), dim3(256), 0, st, w.part1, w.part2, COLSUM_S, C, n_bg_orig,
+                         n_bg_trans, w.sgn, w.bg_part);
+      bg_norm = 1.f / (float)C;
+      hipLaunchKernelGGL(k_global_apply, dim3(n_bg_trans), dim3(256), 0, st, bg_trans, n_bg_trans, w.sgn, C,
+                         bg_w * bg_norm / (float)n_bg_trans, w.acc);
+      n_bg_part = 1;
+    }
+  } else if (n_bg_both > 0) {
+    DH_REQUIRE(bg_both, "null bg list");
+    hipLaunchKernelGGL(k_identity_pairs, dim3(cdiv(n_bg_both, 256)), dim3(256), 0, st, bg_both, n_bg_both, w.idpairs);
+    bg_norm = 1.f / ((float)C * (float)n_bg_both);
+    pair_term(w, w.idpairs, n_bg_both, C, grid, bg_patch, bg_w * bg_norm, w.bg_part, st);
+    n_bg_part = G2;
+  }
+  hipLaunchKernelGGL(k_final_loss, dim3(1), dim3(256), 0, st, w.fg_part, n_fg_part, fg_norm, w.bg_part, n_bg_part,
+                     bg_norm, fg_w, bg_w, loss_out);
+  switch (grad_dtype) {
+    case DH_DTYPE_F16: launch_store<f16>(w.acc, grad, C, h_in, w_in, grid, grad_scale, st); break;
+    case DH_DTYPE_BF16: launch_store<bf16>(w.acc, grad, C, h_in, w_in, grid, grad_scale, st); break;
+    default: launch_store<float>(w.acc, grad, C, h_in, w_in, grid, grad_scale, st); break;
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}

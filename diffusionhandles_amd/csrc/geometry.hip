@@ -1,0 +1,504 @@
+// Depth re-projection kernels for gfx950: unproject -> SE(3) -> project -> two-pass
+// 64-bit atomic z-buffer -> mask morphology -> ordered compaction of correspondences ->
+// harmonic in-fill (single-workgroup f64 CG) -> normalised disparity.
+//
+// Arithmetic contract (bit-exact integer outputs vs oracle/depth_ref.py, which is pinned
+// to the reference depth_transform.py:198-747): float32 where NumPy/torch compute in
+// float32, float64 where they compute in float64, no FMA contraction (this TU is built
+// with -ffp-contract=off), divisions done in f64 and rounded once (innocuous double
+// rounding: 53 >= 2*24+2).
+#include "common.h"
+#include "compact.h"
+
+namespace dh {
+
+// ---------------------------------------------------------------------- point geometry
+__device__ __forceinline__ void unproject_px(const float* depth, int p, int res, const float* gx, const float* gy,
+                                             float ifx, float ify, float& X, float& Y, float& Z) {
+  int row = p / res, col = p - row * res;
+  float d = depth[p];
+  float ax = d * ifx;
+  float ay = d * ify;
+  X = -(ax * gx[col]);
+  Y = -(ay * gy[row]);
+  Z = d;
+}
+
+__global__ void k_unproject(const float* depth, int res, const float* gx, const float* gy, float ifx, float ify,
+                            float* pts) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= res * res) return;
+  float X, Y, Z;
+  unproject_px(depth, p, res, gx, gy, ifx, ify, X, Y, Z);
+  pts[3 * p + 0] = X;
+  pts[3 * p + 1] = Y;
+  pts[3 * p + 2] = Z;
+}
+
+// NumPy's mean over an [N,3] float32 array along axis 0: sequential float32 accumulation in
+// row order, then / float32(N).  One wave; lanes 0..2 own one coordinate each.
+__global__ void k_centroid(const float* depth, const int* fg_pix, int n, int res, const float* gx, const float* gy,
+                           float ifx, float ify, float* cen) {
+  int lane = threadIdx.x;
+  if (lane >= 3) return;
+  float acc = 0.f;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float X, Y, Z;
+      unproject_px(depth, fg_pix[i + k], res, gx, gy, ifx, ify, X, Y, Z);
+      v[k] = lane == 0 ? X : (lane == 1 ? Y : Z);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = acc + v[k];
+  }
+  for (; i < n; ++i) {
+    float X, Y, Z;
+    unproject_px(depth, fg_pix[i], res, gx, gy, ifx, ify, X, Y, Z);
+    acc = acc + (lane == 0 ? X : (lane == 1 ? Y : Z));
+  }
+  cen[lane] = (float)((double)acc / (double)(float)n);
+}
+
+__device__ __forceinline__ unsigned long long sortable_f64(double z) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(z);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unsort_f64(unsigned long long k) {
+  unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+struct Xf {
+  double ax, ay, az, c, s, tx, ty, tz;
+};
+
+// one thread per (edit, point): points [0,R2) are background pixels, [R2,R2+n_fg) foreground.
+__global__ void k_points(const float* depth, const float* bg_depth, const int* fg_pix, int n_fg, int res,
+                         const float* gx, const float* gy, float ifx, float ify, double fx, double fy,
+                         const Xf* xf, const float* cen, unsigned long long* zbuf, int* pix_out,
+                         unsigned long long* key_out) {
+  const int R2 = res * res, P = R2 + n_fg;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  if (i >= P) return;
+  double X, Y, Z;
+  if (i < R2) {
+    float x, y, z;
+    unproject_px(bg_depth, i, res, gx, gy, ifx, ify, x, y, z);
+    X = x; Y = y; Z = z;
+  } else {
+    float x, y, z;
+    unproject_px(depth, fg_pix[i - R2], res, gx, gy, ifx, ify, x, y, z);
+    const Xf t = xf[e];
+    const float c0 = cen[0], c1 = cen[1], c2 = cen[2];
+    const float q0 = x - c0, q1 = y - c1, q2 = z - c2;
+    const float a0 = (float)t.ax, a1 = (float)t.ay, a2 = (float)t.az;
+    const float cr0 = a1 * q2 - a2 * q1;
+    const float cr1 = a2 * q0 - a0 * q2;
+    const float cr2 = a0 * q1 - a1 * q0;
+    const float dt = (q0 * a0 + q1 * a1) + q2 * a2;
+    const double omc = 1.0 - t.c;
+    const double r0 = ((double)q0 * t.c + (double)cr0 * t.s) + (double)(a0 * dt) * omc;
+    const double r1 = ((double)q1 * t.c + (double)cr1 * t.s) + (double)(a1 * dt) * omc;
+    const double r2 = ((double)q2 * t.c + (double)cr2 * t.s) + (double)(a2 * dt) * omc;
+    X = (r0 + (double)c0) + t.tx;
+    Y = (r1 + (double)c1) + t.ty;
+    Z = (r2 + (double)c2) + t.tz;
+  }
+  const double m = (double)(res - 1);
+  double u = (fx * (-X)) / Z;
+  double v = (fy * (-Y)) / Z;
+  u = (u * 0.5 + 0.5) * m;
+  v = (v * 0.5 + 0.5) * m;
+  u = fmin(fmax(u, 0.0), m);
+  v = fmin(fmax(v, 0.0), m);
+  const int ui = (int)rint(u), vi = (int)rint(v);
+  const int pix = vi * res + ui;
+  const unsigned long long key = sortable_f64(Z);
+  pix_out[(size_t)e * P + i] = pix;
+  key_out[(size_t)e * P + i] = key;
+  atomicMin(&zbuf[(size_t)e * R2 + pix], key);
+}
+
+__global__ void k_resolve(int P, int R2, const unsigned long long* zbuf, const int* pix_arr,
+                          const unsigned long long* key_arr, int* owner) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  if (i >= P) return;
+  int pix = pix_arr[(size_t)e * P + i];
+  if (key_arr[(size_t)e * P + i] == zbuf[(size_t)e * R2 + pix]) atomicMin(&owner[(size_t)e * R2 + pix], i);
+}
+
+__device__ __forceinline__ unsigned int sortable_f32(float x) {
+  unsigned int b = __float_as_uint(x);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unsort_f32(unsigned int k) {
+  unsigned int b = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(b);
+}
+
+// per pixel: depth map, raw fg mask, raw disparity 1/z and its min/max keys
+__global__ void k_pixels(int R2, const unsigned long long* zbuf, const int* owner, float* zmap, uint8_t* raw_mask,
+                         float* disp, unsigned int* minmax) {
+  __shared__ unsigned int smin[4], smax[4];
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  unsigned int kmin = 0xffffffffu, kmax = 0u;
+  if (p < R2) {
+    size_t o = (size_t)e * R2 + p;
+    unsigned long long k = zbuf[o];
+    float z = (k == ~0ull) ? __uint_as_float(0x7f800000u) : (float)unsort_f64(k);
+    zmap[o] = z;
+    int w = owner[o];
+    raw_mask[o] = (k != ~0ull && w >= R2) ? 1 : 0;
+    float d = (float)(1.0 / (double)z);
+    disp[o] = d;
+    kmin = kmax = sortable_f32(d);
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    unsigned int a = __shfl_xor(kmin, s, 64), b = __shfl_xor(kmax, s, 64);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { smin[wv] = kmin; smax[wv] = kmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+      kmin = smin[i] < kmin ? smin[i] : kmin;
+      kmax = smax[i] > kmax ? smax[i] : kmax;
+    }
+    atomicMin(&minmax[2 * e], kmin);
+    atomicMax(&minmax[2 * e + 1], kmax);
+  }
+}
+
+__global__ void k_fg_vis(int n_fg, int R2, int P, int res, const int* pix_arr, const int* owner, uint8_t* vis,
+                         int* target_xy) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  if (j >= n_fg) return;
+  int i = R2 + j;
+  int pix = pix_arr[(size_t)e * P + i];
+  vis[(size_t)e * n_fg + j] = owner[(size_t)e * R2 + pix] == i ? 1 : 0;
+  target_xy[((size_t)e * n_fg + j) * 2 + 0] = pix % res;
+  target_xy[((size_t)e * n_fg + j) * 2 + 1] = pix / res;
+}
+
+// binary morphology with an explicit offset list; pixels outside the image are ignored.
+__global__ void k_morph(const uint8_t* src, uint8_t* dst, int res, const int2* offs, int n_off, int dilate) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  if (p >= res * res) return;
+  const uint8_t* s = src + (size_t)e * res * res;
+  int y = p / res, x = p - y * res;
+  int acc = dilate ? 0 : 1;
+  for (int k = 0; k < n_off; ++k) {
+    int yy = y + offs[k].y, xx = x + offs[k].x;
+    if (yy < 0 || yy >= res || xx < 0 || xx >= res) continue;
+    int v = s[yy * res + xx] ? 1 : 0;
+    acc = dilate ? (acc | v) : (acc & v);
+  }
+  dst[(size_t)e * res * res + p] = (uint8_t)acc;
+}
+
+__global__ void k_keep_flags(int n_fg, int R2, int P, const int* pix_arr, const uint8_t* vis, const uint8_t* clean,
+                             uint8_t* keep) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  if (j >= n_fg) return;
+  int pix = pix_arr[(size_t)e * P + R2 + j];
+  keep[(size_t)e * n_fg + j] = (vis[(size_t)e * n_fg + j] && clean[(size_t)e * R2 + pix]) ? 1 : 0;
+}
+
+__global__ void k_write_corr(int n_fg, int res, const int* fg_pix, const int* target_xy, const int* keep_idx,
+                             const int* counts, int count_stride, long long* corr) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  if (r >= counts[e * count_stride]) return;
+  int j = keep_idx[(size_t)e * n_fg + r];
+  int p = fg_pix[j];
+  long long* c = corr + ((size_t)e * n_fg + r) * 4;
+  c[0] = p % res;
+  c[1] = p / res;
+  c[2] = target_xy[((size_t)e * n_fg + j) * 2 + 0];
+  c[3] = target_xy[((size_t)e * n_fg + j) * 2 + 1];
+}
+
+__global__ void k_count_flags(const uint8_t* f, int n, int* out, int out_stride, int slot) {
+  __shared__ int sm[4];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  int c = (i < n && f[(size_t)e * n + i]) ? 1 : 0;
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sm[k];
+    if (t) atomicAdd(&out[e * out_stride + slot], t);
+  }
+}
+
+// normalise disparity in place and flag the pixels to in-fill (cleaned xor raw)
+__global__ void k_normalize(int R2, float* disp, const unsigned int* minmax, const float* bounds,
+                            const uint8_t* raw, const uint8_t* clean, uint8_t* inpaint) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = blockIdx.y;
+  if (p >= R2) return;
+  size_t o = (size_t)e * R2 + p;
+  float lo = bounds ? bounds[0] : unsort_f32(minmax[2 * e]);
+  float hi = bounds ? bounds[1] : unsort_f32(minmax[2 * e + 1]);
+  float t = disp[o] - lo;
+  t = 255.0f * t;
+  float den = hi - lo;
+  disp[o] = (float)((double)t / (double)den);
+  inpaint[o] = (clean[o] != 0) != (raw[o] != 0) ? 1 : 0;
+}
+
+// Harmonic in-fill: A x = b with A = 4 I - adjacency(masked), solved by CG in float64 by ONE
+// workgroup per edit (deterministic fixed-tree reductions).
+__global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const uint8_t* inpaint, const int* unk,
+                                                  const int* counts, int count_stride, int slot_n, int slot_it,
+                                                  double* vx, double* vr, double* vp, double* vq, int max_iter,
+                                                  double tol2, int* counts_out) {
+  __shared__ double sm[16];
+  const int e = blockIdx.x, R2 = res * res;
+  const int n = counts[e * count_stride + slot_n];
+  float* d = disp + (size_t)e * R2;
+  const uint8_t* mk = inpaint + (size_t)e * R2;
+  const int* U = unk + (size_t)e * R2;
+  double* x = vx + (size_t)e * R2;
+  double* r = vr + (size_t)e * R2;
+  double* p = vp + (size_t)e * R2;
+  double* q = vq + (size_t)e * R2;
+  if (n == 0) {
+    if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = 0;
+    return;
+  }
+  double part = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int pix = U[i], y = pix / res, xx = pix - y * res;
+    double b = 0.0;
+    if (y > 0 && !mk[pix - res]) b += (double)d[pix - res];
+    if (y < res - 1 && !mk[pix + res]) b += (double)d[pix + res];
+    if (xx > 0 && !mk[pix - 1]) b += (double)d[pix - 1];
+    if (xx < res - 1 && !mk[pix + 1]) b += (double)d[pix + 1];
+    x[pix] = 0.0;
+    r[pix] = b;
+    p[pix] = b;
+    part += b * b;
+  }
+  double rs = block_sum(part, sm);
+  const double bnorm = rs;
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    if (!(rs > tol2 * bnorm)) break;
+    __syncthreads();
+    part = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      int pix = U[i], y = pix / res, xx = pix - y * res;
+      double a = 4.0 * p[pix];
+      if (y > 0 && mk[pix - res]) a -= p[pix - res];
+      if (y < res - 1 && mk[pix + res]) a -= p[pix + res];
+      if (xx > 0 && mk[pix - 1]) a -= p[pix - 1];
+      if (xx < res - 1 && mk[pix + 1]) a -= p[pix + 1];
+      q[pix] = a;
+      part += p[pix] * a;
+    }
+    const double pq = block_sum(part, sm);
+    const double alpha = rs / pq;
+    part = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      int pix = U[i];
+      x[pix] += alpha * p[pix];
+      double rr = r[pix] - alpha * q[pix];
+      r[pix] = rr;
+      part += rr * rr;
+    }
+    const double rsn = block_sum(part, sm);
+    const double beta = rsn / rs;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      int pix = U[i];
+      p[pix] = r[pix] + beta * p[pix];
+    }
+    rs = rsn;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int pix = U[i];
+    d[pix] = (float)x[pix];
+  }
+  if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = it;
+}
+
+// OpenCV's classic MORPH_ELLIPSE rows, as (dx, dy) offsets from the anchor
+static int ellipse_offsets(int k, int2* out) {
+  int n = 0;
+  if (k <= 1) {
+    out[n++] = make_int2(0, 0);
+    return n;
+  }
+  const int r = k / 2, c = k / 2;
+  const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+  for (int i = 0; i < k; ++i) {
+    int dy = i - r;
+    if (abs(dy) > r) continue;
+    int dx = (int)nearbyint(c * sqrt((r * r - dy * dy) * inv_r2));
+    int j1 = c - dx > 0 ? c - dx : 0, j2 = c + dx + 1 < k ? c + dx + 1 : k;
+    for (int j = j1; j < j2; ++j) out[n++] = make_int2(j - c, i - r);
+  }
+  return n;
+}
+
+constexpr int MAX_OFFS = 4096;
+
+struct ReprojectWs {
+  Xf* xf;
+  float* cen;
+  unsigned long long* zbuf;
+  int* owner;
+  int* pix;
+  unsigned long long* key;
+  unsigned int* minmax;
+  uint8_t* tmp_a;
+  uint8_t* tmp_b;
+  uint8_t* keep;
+  uint8_t* inpaint;
+  int* keep_idx;
+  int* unk;
+  int* block_counts;
+  int2* offs_close;
+  int2* offs_open;
+  double *vx, *vr, *vp, *vq;
+};
+
+static bool carve(Arena& a, int res, int n_fg, int K, ReprojectWs& w) {
+  const size_t R2 = (size_t)res * res, P = R2 + n_fg;
+  w.xf = a.take<Xf>(K);
+  w.cen = a.take<float>(4);
+  w.zbuf = a.take<unsigned long long>(K * R2);
+  w.owner = a.take<int>(K * R2);
+  w.pix = a.take<int>(K * P);
+  w.key = a.take<unsigned long long>(K * P);
+  w.minmax = a.take<unsigned int>(2 * K);
+  w.tmp_a = a.take<uint8_t>(K * R2);
+  w.tmp_b = a.take<uint8_t>(K * R2);
+  w.keep = a.take<uint8_t>((size_t)K * (n_fg > 0 ? n_fg : 1));
+  w.inpaint = a.take<uint8_t>(K * R2);
+  w.keep_idx = a.take<int>((size_t)K * (n_fg > 0 ? n_fg : 1));
+  w.unk = a.take<int>(K * R2);
+  w.block_counts = a.take<int>((size_t)K * (cdiv((int)P, CP_TILE) + 1));
+  w.offs_close = a.take<int2>(MAX_OFFS);
+  w.offs_open = a.take<int2>(MAX_OFFS);
+  w.vx = a.take<double>(K * R2);
+  w.vr = a.take<double>(K * R2);
+  w.vp = a.take<double>(K * R2);
+  w.vq = a.take<double>(K * R2);
+  return a.ok();
+}
+
+}  // namespace dh
+
+using namespace dh;
+
+extern "C" int dh_reproject_workspace_bytes(int res, int n_fg, int n_edits, size_t* bytes) {
+  DH_REQUIRE(res >= 2 && n_fg >= 0 && n_edits >= 1 && bytes, "bad arguments");
+  Arena a(nullptr, (size_t)-1);
+  ReprojectWs w;
+  carve(a, res, n_fg, n_edits, w);
+  *bytes = a.off + 256;
+  return DH_OK;
+}
+
+extern "C" int dh_fg_pixel_list(const uint8_t* fg_mask, int res, int32_t* fg_pix, int32_t* n_fg_dev, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  DH_REQUIRE(fg_mask && fg_pix && n_fg_dev && workspace, "null pointer");
+  int n = res * res;
+  DH_REQUIRE(workspace_bytes >= (size_t)(cdiv(n, CP_TILE) + 1) * sizeof(int), "workspace too small");
+  compact(fg_mask, n, 1, 0, fg_pix, 0, n_fg_dev, 1, (int*)workspace, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_unproject(const float* depth, int res, const float* grid_x, const float* grid_y, float inv_fx,
+                            float inv_fy, float* points, void* stream) {
+  DH_REQUIRE(depth && grid_x && grid_y && points && res >= 2, "bad arguments");
+  hipLaunchKernelGGL(k_unproject, dim3(cdiv(res * res, 256)), dim3(256), 0, (hipStream_t)stream, depth, res, grid_x,
+                     grid_y, inv_fx, inv_fy, points);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_masked_centroid(const float* depth, const int32_t* fg_pix, int n_fg, int res, const float* grid_x,
+                                  const float* grid_y, float inv_fx, float inv_fy, float* centroid, void* stream) {
+  DH_REQUIRE(depth && fg_pix && centroid && n_fg > 0, "bad arguments");
+  hipLaunchKernelGGL(k_centroid, dim3(1), dim3(64), 0, (hipStream_t)stream, depth, fg_pix, n_fg, res, grid_x, grid_y,
+                     inv_fx, inv_fy, centroid);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, const int32_t* fg_pix, int n_fg, int res,
+                                  const float* grid_x, const float* grid_y, float inv_fx, float inv_fy, double fx,
+                                  double fy, int n_edits, const double* xforms_host, const float* bounds, float* zmap,
+                                  uint8_t* raw_mask, uint8_t* clean_mask, float* disparity, uint8_t* vis,
+                                  int32_t* target_xy, int64_t* corr, int32_t* counts, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  DH_REQUIRE(depth && bg_depth && fg_pix && grid_x && grid_y && xforms_host, "null input");
+  DH_REQUIRE(zmap && raw_mask && clean_mask && disparity && vis && target_xy && corr && counts, "null output");
+  DH_REQUIRE(res >= 2 && n_fg > 0 && n_edits >= 1, "bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int K = n_edits, R2 = res * res, P = R2 + n_fg;
+  Arena a(workspace, workspace_bytes);
+  ReprojectWs w;
+  DH_REQUIRE(carve(a, res, n_fg, K, w), "workspace too small");
+
+  int2 hc[MAX_OFFS], ho[MAX_OFFS];
+  const int kc = res / 50, ko = res / 250;
+  DH_REQUIRE(kc * kc <= MAX_OFFS && kc >= 1, "unsupported resolution for the close kernel");
+  const int nc = ellipse_offsets(kc, hc);
+  const int no = ellipse_offsets(ko < 1 ? 1 : ko, ho);
+  DH_CHECK_HIP(hipMemcpyAsync(w.offs_close, hc, nc * sizeof(int2), hipMemcpyHostToDevice, st));
+  DH_CHECK_HIP(hipMemcpyAsync(w.offs_open, ho, no * sizeof(int2), hipMemcpyHostToDevice, st));
+  DH_CHECK_HIP(hipMemcpyAsync(w.xf, xforms_host, K * sizeof(Xf), hipMemcpyHostToDevice, st));
+  DH_CHECK_HIP(hipMemsetAsync(w.zbuf, 0xff, (size_t)K * R2 * sizeof(unsigned long long), st));
+  DH_CHECK_HIP(hipMemsetAsync(w.owner, 0x7f, (size_t)K * R2 * sizeof(int), st));
+  DH_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)K * 4 * sizeof(int), st));
+  // minmax init: min slot = 0xffffffff, max slot = 0
+  DH_CHECK_HIP(hipMemsetAsync(w.minmax, 0, (size_t)2 * K * sizeof(unsigned int), st));
+  for (int e = 0; e < K; ++e) DH_CHECK_HIP(hipMemsetAsync(w.minmax + 2 * e, 0xff, sizeof(unsigned int), st));
+
+  hipLaunchKernelGGL(k_centroid, dim3(1), dim3(64), 0, st, depth, fg_pix, n_fg, res, grid_x, grid_y, inv_fx, inv_fy,
+                     w.cen);
+  hipLaunchKernelGGL(k_points, dim3(cdiv(P, 256), K), dim3(256), 0, st, depth, bg_depth, fg_pix, n_fg, res, grid_x,
+                     grid_y, inv_fx, inv_fy, fx, fy, w.xf, w.cen, w.zbuf, w.pix, w.key);
+  hipLaunchKernelGGL(k_resolve, dim3(cdiv(P, 256), K), dim3(256), 0, st, P, R2, w.zbuf, w.pix, w.key, w.owner);
+  hipLaunchKernelGGL(k_pixels, dim3(cdiv(R2, 256), K), dim3(256), 0, st, R2, w.zbuf, w.owner, zmap, raw_mask,
+                     disparity, w.minmax);
+  hipLaunchKernelGGL(k_fg_vis, dim3(cdiv(n_fg, 256), K), dim3(256), 0, st, n_fg, R2, P, res, w.pix, w.owner, vis,
+                     target_xy);
+  // CLOSE = dilate, erode ; OPEN = erode, dilate
+  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, raw_mask, w.tmp_a, res, w.offs_close, nc, 1);
+  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_a, w.tmp_b, res, w.offs_close, nc, 0);
+  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_b, w.tmp_a, res, w.offs_open, no, 0);
+  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_a, clean_mask, res, w.offs_open, no, 1);
+  hipLaunchKernelGGL(k_keep_flags, dim3(cdiv(n_fg, 256), K), dim3(256), 0, st, n_fg, R2, P, w.pix, vis, clean_mask,
+                     w.keep);
+  compact(w.keep, n_fg, K, n_fg, w.keep_idx, n_fg, counts + 0, 4, w.block_counts, st);
+  hipLaunchKernelGGL(k_write_corr, dim3(cdiv(n_fg, 256), K), dim3(256), 0, st, n_fg, res, fg_pix, target_xy,
+                     w.keep_idx, counts, 4, (long long*)corr);
+  hipLaunchKernelGGL(k_count_flags, dim3(cdiv(n_fg, 256), K), dim3(256), 0, st, vis, n_fg, counts, 4, 1);
+  hipLaunchKernelGGL(k_normalize, dim3(cdiv(R2, 256), K), dim3(256), 0, st, R2, disparity, w.minmax, bounds, raw_mask,
+                     clean_mask, w.inpaint);
+  compact(w.inpaint, R2, K, R2, w.unk, R2, counts + 2, 4, w.block_counts, st);
+  hipLaunchKernelGGL(k_cg_fill, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3, w.vx,
+                     w.vr, w.vp, w.vq, 20000, 1e-24, counts);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}

@@ -1,0 +1,187 @@
+/*
+ * diffhandles_hip.h -- C ABI of the MI355X (gfx950) native library behind the
+ * DiffusionHandles guided-denoising edit path.
+ *
+ * The reference (adobe-research/DiffusionHandles) has no FFI of its own: its boundary is
+ * the Python class API (diffhandles/diffusion_handles.py:15-166,
+ * guided_stable_diffuser.py:22-610, stable_null_inverter.py:12-181).  These entry points
+ * are what a ctypes binding of that path calls; each one cites the reference code whose
+ * arithmetic it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - return value 0 = ok, negative = error (dh_last_error() gives the text);
+ *   - no hidden device allocation on the hot path: callers pass workspaces whose size the
+ *     *_workspace_bytes() queries return.  Engine handles own their weights/workspaces.
+ *   - 16-bit activations are passed as raw uint16 storage; `dtype` says how to read them.
+ */
+#ifndef DIFFHANDLES_HIP_H
+#define DIFFHANDLES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_OK 0
+#define DH_ERR_ARG -1
+#define DH_ERR_HIP -2
+#define DH_ERR_STATE -3
+
+#define DH_DTYPE_F16 0
+#define DH_DTYPE_BF16 1
+#define DH_DTYPE_F32 2
+
+const char* dh_last_error(void);
+int dh_version(void);
+/* number of visible HIP devices (<=0: no GPU) */
+int dh_device_count(void);
+
+/* --------------------------------------------------------------------------------------
+ * Depth re-projection: unproject -> SE(3) about the masked centroid -> project ->
+ * z-buffer -> mask clean-up -> correspondence filter -> harmonic in-fill -> disparity.
+ * Replaces transform_depth_pc / depth_to_world_coords / transform_point_cloud /
+ * points_to_depth / poisson_solve / normalize_depth
+ * (depth_transform.py:198-363, 589-641, 461-533, 643-747, 535-587, 15-28) and the cv2
+ * morphology at :308-321, for a batch of n_edits rigid transforms of ONE image.
+ *
+ * xforms_host: n_edits x 8 doubles {ax, ay, az (unit axis, float32 values widened),
+ *              cos(theta), sin(theta), tx, ty, tz} prepared on the host with NumPy so the
+ *              transcendental values match the reference's.
+ * grid_x/grid_y: the float32 pixel-centre coordinates torch.linspace gives (device).
+ * Outputs per edit e (all device):
+ *   zmap[e][res*res]       f32  z-buffered depth (inf where empty)
+ *   raw_mask[e][res*res]   u8   pixel won by a foreground point
+ *   clean_mask[e][res*res] u8   after CLOSE(ellipse res/50) + OPEN(ellipse res/250)
+ *   disparity[e][res*res]  f32  255*(1/z - min)/(max - min), harmonically in-filled
+ *   vis[e][n_fg]           u8   foreground point j is the (z, index) winner of its pixel
+ *   target_xy[e][n_fg][2]  i32  projected pixel (x, y) of every foreground point
+ *   corr[e][n_fg][4]       i64  (ox, oy, tx, ty), first counts[e] rows valid, in
+ *                               row-major order of the original pixel
+ *   counts[e][4]           i32  {n_corr, n_visible, n_inpaint, cg_iterations}
+ * bounds: optional [2] f32 {lo, hi} normalisation bounds (use_input_depth_normalization),
+ *         NULL = per-edit min/max of the rendered disparity.
+ * ------------------------------------------------------------------------------------ */
+int dh_reproject_workspace_bytes(int res, int n_fg, int n_edits, size_t* bytes);
+int dh_fg_pixel_list(const uint8_t* fg_mask, int res, int32_t* fg_pix, int32_t* n_fg_dev,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int dh_reproject_edits(const float* depth, const float* bg_depth, const int32_t* fg_pix, int n_fg,
+                       int res, const float* grid_x, const float* grid_y, float inv_fx, float inv_fy,
+                       double fx, double fy, int n_edits, const double* xforms_host,
+                       const float* bounds,
+                       float* zmap, uint8_t* raw_mask, uint8_t* clean_mask, float* disparity,
+                       uint8_t* vis, int32_t* target_xy, int64_t* corr, int32_t* counts,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* unprojected points only (depth_to_world_coords), [res*res][3] f32 */
+int dh_unproject(const float* depth, int res, const float* grid_x, const float* grid_y,
+                 float inv_fx, float inv_fy, float* points, void* stream);
+/* masked centroid with NumPy's sequential float32 accumulation order (f32[3]) */
+int dh_masked_centroid(const float* depth, const int32_t* fg_pix, int n_fg, int res,
+                       const float* grid_x, const float* grid_y, float inv_fx, float inv_fy,
+                       float* centroid, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Correspondences -> grid x grid cell index lists.  Replaces
+ * GuidedStableDiffuser.process_correspondences (guided_stable_diffuser.py:490-584),
+ * including scipy.ndimage.binary_erosion (cross element, border 0).
+ *   corr [n][4] i64 (ox, oy, tx, ty) in pixels.
+ *   pairs [n][2] i32 (orig cell id, target cell id), first counts[0] valid, order kept
+ *   bg_lists [3][grid*grid] i32 cell ids (row-major nonzero order) of
+ *            {both, orig, trans} background masks; counts[1..3] = their lengths
+ *   bg_masks [3][grid*grid] u8
+ *   counts [4] i32
+ * ------------------------------------------------------------------------------------ */
+int dh_cells_workspace_bytes(int n, int grid, size_t* bytes);
+int dh_cells_from_correspondences(const int64_t* corr, int n, int img_res, int grid, int bg_erosion,
+                                  int32_t* pairs, int32_t* bg_lists, uint8_t* bg_masks, int32_t* counts,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Guidance energy (losses.py:4-84) on channels-last maps [h][w][C].
+ * One call evaluates, for ONE activation layer,
+ *     loss = fg_w * fg_term + bg_w * bg_term
+ * and writes d(loss * grad_scale)/d(cur) for every element (no accumulation, no atomics).
+ * cur/orig: [hw_in][C] in `dtype`; when hw_in != grid*grid the maps are bilinearly resized
+ * (align_corners=False) to grid x grid first and the gradient is carried back.
+ * bg_mode: 0 = global_avg, 1 = local_avg.  patch: fg/bg pooling window (odd, >=1).
+ * pairs/bg lists as produced by dh_cells_from_correspondences (device).
+ * loss_out: f32[3] = {loss, fg_term, bg_term}.  grad: same shape as cur, in `grad_dtype`.
+ * ------------------------------------------------------------------------------------ */
+int dh_energy_workspace_bytes(int C, int grid, int n_pairs, size_t* bytes);
+int dh_energy_fwd_bwd(const void* cur, const void* orig, int dtype, int C, int h_in, int w_in, int grid,
+                      const int32_t* pairs, int n_pairs,
+                      const int32_t* bg_both, int n_bg_both,
+                      const int32_t* bg_orig, int n_bg_orig,
+                      const int32_t* bg_trans, int n_bg_trans,
+                      float fg_w, float bg_w, int fg_patch, int bg_patch, int bg_mode,
+                      float grad_scale, float* loss_out, void* grad, int grad_dtype,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * SD-2-depth U-Net engine (model/unet_2d_condition.py:809-1198 and the block files it
+ * calls): forward with the three decoder activation captures, and the backward pass to the
+ * input sample / to the text embedding.  Channels-last 16-bit activations, f32 accumulate.
+ * ------------------------------------------------------------------------------------ */
+typedef struct dh_unet dh_unet;
+
+typedef struct dh_unet_config {
+  int in_channels;            /* 5 */
+  int out_channels;           /* 4 */
+  int n_levels;               /* 4 */
+  int block_out_channels[4];  /* 320 640 1280 1280 */
+  int layers_per_block;       /* 2 */
+  int heads[4];               /* 5 10 20 20 (head dim must be 64) */
+  int cross_attention_dim;    /* 1024 */
+  int norm_groups;            /* 32 */
+  int sample_size;            /* 64 (latent H = W) */
+  int text_len;               /* 77 */
+  int max_batch;              /* largest batch a forward will see */
+  int dtype;                  /* DH_DTYPE_F16 or DH_DTYPE_BF16 */
+} dh_unet_config;
+
+int dh_unet_create(const dh_unet_config* cfg, dh_unet** out);
+void dh_unet_destroy(dh_unet* u);
+/* parameter table: diffusers state-dict names, torch shapes */
+int dh_unet_num_params(const dh_unet* u);
+int dh_unet_param_info(const dh_unet* u, int i, const char** name, int* ndim, int64_t* shape4);
+/* upload parameter i from a DEVICE f32 tensor in torch layout (conv: [Cout,Cin,kh,kw]) */
+int dh_unet_load_param(dh_unet* u, int i, const float* src, void* stream);
+size_t dh_unet_weight_bytes(const dh_unet* u);
+size_t dh_unet_workspace_bytes(const dh_unet* u);
+
+/* forward.  sample [B][H][W][Cin] f32 channels-last; timestep host float; text [B][L][D] f32.
+ * eps_out [B][H][W][Cout] f32.  act_out[3] (may be NULL): [B][h][w][C] in engine dtype.
+ * save_for_backward != 0 keeps what dh_unet_backward needs (one saved pass at a time). */
+int dh_unet_forward(dh_unet* u, const float* sample, float timestep, const float* text, int batch,
+                    int save_for_backward, float* eps_out, void* const* act_out, void* stream);
+/* backward of the LAST saved forward.  d_act[3]: gradients w.r.t. the three captured
+ * activations (engine dtype, may be NULL each); d_eps: gradient w.r.t. eps (f32, may be
+ * NULL).  Outputs (either may be NULL): d_sample [B][H][W][Cin] f32, d_text [B][L][D] f32. */
+int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* d_sample, float* d_text,
+                     void* stream);
+/* per-kernel-class accumulated launch counts / algorithmic flops of the last forward */
+int dh_unet_stats(const dh_unet* u, double* flops_fwd, double* flops_bwd, int64_t* launches);
+
+/* --------------------------------------------------------------------------------------
+ * Loop arithmetic (f32 latents, channels-last [B][H][W][4]).
+ * ------------------------------------------------------------------------------------ */
+/* eps = eps_u + scale*(eps_c - eps_u); x <- sqrt(a_prev)*(x - sqrt(1-a_t) eps)/sqrt(a_t) +
+ * sqrt(1-a_prev) eps.   DDIMScheduler.step, eta 0 (guided_stable_diffuser.py:468-474) and
+ * prev_step/next_step (stable_null_inverter.py:25-43).  eps_u may be NULL (no CFG). */
+int dh_ddim_cfg_step(float* x_out, const float* x, const float* eps_u, const float* eps_c, float scale,
+                     float alpha_t, float alpha_prev, int n, void* stream);
+/* x_out = x - lr * g / grad_scale                         guided_stable_diffuser.py:434 */
+int dh_latent_update(float* x_out, const float* x, const float* g, float lr, float grad_scale, int n,
+                     void* stream);
+/* Adam step on the null-text embedding (torch defaults; stable_null_inverter.py:143-155) */
+int dh_adam_step(float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                 float eps, int step, int n, void* stream);
+/* mse(rec, target) and d mse / d rec                        stable_null_inverter.py:152 */
+int dh_mse_fwd_bwd(const float* rec, const float* target, int n, float* loss_out, float* d_rec,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -135,7 +135,7 @@ def _eps_single(unet, x, depth64, t, ctx):
 
 
 def null_text_inversion(unet, sched, latent0, disparity, uncond0, cond, num_inner_steps=5, eps0=1e-5,
-                        num_steps=50):
+                        num_steps=50, null_steps=None):
     """Returns (ddim_latents list[51], uncond [50,1,77,C])."""
     sched.set_timesteps(num_steps)
     s = unet.config.sample_size
@@ -150,7 +150,7 @@ def null_text_inversion(unet, sched, latent0, disparity, uncond0, cond, num_inne
     unc = uncond0
     out = []
     cur = lat[-1]
-    for i in range(num_steps):
+    for i in range(num_steps if null_steps is None else null_steps):
         unc = unc.clone().detach().requires_grad_(True)
         opt = torch.optim.Adam([unc], lr=1e-2 * (1.0 - i / 100.0))
         target = lat[len(lat) - i - 2]
