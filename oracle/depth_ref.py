@@ -226,7 +226,7 @@ def clean_mask(raw_mask_bool, img_res):
     """CLOSE with ellipse(res//50) then OPEN with ellipse(res//250) on a {0,255} mask."""
     m = raw_mask_bool.astype(np.uint8) * 255
     kc = ellipse_kernel(img_res // 50, img_res // 50)
-    ko = ellipse_kernel(img_res // 250, img_res // 250)
+    ko = ellipse_kernel(max(img_res // 250, 1), max(img_res // 250, 1))   # cv2 rejects a 0x0 kernel (res < 250)
     return morph_open(morph_close(m, kc), ko)
 
 

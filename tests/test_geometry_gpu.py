@@ -62,11 +62,11 @@ def test_batched_edits_bit_exact_vs_golden_and_oracle(golden):
 
 
 def test_general_axis_and_small_res_vs_oracle():
-    """res 64 scene, non axis-aligned rotation: <= a handful of differing map entries allowed
+    """res 256 scene, non axis-aligned rotation: <= a handful of differing map entries allowed
     (np.dot goes through BLAS on the oracle side)."""
     from oracle import depth_ref as D
     from diffusionhandles_amd import depth_transform as DT
-    depth, bg, mask = make_scene(100)
+    depth, bg, mask = make_scene(256)
     K = D.intrinsics_f32()
     dev = _dev()
     axis = torch.tensor([0.3, 0.9, -0.2])
@@ -84,7 +84,7 @@ def test_general_axis_and_small_res_vs_oracle():
 def test_edge_cases_empty_mask_and_input_normalisation():
     from oracle import depth_ref as D
     from diffusionhandles_amd import depth_transform as DT
-    depth, bg, mask = make_scene(128)
+    depth, bg, mask = make_scene(256)
     K = D.intrinsics_f32()
     dev = _dev()
     disp, corr = DT.transform_depth(depth.to(dev), bg.to(dev), torch.zeros_like(mask).to(dev), K)
