@@ -59,6 +59,18 @@ SIGNATURES = {
     "dh_mse_fwd_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
 }
 
+# test hooks (csrc/debug_api.cpp): single-kernel entry points used only by tests/
+c_l = ctypes.c_long
+DEBUG_SIGNATURES = {
+    "dh_dbg_gemm": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i,
+                          c_p, c_l, c_p, c_l, c_i, c_p, c_sz, c_p]),
+    "dh_dbg_groupnorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "dh_dbg_layernorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    "dh_dbg_geglu": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "dh_dbg_attention": (c_i, [c_i, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dh_dbg_pool2x2": (c_i, [c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+}
+
 
 def lib():
     """Load the shared library once; raise loudly if it has not been built."""
@@ -70,7 +82,7 @@ def lib():
                 "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
         handle = ctypes.CDLL(LIB_PATH)
         missing = []
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             try:
                 fn = getattr(handle, name)
             except AttributeError:

@@ -1,0 +1,354 @@
+// Flash attention for head dim 64 on gfx950 MFMA (v_mfma_f32_32x32x16), forward + backward.
+//
+// Everything is computed TRANSPOSED so that softmax statistics are per-lane scalars:
+//   S^T = K Q^T   : A operand = K rows from LDS, B operand = Q fragment in registers
+//                   -> accumulator rows = keys (spread over the 16 registers and the two
+//                      lane halves), column = query = lane & 31
+//   O^T += V^T P^T: the accumulator layout of P^T is, register-for-register, a valid B
+//                   operand (k = keys) as long as the A operand (V^T, read from a transposed
+//                   LDS tile) enumerates the keys in the same order -- slot j of lane half hi
+//                   in MFMA step s is key 16 s + 8 (j >> 2) + 4 hi + (j & 3).
+// The backward kernels use the same two product shapes (one with the roles of keys and
+// queries exchanged).  dQ and dK/dV are separate kernels (no atomics, deterministic).
+#include "unet_kernels.h"
+
+namespace dh {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 v8b __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <class T> struct Mma;
+template <> struct Mma<f16> {
+  static __device__ __forceinline__ v16f run(uint4 a, uint4 b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16> {
+  static __device__ __forceinline__ v16f run(uint4 a, uint4 b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8b, a), __builtin_bit_cast(v8b, b), c, 0, 0, 0);
+  }
+};
+
+constexpr int HD = 64;        // head dim
+constexpr int TLD = 72;       // LDS row stride in halves
+constexpr int TILE = 64 * TLD;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float SCALE = 0.125f;   // 1/sqrt(64)
+
+__device__ __forceinline__ v16f zero16() {
+  v16f z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// 4 register fragments (k = d) of row `row` of a [rows][ld] matrix at column col0: B-operand layout
+template <class T>
+__device__ __forceinline__ void load_row_frags(const T* base, long ld, long row, bool ok, int col0, int hi, uint4 (&f)[4]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    f[kk] = ok ? *reinterpret_cast<const uint4*>(base + row * ld + col0 + 16 * kk + 8 * hi) : make_uint4(0, 0, 0, 0);
+}
+
+// stage a 64 x 64 tile (rows row0.., cols col0..col0+63) row-major into `rm` and/or transposed into `tr`
+template <class T>
+__device__ __forceinline__ void stage_tile(const T* base, long ld, long row0, long rows_total, int col0,
+                                           unsigned short* rm, unsigned short* tr) {
+  const int t = threadIdx.x, chunk = t & 7;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (t >> 3) + 32 * j;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + r < rows_total) v = *reinterpret_cast<const uint4*>(base + (row0 + r) * ld + col0 + chunk * 8);
+    if (rm) *reinterpret_cast<uint4*>(&rm[r * TLD + chunk * 8]) = v;
+    if (tr) {
+      const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tr[(chunk * 8 + i) * TLD + r] = e[i];
+    }
+  }
+}
+
+// acc = sum_kk mfma(A = rows (rowbase + lane&31) of an LDS row-major tile, B = register fragments)
+template <class T>
+__device__ __forceinline__ v16f tile_times_frags(const unsigned short* tile, int rowbase, int ln, int hi, const uint4 (&f)[4]) {
+  v16f acc = zero16();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const uint4 a = *reinterpret_cast<const uint4*>(&tile[(rowbase + ln) * TLD + 16 * kk + 8 * hi]);
+    acc = Mma<T>::run(a, f[kk], acc);
+  }
+  return acc;
+}
+
+// A operand from a TRANSPOSED tile: row = drow, reduction slots (step s within a 32-block at kbase)
+__device__ __forceinline__ uint4 tr_frag(const unsigned short* tr, int drow, int kbase, int s, int hi) {
+  const uint2 lo = *reinterpret_cast<const uint2*>(&tr[drow * TLD + kbase + 16 * s + 4 * hi]);
+  const uint2 hi2 = *reinterpret_cast<const uint2*>(&tr[drow * TLD + kbase + 16 * s + 8 + 4 * hi]);
+  return make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+}
+
+// registers 8s..8s+7 of an accumulator -> B operand (16-bit)
+template <class T>
+__device__ __forceinline__ uint4 pack8(const v16f& p, int s) {
+  T o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(p[8 * s + j]);
+  return *reinterpret_cast<uint4*>(o);
+}
+
+// store a transposed accumulator pair (rows = d, col = lane's row) as row `row` of a [rows][ld] matrix
+template <class T>
+__device__ __forceinline__ void store_rows_t(T* base, long ld, long row, int col0, int hi, const v16f (&acc)[2], float mul) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      T o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(acc[dt][4 * g + i] * mul);
+      *reinterpret_cast<uint2*>(base + row * ld + col0 + dt * 32 + 8 * g + 4 * hi) = *reinterpret_cast<uint2*>(o);
+    }
+}
+
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ------------------------------------------------------------------------------- forward
+template <class T>
+__global__ void __launch_bounds__(256) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
+                                                  float* lse, int H, int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) unsigned short sK[TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short sVt[TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
+  const bool qok = qrow < Nq;
+  uint4 qf[4];
+  load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
+  v16f oacc[2] = {zero16(), zero16()};
+  float m_run = -INFINITY, l_run = 0.f;
+  const T* kb = k + (long)b * Nk * ldk;
+  const T* vb = v + (long)b * Nk * ldk;
+  for (int k0 = 0; k0 < Nk; k0 += 64) {
+    __syncthreads();
+    stage_tile<T>(kb, ldk, k0, Nk, h * HD, sK, nullptr);
+    stage_tile<T>(vb, ldk, k0, Nk, h * HD, nullptr, sVt);
+    __syncthreads();
+    v16f s[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      s[t2] = tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + t2 * 32 + acc_row(r, hi);
+        const float x = key < Nk ? s[t2][r] * (SCALE * LOG2E) : -INFINITY;
+        s[t2][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(s[t2][r] - m_new);
+        s[t2][r] = p;
+        rs += p;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const uint4 pf = pack8<T>(s[t2], st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          oacc[dt] = Mma<T>::run(tr_frag(sVt, dt * 32 + ln, t2 * 32, st, hi), pf, oacc[dt]);
+      }
+  }
+  if (qok) {
+    store_rows_t<T>(o + (long)b * Nq * ldo, ldo, qrow, h * HD, hi, oacc, 1.f / l_run);
+    if (lse && hi == 0) lse[((long)b * H + h) * Nq + qrow] = (m_run + log2f(l_run)) * LN2;
+  }
+}
+
+template <class T>
+__global__ void k_attn_delta(const T* o, long ldo, const T* d_o, long lddo, float* delta, int H, int Nq, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*Nq
+  if (idx >= total) return;
+  const long qrow = idx % Nq;
+  const int h = (int)((idx / Nq) % H);
+  const long b = idx / ((long)Nq * H);
+  const T* po = o + (b * Nq + qrow) * ldo + h * HD;
+  const T* pd = d_o + (b * Nq + qrow) * lddo + h * HD;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint4 a = *reinterpret_cast<const uint4*>(po + c * 8), d = *reinterpret_cast<const uint4*>(pd + c * 8);
+    const T* av = reinterpret_cast<const T*>(&a);
+    const T* dv = reinterpret_cast<const T*>(&d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += to_f32<T>(av[i]) * to_f32<T>(dv[i]);
+  }
+  delta[idx] = s;
+}
+
+// ---------------------------------------------------------------------------- backward dQ
+template <class T>
+__global__ void __launch_bounds__(256) k_attn_bwd_dq(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
+                                                     long lddo, const float* lse, const float* delta, T* dq, long lddq,
+                                                     int H, int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) unsigned short sK[TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short sV[TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short sKt[TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
+  const bool qok = qrow < Nq;
+  uint4 qf[4], dof[4];
+  load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
+  load_row_frags<T>(d_o + (long)b * Nq * lddo, lddo, qrow, qok, h * HD, hi, dof);
+  const float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;
+  const float del_q = qok ? delta[((long)b * H + h) * Nq + qrow] : 0.f;
+  v16f dqacc[2] = {zero16(), zero16()};
+  const T* kb = k + (long)b * Nk * ldk;
+  const T* vb = v + (long)b * Nk * ldk;
+  for (int k0 = 0; k0 < Nk; k0 += 64) {
+    __syncthreads();
+    stage_tile<T>(kb, ldk, k0, Nk, h * HD, sK, sKt);
+    stage_tile<T>(vb, ldk, k0, Nk, h * HD, sV, nullptr);
+    __syncthreads();
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      v16f s = tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
+      const v16f dp = tile_times_frags<T>(sV, t2 * 32, ln, hi, dof);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + t2 * 32 + acc_row(r, hi);
+        const float p = key < Nk ? exp2f(s[r] * (SCALE * LOG2E) - lse_q) : 0.f;
+        s[r] = p * (dp[r] - del_q) * SCALE;
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const uint4 dsf = pack8<T>(s, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dqacc[dt] = Mma<T>::run(tr_frag(sKt, dt * 32 + ln, t2 * 32, st, hi), dsf, dqacc[dt]);
+      }
+    }
+  }
+  if (qok) store_rows_t<T>(dq + (long)b * Nq * lddq, lddq, qrow, h * HD, hi, dqacc, 1.f);
+}
+
+// ------------------------------------------------------------------------- backward dK, dV
+template <class T>
+__global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
+                                                      long lddo, const float* lse, const float* delta, T* dk, T* dv,
+                                                      long lddk, int H, int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) unsigned short sQ[TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short sdO[TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short sQt[TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short sdOt[TILE];
+  __shared__ float sLse[64], sDel[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long krow = (long)blockIdx.x * 128 + wave * 32 + ln;
+  const bool kok = krow < Nk;
+  uint4 kf[4], vf[4];
+  load_row_frags<T>(k + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, kf);
+  load_row_frags<T>(v + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, vf);
+  v16f dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
+  const T* qb = q + (long)b * Nq * ldq;
+  const T* dob = d_o + (long)b * Nq * lddo;
+  for (int q0 = 0; q0 < Nq; q0 += 64) {
+    __syncthreads();
+    stage_tile<T>(qb, ldq, q0, Nq, h * HD, sQ, sQt);
+    stage_tile<T>(dob, lddo, q0, Nq, h * HD, sdO, sdOt);
+    if (threadIdx.x < 64) {
+      const long qr = q0 + threadIdx.x;
+      sLse[threadIdx.x] = qr < Nq ? lse[((long)b * H + h) * Nq + qr] * LOG2E : INFINITY;
+      sDel[threadIdx.x] = qr < Nq ? delta[((long)b * H + h) * Nq + qr] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      v16f s = tile_times_frags<T>(sQ, t2 * 32, ln, hi, kf);      // rows = queries, col = key
+      const v16f dp = tile_times_frags<T>(sdO, t2 * 32, ln, hi, vf);
+      v16f ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = t2 * 32 + acc_row(r, hi);
+        const float p = exp2f(s[r] * (SCALE * LOG2E) - sLse[ql]);
+        s[r] = p;
+        ds[r] = p * (dp[r] - sDel[ql]) * SCALE;
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const uint4 pf = pack8<T>(s, st), dsf = pack8<T>(ds, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dvacc[dt] = Mma<T>::run(tr_frag(sdOt, dt * 32 + ln, t2 * 32, st, hi), pf, dvacc[dt]);
+          dkacc[dt] = Mma<T>::run(tr_frag(sQt, dt * 32 + ln, t2 * 32, st, hi), dsf, dkacc[dt]);
+        }
+      }
+    }
+  }
+  if (kok) {
+    store_rows_t<T>(dk + (long)b * Nk * lddk, lddk, krow, h * HD, hi, dkacc, 1.f);
+    store_rows_t<T>(dv + (long)b * Nk * lddk, lddk, krow, h * HD, hi, dvacc, 1.f);
+  }
+}
+
+// ------------------------------------------------------------------------------ launchers
+void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o, long ldo,
+                          float* lse, int B, int H, int Nq, int Nk, hipStream_t st) {
+  dim3 grid(cdiv(Nq, 128), H, B);
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_attn_fwd<f16>), grid, dim3(256), 0, st, (const f16*)q, ldq, (const f16*)k, (const f16*)v, ldk, (f16*)o, ldo, lse, H, Nq, Nk);
+  else
+    hipLaunchKernelGGL((k_attn_fwd<bf16>), grid, dim3(256), 0, st, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldk, (bf16*)o, ldo, lse, H, Nq, Nk);
+}
+
+void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o, long lddo, float* delta, int B, int H,
+                            int Nq, hipStream_t st) {
+  const long total = (long)B * H * Nq;
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_attn_delta<f16>), dim3(nb), dim3(256), 0, st, (const f16*)o, ldo, (const f16*)d_o, lddo, delta, H, Nq, total);
+  else
+    hipLaunchKernelGGL((k_attn_delta<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)o, ldo, (const bf16*)d_o, lddo, delta, H, Nq, total);
+}
+
+void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* d_o,
+                             long lddo, const float* lse, const float* delta, void* dq, long lddq, int B, int H, int Nq,
+                             int Nk, hipStream_t st) {
+  dim3 grid(cdiv(Nq, 128), H, B);
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_attn_bwd_dq<f16>), grid, dim3(256), 0, st, (const f16*)q, ldq, (const f16*)k, (const f16*)v, ldk, (const f16*)d_o, lddo, lse, delta, (f16*)dq, lddq, H, Nq, Nk);
+  else
+    hipLaunchKernelGGL((k_attn_bwd_dq<bf16>), grid, dim3(256), 0, st, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldk, (const bf16*)d_o, lddo, lse, delta, (bf16*)dq, lddq, H, Nq, Nk);
+}
+
+void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* d_o,
+                              long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk, int B,
+                              int H, int Nq, int Nk, hipStream_t st) {
+  dim3 grid(cdiv(Nk, 128), H, B);
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_attn_bwd_dkv<f16>), grid, dim3(256), 0, st, (const f16*)q, ldq, (const f16*)k, (const f16*)v, ldk, (const f16*)d_o, lddo, lse, delta, (f16*)dk, (f16*)dv, lddk, H, Nq, Nk);
+  else
+    hipLaunchKernelGGL((k_attn_bwd_dkv<bf16>), grid, dim3(256), 0, st, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldk, (const bf16*)d_o, lddo, lse, delta, (bf16*)dk, (bf16*)dv, lddk, H, Nq, Nk);
+}
+
+}  // namespace dh

@@ -1,0 +1,60 @@
+// Test hooks: C-ABI wrappers around the individual kernel launchers so that the GPU parity
+// tests can check each kernel against a torch fp32 reference in isolation.  Not used by the
+// product path.
+#include "unet_kernels.h"
+using namespace dh;
+
+extern "C" int dh_dbg_gemm(int dtype, const void* A, long lda, const void* W, int M, int N, int K, int mode, int Hin,
+                           int Win, int Cin, int Hout, int Wout, int stride, int up, const float* bias,
+                           const float* rowvec, int rowvec_ld, int rows_per_batch, const void* R, long ldr, void* C,
+                           long ldc, int act_silu, float* partial, size_t partial_elems, void* stream) {
+  DH_REQUIRE(A && W && C && K % 64 == 0 && N % 4 == 0, "bad arguments");
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.mode = mode; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
+  g.Hout = Hout; g.Wout = Wout; g.stride = stride; g.up = up; g.bias = bias; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld;
+  g.rows_per_batch = rows_per_batch; g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc; g.act_silu = act_silu;
+  g.partial = partial; g.partial_elems = partial_elems;
+  launch_gemm(dtype, g, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+extern "C" int dh_dbg_groupnorm(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                const void* dy, void* dx, float* scratch, int B, int HW, int C, int G, float eps,
+                                int silu, int accumulate, void* stream) {
+  launch_groupnorm_fwd(dtype, x, gamma, beta, y, stats, scratch, B, HW, C, G, eps, silu, (hipStream_t)stream);
+  if (dy && dx)
+    launch_groupnorm_bwd(dtype, x, dy, gamma, beta, stats, dx, scratch, B, HW, C, G, silu, accumulate, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+extern "C" int dh_dbg_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                const void* dy, const void* add, void* dx, int rows, int C, float eps, void* stream) {
+  launch_layernorm_fwd(dtype, x, gamma, beta, y, stats, rows, C, eps, (hipStream_t)stream);
+  if (dy && dx) launch_layernorm_bwd(dtype, x, dy, gamma, stats, add, dx, rows, C, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+extern "C" int dh_dbg_geglu(int dtype, const void* x, void* y, const void* dy, void* dx, int rows, int F, void* stream) {
+  launch_geglu_fwd(dtype, x, y, rows, F, (hipStream_t)stream);
+  if (dy && dx) launch_geglu_bwd(dtype, x, dy, dx, rows, F, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+extern "C" int dh_dbg_attention(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
+                                long ldo, float* lse, const void* d_o, float* delta, void* dq, void* dk, void* dv,
+                                int B, int H, int Nq, int Nk, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  launch_attention_fwd(dtype, q, ldq, k, v, ldk, o, ldo, lse, B, H, Nq, Nk, st);
+  if (d_o) {
+    launch_attention_delta(dtype, o, ldo, d_o, ldo, delta, B, H, Nq, st);
+    if (dq) launch_attention_bwd_dq(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dq, ldq, B, H, Nq, Nk, st);
+    if (dk && dv) launch_attention_bwd_dkv(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dk, dv, ldk, B, H, Nq, Nk, st);
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+extern "C" int dh_dbg_pool2x2(int dtype, const void* src, void* dst, int B, int h, int w, int C, int accumulate, void* stream) {
+  launch_pool2x2_sum(dtype, src, dst, B, h, w, C, accumulate, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}

@@ -1,0 +1,281 @@
+// MFMA implicit-GEMM for gfx950:  D[m][n] = sum_k A(m,k) * W[n][k]  (+ epilogue)
+//
+//   A(m,k): dense rows, or the im2col view of a channels-last image for a 3x3 convolution
+//           (stride 1/2, optional nearest-2x upsampled source), or the transposed-stride-2
+//           view used by the input-gradient of a stride-2 convolution.  K is ordered
+//           (tap, channel) so a 64-wide K tile lies inside one tap: the gather is a row of
+//           64 contiguous channels of a shifted pixel (zero outside the image).
+//   W:      [N][K] with K contiguous (torch Linear layout; conv weights are re-laid to
+//           [Cout][ky][kx][Cin] at load time).
+//
+// 256 threads = 4 waves (2 x 2).  Per K tile of 64: global -> registers (issued one tile
+// ahead, T14 split) -> LDS rows padded to 72 halves (conflict-free ds_read_b128) ->
+// v_mfma_f32_32x32x16 with the operands SWAPPED (W is the A operand), so a lane owns one
+// output row m and 4 consecutive n per accumulator group: 8-byte stores, per-lane row
+// scalars.  f32 accumulate; optional split-K through f32 partial slabs + a reduce kernel
+// that applies the same epilogue.
+#include "unet_kernels.h"
+
+namespace dh {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 v8b __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <class T> struct Mfma;
+template <> struct Mfma<f16> {
+  static __device__ __forceinline__ v16f run(uint4 a, uint4 b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<bf16> {
+  static __device__ __forceinline__ v16f run(uint4 a, uint4 b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8b, a), __builtin_bit_cast(v8b, b), c, 0, 0, 0);
+  }
+};
+
+struct GemmK {   // kernel-side copy of GemmArgs (plain data)
+  const void* A; long lda;
+  const void* W;
+  int M, N, K;
+  int mode, Hin, Win, Cin, Hout, Wout, stride, up;
+  const float* bias;
+  const float* rowvec; int rowvec_ld; int rows_per_batch;
+  const void* R; long ldr;
+  void* C; long ldc;
+  int act_silu;
+  float* partial;
+  int splits, k_per_split;
+};
+
+constexpr int BK = 64;
+constexpr int LDS_LD = 72;   // halves per LDS row (64 + 8 pad): 144 B, rows 9 sixteen-byte slots apart
+
+template <class T>
+__device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0, v1, v2, v3};
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.rowvec) {
+    const float4 b = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.act_silu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
+  }
+  if (p.R) {
+    const T* r = reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n;
+    uint2 raw = *reinterpret_cast<const uint2*>(r);
+    const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += to_f32<T>(rv[i]);
+  }
+  T o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(v[i]);
+  *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = *reinterpret_cast<uint2*>(o);
+}
+
+template <class T, int BM, int BN>
+__global__ void __launch_bounds__(256) k_gemm(const GemmK p) {
+  constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 tiles per wave along m and n
+  constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte chunks per thread per K tile
+  __shared__ __attribute__((aligned(16))) unsigned short sA[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short sB[BN * LDS_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  int kend = kbeg + p.k_per_split;
+  if (kend > p.K) kend = p.K;
+  const int ntiles = (kend - kbeg) / BK;
+
+  const int lrow = tid >> 3, chunk = tid & 7;
+  const T* Ag = reinterpret_cast<const T*>(p.A);
+  const T* Wg = reinterpret_cast<const T*>(p.W);
+
+  // per-thread A row descriptors
+  bool a_ok[RA];
+  long a_base[RA];      // dense: element offset of the row; conv: pixel index of batch start
+  int a_oy[RA], a_ox[RA];
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int m = m0 + lrow + 32 * j;
+    a_ok[j] = m < p.M;
+    if (p.mode == A_DENSE) {
+      a_base[j] = (long)m * p.lda;
+      a_oy[j] = a_ox[j] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int b = m / hw, r = m - b * hw;
+      a_oy[j] = r / p.Wout;
+      a_ox[j] = r - a_oy[j] * p.Wout;
+      a_base[j] = (long)b * p.Hin * p.Win;
+    }
+  }
+  bool b_ok[RB];
+  long b_base[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int n = n0 + lrow + 32 * j;
+    b_ok[j] = n < p.N;
+    b_base[j] = (long)n * p.K;
+  }
+
+  // running (tap, channel) position of the K tile for the conv gathers
+  int tap = 0, c0 = 0;
+  if (p.mode != A_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
+
+  uint4 ra[RA], rb[RB];
+  auto load_tile = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+    if (p.mode == A_DENSE) {
+#pragma unroll
+      for (int j = 0; j < RA; ++j)
+        ra[j] = a_ok[j] ? *reinterpret_cast<const uint4*>(Ag + a_base[j] + k0 + chunk * 8) : make_uint4(0, 0, 0, 0);
+    } else {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        bool ok = a_ok[j];
+        int sy, sx;
+        if (p.mode == A_CONV3) {
+          const int iy = a_oy[j] * p.stride + ky - 1, ix = a_ox[j] * p.stride + kx - 1;
+          ok = ok && iy >= 0 && ix >= 0 && iy < (p.Hin << p.up) && ix < (p.Win << p.up);
+          sy = iy >> p.up; sx = ix >> p.up;
+        } else {
+          const int ty = a_oy[j] + ky - 1, tx = a_ox[j] + kx - 1;
+          ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < p.Hin && (tx >> 1) < p.Win;
+          sy = ty >> 1; sx = tx >> 1;
+        }
+        ra[j] = ok ? *reinterpret_cast<const uint4*>(Ag + (a_base[j] + (long)sy * p.Win + sx) * p.lda + c0 + chunk * 8)
+                   : make_uint4(0, 0, 0, 0);
+      }
+      c0 += BK;
+      if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      rb[j] = b_ok[j] ? *reinterpret_cast<const uint4*>(Wg + b_base[j] + k0 + chunk * 8) : make_uint4(0, 0, 0, 0);
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (ntiles > 0) load_tile(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RA; ++j) *reinterpret_cast<uint4*>(&sA[(lrow + 32 * j) * LDS_LD + chunk * 8]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) *reinterpret_cast<uint4*>(&sB[(lrow + 32 * j) * LDS_LD + chunk * 8]) = rb[j];
+    __syncthreads();
+    if (kt + 1 < ntiles) load_tile(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int koff = kk * 16 + (lane >> 5) * 8;
+      uint4 fw[TN], fx[TM];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fw[j] = *reinterpret_cast<const uint4*>(&sB[(wn * (BN / 2) + j * 32 + (lane & 31)) * LDS_LD + koff]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fx[i] = *reinterpret_cast<const uint4*>(&sA[(wm * (BM / 2) + i * 32 + (lane & 31)) * LDS_LD + koff]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[j], fx[i], acc[i][j]);
+    }
+  }
+
+  // epilogue: lane owns row m, accumulator group g holds n = 8g + 4*(lane>>5) + 0..3
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= p.N) continue;
+        if (p.splits > 1) {
+          float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = o;
+        } else {
+          epilogue_store<T>(p, m, n, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+      }
+  }
+}
+
+template <class T>
+__global__ void k_splitk_reduce(const GemmK p) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // index of a 4-wide group
+  const size_t total = (size_t)p.M * p.N / 4;
+  if (q >= total) return;
+  const size_t e = q * 4;
+  const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < p.splits; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)z * p.M * p.N + e);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  epilogue_store<T>(p, m, n, s.x, s.y, s.z, s.w);
+}
+
+template <class T>
+static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
+  int BM, BN;
+  if (k.M <= 64) { BM = 64; BN = 64; }
+  else if (k.N % 128 == 0) { BM = 128; BN = 128; }
+  else { BM = 128; BN = 64; }
+  const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
+  const int ktiles = k.K / BK;
+  int splits = 1;
+  if (k.partial && tiles < 200 && ktiles >= 8) {
+    splits = 512 / tiles;
+    if (splits > ktiles / 4) splits = ktiles / 4;
+    if (splits > 32) splits = 32;
+    const size_t fit = partial_elems / ((size_t)k.M * k.N);
+    if ((size_t)splits > fit) splits = (int)fit;
+    if (splits < 1) splits = 1;
+  }
+  const int tiles_per_split = cdiv(ktiles, splits);
+  splits = cdiv(ktiles, tiles_per_split);
+  k.splits = splits;
+  k.k_per_split = tiles_per_split * BK;
+  dim3 grid(tm, tn, splits);
+  if (BM == 64) hipLaunchKernelGGL((k_gemm<T, 64, 64>), grid, dim3(256), 0, st, k);
+  else if (BN == 128) hipLaunchKernelGGL((k_gemm<T, 128, 128>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((k_gemm<T, 128, 64>), grid, dim3(256), 0, st, k);
+  if (splits > 1) {
+    const size_t groups = (size_t)k.M * k.N / 4;
+    hipLaunchKernelGGL((k_splitk_reduce<T>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, k);
+  }
+}
+
+double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
+  GemmK k;
+  k.A = a.A; k.lda = a.lda; k.W = a.W; k.M = a.M; k.N = a.N; k.K = a.K;
+  k.mode = a.mode; k.Hin = a.Hin; k.Win = a.Win; k.Cin = a.Cin; k.Hout = a.Hout; k.Wout = a.Wout;
+  k.stride = a.stride; k.up = a.up;
+  k.bias = a.bias; k.rowvec = a.rowvec; k.rowvec_ld = a.rowvec_ld;
+  k.rows_per_batch = a.rows_per_batch > 0 ? a.rows_per_batch : 1;
+  k.R = a.R; k.ldr = a.ldr; k.C = a.C; k.ldc = a.ldc; k.act_silu = a.act_silu;
+  k.partial = a.partial; k.splits = 1; k.k_per_split = a.K;
+  if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st);
+  else gemm_dispatch<bf16>(k, a.partial_elems, st);
+  return 2.0 * (double)a.M * (double)a.N * (double)a.K;
+}
+
+}  // namespace dh

@@ -1,0 +1,798 @@
+// SD-2-depth U-Net engine: builds a static tape of ops from a config, owns weights (forward
+// layout + transposed/flipped copies for the input-gradient GEMMs) and activation storage,
+// runs forward with activation capture and the backward pass to the sample / text inputs.
+//
+// Structure follows SURVEY.md section 8 a3 (reference model/unet_2d_condition.py:809-1198,
+// unet_2d_blocks.py, transformer_2d.py:242-444, attention.py:219-342,
+// attention_processor.py:1178-1262; diffusers-0.23 ResnetBlock2D/Up/Downsample2D [ext]).
+// Parameter names are the diffusers state-dict names.
+//
+// MI355X layout decisions: channels-last 16-bit activations (a pixel row is a GEMM row and
+// a token), every tensor has its own HBM slot (288 GB: nothing is recomputed or reused),
+// the 32 text K/V projections and the 22 time-embedding projections are hoisted into one
+// GEMM each, q/k/v of self-attention is one GEMM, weights are stored twice ([N][K] and the
+// transposed / tap-flipped [K][N]) so forward and input-gradient use the same NT kernel.
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "unet_kernels.h"
+
+namespace dh {
+
+enum OpType { OP_CONV_IN, OP_CONV_OUT, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_CONCAT, OP_TIMESTEP, OP_T2F };
+enum ParamKind { PK_F32, PK_MAT };
+
+struct Ten {
+  size_t off = 0, goff = 0;   // element offsets into the activation / gradient arenas
+  int rows = 0, C = 0;        // rows per batch item
+  bool req_grad = true;
+};
+
+struct Wt {
+  size_t fwd_off = 0, bwd_off = 0;   // element offsets (16-bit arena, or f32 arena when f32)
+  int N = 0, K = 0, taps = 1;
+  bool has_bwd = true, f32 = false;
+};
+
+struct ParamInfo {
+  std::string name;
+  int ndim = 0;
+  int64_t shape[4] = {0, 0, 0, 0};
+  int kind = PK_F32;
+  size_t f32_off = 0;   // PK_F32
+  int wt = -1;          // PK_MAT
+  int row_off = 0;      // rows [row_off, row_off + shape[0]) of the (fused) weight
+};
+
+struct Op {
+  int type = OP_GEMM;
+  int in0 = -1, in1 = -1, out = -1, res = -1;
+  int wt = -1;
+  long bias_off = -1;      // f32 arena
+  long gamma_off = -1, beta_off = -1;
+  // gemm / conv
+  int mode = A_DENSE, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, stride = 1, up = 0;
+  int in_col = 0, in_cols = 0;      // column window of in0 used as A (dense)
+  long rowvec_off = -1; int rowvec_ld = 0;   // f32 arena: per-batch vector (time embedding)
+  int act_silu = 0;
+  // norms
+  float eps = 1e-5f; int silu = 0; int groups = 32; size_t stats_off = 0;
+  // attention
+  int heads = 0, Nq = 0, Nk = 0, cross = 0, kv_col = 0; size_t lse_off = 0;
+  // concat: in0 | in1
+};
+
+}  // namespace dh
+
+using namespace dh;
+
+struct dh_unet {
+  dh_unet_config cfg;
+  int dtype = DH_DTYPE_F16;
+  std::vector<Ten> tens;
+  std::vector<Wt> wts;
+  std::vector<ParamInfo> params;
+  std::vector<Op> ops;
+  std::map<std::string, int> pindex;
+  // arena sizes (elements)
+  size_t w16_elems = 0, pf_elems = 0, act_elems = 0, grad_elems = 0, f32_elems = 0;
+  size_t partial_elems = 0, scratch_elems = 0, small_elems = 0;
+  // device arenas
+  unsigned short *w16 = nullptr, *act = nullptr, *grad = nullptr, *scratch = nullptr;
+  float *pf = nullptr, *f32a = nullptr, *partial = nullptr, *small = nullptr;
+  // well-known tensors
+  int t_text = -1, t_kv = -1, t_conv_in_out = -1, t_final = -1, act_ids[3] = {-1, -1, -1};
+  long temb_f32_off = -1;
+  int temb_total = 0, kv_total = 0;
+  // run state
+  int saved_batch = 0;
+  const float* saved_sample = nullptr;
+  std::vector<char> gready;
+  double flops_fwd = 0, flops_bwd = 0;
+  int64_t launches = 0;
+
+  unsigned short* aptr(int t, int B_unused = 0) { return act + tens[t].off; }
+  unsigned short* gptr(int t) { return grad + tens[t].goff; }
+};
+
+namespace {
+
+struct Builder {
+  dh_unet& u;
+  int maxB;
+  explicit Builder(dh_unet& uu) : u(uu), maxB(uu.cfg.max_batch) {}
+
+  int tensor(int rows, int C, bool req_grad = true) {
+    Ten t;
+    t.rows = rows; t.C = C; t.req_grad = req_grad;
+    t.off = u.act_elems;
+    u.act_elems += align_up((size_t)rows * C * maxB, 128);
+    if (req_grad) { t.goff = u.grad_elems; u.grad_elems += align_up((size_t)rows * C * maxB, 128); }
+    u.tens.push_back(t);
+    return (int)u.tens.size() - 1;
+  }
+  size_t f32_slot(size_t n) { size_t o = u.f32_elems; u.f32_elems += align_up(n, 64); return o; }
+
+  long param_f32(const std::string& name, int n) {
+    ParamInfo p;
+    p.name = name; p.ndim = 1; p.shape[0] = n; p.kind = PK_F32;
+    p.f32_off = u.pf_elems;
+    u.pf_elems += align_up((size_t)n, 64);
+    u.pindex[name] = (int)u.params.size();
+    u.params.push_back(p);
+    return (long)p.f32_off;
+  }
+  // slice [row_off, row_off+n) of an f32 vector that other params also fill
+  void param_f32_at(const std::string& name, int n, size_t off) {
+    ParamInfo p;
+    p.name = name; p.ndim = 1; p.shape[0] = n; p.kind = PK_F32; p.f32_off = off;
+    u.pindex[name] = (int)u.params.size();
+    u.params.push_back(p);
+  }
+  int weight(int N, int K, int taps = 1, bool has_bwd = true, bool f32 = false) {
+    Wt w;
+    w.N = N; w.K = K; w.taps = taps; w.has_bwd = has_bwd; w.f32 = f32;
+    size_t& arena = f32 ? u.pf_elems : u.w16_elems;
+    w.fwd_off = arena; arena += align_up((size_t)N * K, 128);
+    if (has_bwd) { w.bwd_off = arena; arena += align_up((size_t)N * K, 128); }
+    u.wts.push_back(w);
+    return (int)u.wts.size() - 1;
+  }
+  void bind_mat(const std::string& name, int wt, int rows, int row_off, int cin, int taps) {
+    ParamInfo p;
+    p.name = name; p.kind = PK_MAT; p.wt = wt; p.row_off = row_off;
+    if (taps == 9) { p.ndim = 4; p.shape[0] = rows; p.shape[1] = cin; p.shape[2] = 3; p.shape[3] = 3; }
+    else { p.ndim = 2; p.shape[0] = rows; p.shape[1] = cin; }
+    u.pindex[name] = (int)u.params.size();
+    u.params.push_back(p);
+  }
+  void bind_conv1x1(const std::string& name, int wt, int rows, int cin) {
+    bind_mat(name, wt, rows, 0, cin, 1);
+    ParamInfo& p = u.params.back();
+    p.ndim = 4; p.shape[2] = 1; p.shape[3] = 1;
+  }
+
+  // ---- op builders ----------------------------------------------------------------------
+  int gn(int x, const std::string& pre, float eps, bool silu) {
+    const Ten tx = u.tens[x];   // copy: tensor() grows the vector
+    Op o;
+    o.type = OP_GN; o.in0 = x; o.out = tensor(tx.rows, tx.C);
+    o.gamma_off = param_f32(pre + ".weight", tx.C);
+    o.beta_off = param_f32(pre + ".bias", tx.C);
+    o.eps = eps; o.silu = silu; o.groups = u.cfg.norm_groups;
+    o.stats_off = f32_slot((size_t)maxB * o.groups * 2);
+    u.ops.push_back(o);
+    return o.out;
+  }
+  int ln(int x, const std::string& pre) {
+    const Ten tx = u.tens[x];
+    Op o;
+    o.type = OP_LN; o.in0 = x; o.out = tensor(tx.rows, tx.C);
+    o.gamma_off = param_f32(pre + ".weight", tx.C);
+    o.beta_off = param_f32(pre + ".bias", tx.C);
+    o.eps = 1e-5f;
+    o.stats_off = f32_slot((size_t)maxB * tx.rows * 2);
+    u.ops.push_back(o);
+    return o.out;
+  }
+  // 3x3 conv (pad 1): Hs = source spatial size, stride 1/2, up = source is upsampled 2x first
+  int conv3(int x, const std::string& pre, int Cout, int Hs, int stride, int up, long temb_off, int res) {
+    const Ten& tx = u.tens[x];
+    const int Cin = tx.C;
+    const int Hv = Hs << up, Ho = stride == 2 ? Hv / 2 : Hv;
+    Op o;
+    o.type = OP_GEMM; o.mode = A_CONV3; o.in0 = x; o.res = res;
+    o.Hin = Hs; o.Win = Hs; o.Cin = Cin; o.Hout = Ho; o.Wout = Ho; o.stride = stride; o.up = up;
+    o.wt = weight(Cout, 9 * Cin, 9);
+    bind_mat(pre + ".weight", o.wt, Cout, 0, Cin, 9);
+    o.bias_off = param_f32(pre + ".bias", Cout);
+    if (temb_off >= 0) { o.rowvec_off = u.temb_f32_off + temb_off; o.rowvec_ld = u.temb_total; }
+    o.out = tensor(Ho * Ho, Cout);
+    u.ops.push_back(o);
+    return o.out;
+  }
+  // dense GEMM over (a column window of) x
+  int linear_w(int x, int wt, long bias_off, int res, int in_col = 0, int in_cols = 0, bool silu = false,
+               bool req_grad = true) {
+    const Ten tx = u.tens[x];
+    Op o;
+    o.type = OP_GEMM; o.mode = A_DENSE; o.in0 = x; o.res = res; o.wt = wt; o.bias_off = bias_off;
+    o.in_col = in_col; o.in_cols = in_cols ? in_cols : tx.C; o.act_silu = silu;
+    o.out = tensor(tx.rows, u.wts[wt].N, req_grad);
+    u.ops.push_back(o);
+    return o.out;
+  }
+  int linear(int x, const std::string& pre, int N, bool bias, int res, bool as_conv1x1 = false) {
+    const int K = u.tens[x].C;
+    const int wt = weight(N, K);
+    if (as_conv1x1) bind_conv1x1(pre + ".weight", wt, N, K); else bind_mat(pre + ".weight", wt, N, 0, K, 1);
+    const long b = bias ? param_f32(pre + ".bias", N) : -1;
+    return linear_w(x, wt, b, res);
+  }
+  int concat(int a, int b) {
+    Op o;
+    o.type = OP_CONCAT; o.in0 = a; o.in1 = b;
+    o.out = tensor(u.tens[a].rows, u.tens[a].C + u.tens[b].C);
+    u.ops.push_back(o);
+    return o.out;
+  }
+
+  int temb_cursor = 0, kv_cursor = 0;
+  int wt_temb = -1, wt_kv = -1;
+  size_t temb_bias_off = 0;
+
+  int resnet(int x, const std::string& pre, int Cout, int H) {
+    const int Cin = u.tens[x].C;
+    int h = gn(x, pre + ".norm1", 1e-5f, true);
+    // time embedding projection rows of the fused weight
+    bind_mat(pre + ".time_emb_proj.weight", wt_temb, Cout, temb_cursor, u.cfg.block_out_channels[0] * 4, 1);
+    param_f32_at(pre + ".time_emb_proj.bias", Cout, temb_bias_off + temb_cursor);
+    const long toff = temb_cursor;
+    temb_cursor += Cout;
+    h = conv3(h, pre + ".conv1", Cout, H, 1, 0, toff, -1);
+    h = gn(h, pre + ".norm2", 1e-5f, true);
+    int sc = x;
+    if (Cin != Cout) sc = linear(x, pre + ".conv_shortcut", Cout, true, -1, true);
+    return conv3(h, pre + ".conv2", Cout, H, 1, 0, -1, sc);
+  }
+
+  int transformer(int x, const std::string& pre, int heads, int H) {
+    const int C = u.tens[x].C, N = H * H;
+    int h = gn(x, pre + ".norm", 1e-6f, false);
+    int t0 = linear(h, pre + ".proj_in", C, true, -1);
+    const std::string b = pre + ".transformer_blocks.0";
+    // self attention: one fused q|k|v GEMM
+    int n1 = ln(t0, b + ".norm1");
+    const int wqkv = weight(3 * C, C);
+    bind_mat(b + ".attn1.to_q.weight", wqkv, C, 0, C, 1);
+    bind_mat(b + ".attn1.to_k.weight", wqkv, C, C, C, 1);
+    bind_mat(b + ".attn1.to_v.weight", wqkv, C, 2 * C, C, 1);
+    int qkv = linear_w(n1, wqkv, -1, -1);
+    Op a;
+    a.type = OP_ATTN; a.in0 = qkv; a.heads = heads; a.Nq = N; a.Nk = N; a.cross = 0;
+    a.out = tensor(N, C);
+    a.lse_off = f32_slot((size_t)maxB * heads * N);
+    u.ops.push_back(a);
+    int t1 = linear(a.out, b + ".attn1.to_out.0", C, true, t0);
+    // cross attention: q GEMM; k|v come from the hoisted text projection
+    int n2 = ln(t1, b + ".norm2");
+    int q2 = linear(n2, b + ".attn2.to_q", C, false, -1);
+    bind_mat(b + ".attn2.to_k.weight", wt_kv, C, kv_cursor, u.cfg.cross_attention_dim, 1);
+    bind_mat(b + ".attn2.to_v.weight", wt_kv, C, kv_cursor + C, u.cfg.cross_attention_dim, 1);
+    Op c;
+    c.type = OP_ATTN; c.in0 = q2; c.in1 = u.t_kv; c.heads = heads; c.Nq = N; c.Nk = u.cfg.text_len; c.cross = 1;
+    c.kv_col = kv_cursor;
+    kv_cursor += 2 * C;
+    c.out = tensor(N, C);
+    c.lse_off = f32_slot((size_t)maxB * heads * N);
+    u.ops.push_back(c);
+    int t2 = linear(c.out, b + ".attn2.to_out.0", C, true, t1);
+    // feed forward (GEGLU)
+    int n3 = ln(t2, b + ".norm3");
+    int gg = linear(n3, b + ".ff.net.0.proj", 8 * C, true, -1);
+    Op g;
+    g.type = OP_GEGLU; g.in0 = gg; g.out = tensor(N, 4 * C);
+    u.ops.push_back(g);
+    int t3 = linear(g.out, b + ".ff.net.2", C, true, t2);
+    return linear(t3, pre + ".proj_out", C, true, x);
+  }
+};
+
+void count_fused(const dh_unet_config& c, int& temb_total, int& kv_total) {
+  const int L = c.n_levels, n = c.layers_per_block;
+  temb_total = 0; kv_total = 0;
+  for (int i = 0; i < L; ++i) {
+    temb_total += n * c.block_out_channels[i];
+    if (i < L - 1) kv_total += n * 2 * c.block_out_channels[i];
+  }
+  temb_total += 2 * c.block_out_channels[L - 1];
+  kv_total += 2 * c.block_out_channels[L - 1];
+  for (int i = 0; i < L; ++i) {
+    const int ch = c.block_out_channels[L - 1 - i];
+    temb_total += (n + 1) * ch;
+    if (i > 0) kv_total += (n + 1) * 2 * ch;
+  }
+}
+
+int build(dh_unet& u) {
+  const dh_unet_config& c = u.cfg;
+  Builder b(u);
+  const int L = c.n_levels, n = c.layers_per_block, S = c.sample_size;
+  const int* ch = c.block_out_channels;
+  const int temb_dim = ch[0] * 4;
+  count_fused(c, u.temb_total, u.kv_total);
+
+  // ---- time embedding: sinusoid -> linear+silu -> linear+silu -> fused projections --------
+  int t_sin = b.tensor(1, ch[0], false);
+  { Op o; o.type = OP_TIMESTEP; o.out = t_sin; u.ops.push_back(o); }
+  const int w1 = b.weight(temb_dim, ch[0], 1, false);
+  b.bind_mat("time_embedding.linear_1.weight", w1, temb_dim, 0, ch[0], 1);
+  int e1 = b.linear_w(t_sin, w1, b.param_f32("time_embedding.linear_1.bias", temb_dim), -1, 0, 0, true, false);
+  const int w2 = b.weight(temb_dim, temb_dim, 1, false);
+  b.bind_mat("time_embedding.linear_2.weight", w2, temb_dim, 0, temb_dim, 1);
+  int e2 = b.linear_w(e1, w2, b.param_f32("time_embedding.linear_2.bias", temb_dim), -1, 0, 0, true, false);
+  b.wt_temb = b.weight(u.temb_total, temb_dim, 1, false);
+  b.temb_bias_off = u.pf_elems;
+  u.pf_elems += align_up((size_t)u.temb_total, 64);
+  int t_temb = b.linear_w(e2, b.wt_temb, (long)b.temb_bias_off, -1, 0, 0, false, false);
+  u.temb_f32_off = (long)b.f32_slot((size_t)c.max_batch * u.temb_total);
+  { Op o; o.type = OP_T2F; o.in0 = t_temb; u.ops.push_back(o); }
+
+  // ---- text: hoisted K|V projections of every cross-attention ------------------------------
+  u.t_text = b.tensor(c.text_len, c.cross_attention_dim, true);
+  b.wt_kv = b.weight(u.kv_total, c.cross_attention_dim);
+  u.t_kv = b.linear_w(u.t_text, b.wt_kv, -1, -1);
+
+  // ---- conv_in -------------------------------------------------------------------------------
+  { Op o;
+    o.type = OP_CONV_IN;
+    o.wt = b.weight(ch[0], 9 * c.in_channels, 9, true, true);
+    b.bind_mat("conv_in.weight", o.wt, ch[0], 0, c.in_channels, 9);
+    o.bias_off = b.param_f32("conv_in.bias", ch[0]);
+    o.Hin = S; o.Cin = c.in_channels;
+    o.out = b.tensor(S * S, ch[0]);
+    u.t_conv_in_out = o.out;
+    u.ops.push_back(o); }
+  int x = u.t_conv_in_out;
+  std::vector<int> skips{x};
+  int H = S;
+  for (int i = 0; i < L; ++i) {
+    const std::string pre = "down_blocks." + std::to_string(i);
+    const bool attn = i < L - 1, down = i < L - 1;
+    for (int j = 0; j < n; ++j) {
+      x = b.resnet(x, pre + ".resnets." + std::to_string(j), ch[i], H);
+      if (attn) x = b.transformer(x, pre + ".attentions." + std::to_string(j), c.heads[i], H);
+      skips.push_back(x);
+    }
+    if (down) {
+      x = b.conv3(x, pre + ".downsamplers.0.conv", ch[i], H, 2, 0, -1, -1);
+      H /= 2;
+      skips.push_back(x);
+    }
+  }
+  x = b.resnet(x, "mid_block.resnets.0", ch[L - 1], H);
+  x = b.transformer(x, "mid_block.attentions.0", c.heads[L - 1], H);
+  x = b.resnet(x, "mid_block.resnets.1", ch[L - 1], H);
+  int n_act = 0;
+  for (int i = 0; i < L; ++i) {
+    const std::string pre = "up_blocks." + std::to_string(i);
+    const int co = ch[L - 1 - i];
+    const bool attn = i > 0, up = i < L - 1;
+    for (int j = 0; j < n + 1; ++j) {
+      const int sk = skips.back();
+      skips.pop_back();
+      x = b.concat(x, sk);
+      x = b.resnet(x, pre + ".resnets." + std::to_string(j), co, H);
+      if (attn) x = b.transformer(x, pre + ".attentions." + std::to_string(j), c.heads[L - 1 - i], H);
+    }
+    if (up) {
+      x = b.conv3(x, pre + ".upsamplers.0.conv", co, H, 1, 1, -1, -1);
+      H *= 2;
+    }
+    if (attn && n_act < 3) u.act_ids[n_act++] = x;
+  }
+  x = b.gn(x, "conv_norm_out", 1e-5f, true);
+  u.t_final = x;
+  { Op o;
+    o.type = OP_CONV_OUT; o.in0 = x;
+    o.wt = b.weight(c.out_channels, 9 * ch[0], 9, true, true);
+    b.bind_mat("conv_out.weight", o.wt, c.out_channels, 0, ch[0], 9);
+    o.bias_off = b.param_f32("conv_out.bias", c.out_channels);
+    o.Hin = S; o.Cin = ch[0];
+    u.ops.push_back(o); }
+  if (b.temb_cursor != u.temb_total || b.kv_cursor != u.kv_total) {
+    set_error("internal: fused projection sizes do not match");
+    return DH_ERR_STATE;
+  }
+  // scratch: split-K partial slabs, upsample-backward temporary, small f32 vectors
+  size_t biggest = 0;
+  for (const Ten& t : u.tens) biggest = std::max(biggest, (size_t)t.rows * t.C * c.max_batch);
+  u.scratch_elems = biggest * 4 + 1024;
+  u.partial_elems = std::max<size_t>((size_t)48 << 20, biggest * 2);
+  u.small_elems = (size_t)c.max_batch * 64 * 4096 + (size_t)c.max_batch * c.norm_groups * 4 + 4096;
+  return DH_OK;
+}
+
+template <class D>
+__global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, long fwd_ld, long row_off, D* bwd,
+                              long bwd_ld, long col_off, int Nb) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * C * taps) return;
+  const int tap = (int)(idx % taps);
+  const int cc = (int)((idx / taps) % C);
+  const int nn = (int)(idx / ((size_t)taps * C));
+  const float v = src[idx];
+  fwd[(size_t)(row_off + nn) * fwd_ld + (size_t)tap * C + cc] = from_f32<D>(v);
+  if (bwd) bwd[(size_t)cc * bwd_ld + (size_t)(taps - 1 - tap) * Nb + col_off + nn] = from_f32<D>(v);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
+  DH_REQUIRE(cfg && out, "null pointer");
+  DH_REQUIRE(cfg->n_levels == 4, "n_levels must be 4");
+  DH_REQUIRE(cfg->dtype == DH_DTYPE_F16 || cfg->dtype == DH_DTYPE_BF16, "dtype must be f16 or bf16");
+  DH_REQUIRE(cfg->max_batch >= 1 && cfg->sample_size % 8 == 0 && cfg->sample_size >= 8, "bad batch / sample size");
+  DH_REQUIRE(cfg->in_channels <= 8 && cfg->out_channels <= 8, "in/out channels must be <= 8");
+  DH_REQUIRE(cfg->cross_attention_dim % 64 == 0, "cross_attention_dim must be a multiple of 64");
+  for (int i = 0; i < 4; ++i) {
+    DH_REQUIRE(cfg->block_out_channels[i] % 64 == 0, "block_out_channels must be multiples of 64");
+    DH_REQUIRE(cfg->block_out_channels[i] == cfg->heads[i] * 64, "head dim must be 64");
+    DH_REQUIRE(cfg->block_out_channels[i] % cfg->norm_groups == 0, "channels must divide into norm groups");
+  }
+  dh_unet* u = new dh_unet();
+  u->cfg = *cfg;
+  u->dtype = cfg->dtype;
+  int rc = build(*u);
+  if (rc != DH_OK) { delete u; return rc; }
+  auto fail = [&](hipError_t e, const char* what) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    dh_unet_destroy(u);
+    return DH_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&u->w16, u->w16_elems * 2 + 256)) != hipSuccess) return fail(e, "hipMalloc weights");
+  if ((e = hipMalloc((void**)&u->pf, u->pf_elems * 4 + 256)) != hipSuccess) return fail(e, "hipMalloc f32 params");
+  if ((e = hipMalloc((void**)&u->act, u->act_elems * 2 + 256)) != hipSuccess) return fail(e, "hipMalloc activations");
+  if ((e = hipMalloc((void**)&u->grad, u->grad_elems * 2 + 256)) != hipSuccess) return fail(e, "hipMalloc gradients");
+  if ((e = hipMalloc((void**)&u->f32a, u->f32_elems * 4 + 256)) != hipSuccess) return fail(e, "hipMalloc f32 arena");
+  if ((e = hipMalloc((void**)&u->partial, u->partial_elems * 4)) != hipSuccess) return fail(e, "hipMalloc split-K");
+  if ((e = hipMalloc((void**)&u->scratch, u->scratch_elems * 2)) != hipSuccess) return fail(e, "hipMalloc scratch");
+  if ((e = hipMalloc((void**)&u->small, u->small_elems * 4)) != hipSuccess) return fail(e, "hipMalloc small");
+  (void)hipMemset(u->w16, 0, u->w16_elems * 2);
+  (void)hipMemset(u->pf, 0, u->pf_elems * 4);
+  u->gready.assign(u->tens.size(), 0);
+  *out = u;
+  return DH_OK;
+}
+
+extern "C" void dh_unet_destroy(dh_unet* u) {
+  if (!u) return;
+  (void)hipFree(u->w16); (void)hipFree(u->pf); (void)hipFree(u->act); (void)hipFree(u->grad);
+  (void)hipFree(u->f32a); (void)hipFree(u->partial); (void)hipFree(u->scratch); (void)hipFree(u->small);
+  delete u;
+}
+
+extern "C" int dh_unet_num_params(const dh_unet* u) { return u ? (int)u->params.size() : 0; }
+
+extern "C" int dh_unet_param_info(const dh_unet* u, int i, const char** name, int* ndim, int64_t* shape4) {
+  DH_REQUIRE(u && i >= 0 && i < (int)u->params.size() && name && ndim && shape4, "bad arguments");
+  const ParamInfo& p = u->params[i];
+  *name = p.name.c_str();
+  *ndim = p.ndim;
+  for (int k = 0; k < 4; ++k) shape4[k] = p.shape[k];
+  return DH_OK;
+}
+
+extern "C" int dh_unet_load_param(dh_unet* u, int i, const float* src, void* stream) {
+  DH_REQUIRE(u && src && i >= 0 && i < (int)u->params.size(), "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const ParamInfo& p = u->params[i];
+  if (p.kind == PK_F32) {
+    DH_CHECK_HIP(hipMemcpyAsync(u->pf + p.f32_off, src, (size_t)p.shape[0] * 4, hipMemcpyDeviceToDevice, st));
+    return DH_OK;
+  }
+  const Wt& w = u->wts[p.wt];
+  const int N = (int)p.shape[0], C = (int)p.shape[1], taps = w.taps;
+  const size_t total = (size_t)N * C * taps;
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  const long fwd_ld = w.K;                       // = taps * C
+  const long bwd_ld = (long)taps * w.N;          // fused linear: total N; conv: 9 * N
+  if (w.f32) {
+    float* f = u->pf + w.fwd_off;
+    float* b = w.has_bwd ? u->pf + w.bwd_off : nullptr;
+    hipLaunchKernelGGL((k_load_weight<float>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off,
+                       b, bwd_ld, (long)p.row_off, w.N);
+  } else if (u->dtype == DH_DTYPE_F16) {
+    f16* f = (f16*)(u->w16 + w.fwd_off);
+    f16* b = w.has_bwd ? (f16*)(u->w16 + w.bwd_off) : nullptr;
+    hipLaunchKernelGGL((k_load_weight<f16>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
+                       bwd_ld, (long)p.row_off, w.N);
+  } else {
+    bf16* f = (bf16*)(u->w16 + w.fwd_off);
+    bf16* b = w.has_bwd ? (bf16*)(u->w16 + w.bwd_off) : nullptr;
+    hipLaunchKernelGGL((k_load_weight<bf16>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
+                       bwd_ld, (long)p.row_off, w.N);
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" size_t dh_unet_weight_bytes(const dh_unet* u) { return u ? u->w16_elems * 2 + u->pf_elems * 4 : 0; }
+extern "C" size_t dh_unet_workspace_bytes(const dh_unet* u) {
+  return u ? (u->act_elems + u->grad_elems + u->scratch_elems) * 2 + (u->f32_elems + u->partial_elems + u->small_elems) * 4 : 0;
+}
+
+// ---------------------------------------------------------------------------------- forward
+static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
+  const Wt& w = u->wts[o.wt];
+  const Ten& ti = u->tens[o.in0];
+  const Ten& to = u->tens[o.out];
+  g.A = u->aptr(o.in0) + o.in_col; g.lda = ti.C;
+  g.W = u->w16 + w.fwd_off;
+  g.M = B * to.rows; g.N = w.N; g.K = w.K;
+  g.mode = o.mode; g.Hin = o.Hin; g.Win = o.Win; g.Cin = o.Cin; g.Hout = o.Hout; g.Wout = o.Wout;
+  g.stride = o.stride; g.up = o.up;
+  g.bias = o.bias_off >= 0 ? u->pf + o.bias_off : nullptr;
+  if (o.rowvec_off >= 0) { g.rowvec = u->f32a + o.rowvec_off; g.rowvec_ld = o.rowvec_ld; g.rows_per_batch = to.rows; }
+  if (o.res >= 0) { g.R = u->aptr(o.res); g.ldr = u->tens[o.res].C; }
+  g.C = u->aptr(o.out); g.ldc = to.C;
+  g.act_silu = o.act_silu;
+  g.partial = u->partial; g.partial_elems = u->partial_elems;
+}
+
+extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, const float* text, int batch,
+                               int save_for_backward, float* eps_out, void* const* act_out, void* stream) {
+  DH_REQUIRE(u && sample && text && eps_out, "null pointer");
+  DH_REQUIRE(batch >= 1 && batch <= u->cfg.max_batch, "batch exceeds max_batch");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = batch, dt = u->dtype;
+  const dh_unet_config& c = u->cfg;
+  u->flops_fwd = 0;
+  u->launches = 0;
+  launch_f32_to_t(dt, text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
+  for (const Op& o : u->ops) {
+    switch (o.type) {
+      case OP_TIMESTEP:
+        launch_timestep_embedding(dt, timestep, c.block_out_channels[0], B, u->aptr(o.out), st);
+        break;
+      case OP_T2F:
+        launch_t_to_f32(dt, u->aptr(o.in0), u->f32a + u->temb_f32_off, (size_t)B * u->temb_total, 0, st);
+        break;
+      case OP_CONV_IN: {
+        const Wt& w = u->wts[o.wt];
+        launch_conv_small_fwd(dt, sample, 1, u->pf + w.fwd_off, u->pf + o.bias_off, u->aptr(o.out), 0, B, o.Hin, o.Hin,
+                              o.Cin, w.N, st);
+        u->flops_fwd += 2.0 * B * o.Hin * o.Hin * w.N * w.K;
+        break;
+      }
+      case OP_CONV_OUT: {
+        const Wt& w = u->wts[o.wt];
+        launch_conv_small_fwd(dt, u->aptr(o.in0), 0, u->pf + w.fwd_off, u->pf + o.bias_off, eps_out, 1, B, o.Hin, o.Hin,
+                              o.Cin, w.N, st);
+        u->flops_fwd += 2.0 * B * o.Hin * o.Hin * w.N * w.K;
+        break;
+      }
+      case OP_GEMM: {
+        GemmArgs g;
+        fill_gemm(u, o, B, g);
+        u->flops_fwd += launch_gemm(dt, g, st);
+        break;
+      }
+      case OP_GN: {
+        const Ten& t = u->tens[o.in0];
+        launch_groupnorm_fwd(dt, u->aptr(o.in0), u->pf + o.gamma_off, u->pf + o.beta_off, u->aptr(o.out),
+                             u->f32a + o.stats_off, u->small, B, t.rows, t.C, o.groups, o.eps, o.silu, st);
+        break;
+      }
+      case OP_LN: {
+        const Ten& t = u->tens[o.in0];
+        launch_layernorm_fwd(dt, u->aptr(o.in0), u->pf + o.gamma_off, u->pf + o.beta_off, u->aptr(o.out),
+                             u->f32a + o.stats_off, B * t.rows, t.C, o.eps, st);
+        break;
+      }
+      case OP_ATTN: {
+        const Ten& tq = u->tens[o.in0];
+        const int C = u->tens[o.out].C;
+        if (!o.cross) {
+          const unsigned short* qkv = u->aptr(o.in0);
+          launch_attention_fwd(dt, qkv, tq.C, qkv + C, qkv + 2 * C, tq.C, u->aptr(o.out), C, u->f32a + o.lse_off, B,
+                               o.heads, o.Nq, o.Nk, st);
+        } else {
+          const Ten& tkv = u->tens[o.in1];
+          const unsigned short* kv = u->aptr(o.in1) + o.kv_col;
+          launch_attention_fwd(dt, u->aptr(o.in0), tq.C, kv, kv + C, tkv.C, u->aptr(o.out), C, u->f32a + o.lse_off, B,
+                               o.heads, o.Nq, o.Nk, st);
+        }
+        u->flops_fwd += 4.0 * B * o.heads * (double)o.Nq * o.Nk * 64;
+        break;
+      }
+      case OP_GEGLU: {
+        const Ten& t = u->tens[o.out];
+        launch_geglu_fwd(dt, u->aptr(o.in0), u->aptr(o.out), B * t.rows, t.C, st);
+        break;
+      }
+      case OP_CONCAT: {
+        const Ten &a = u->tens[o.in0], &b2 = u->tens[o.in1], &t = u->tens[o.out];
+        launch_copy_cols(dt, u->aptr(o.in0), a.C, u->aptr(o.out), t.C, B * t.rows, a.C, 0, st);
+        launch_copy_cols(dt, u->aptr(o.in1), b2.C, u->aptr(o.out) + a.C, t.C, B * t.rows, b2.C, 0, st);
+        break;
+      }
+    }
+  }
+  if (act_out) {
+    for (int i = 0; i < 3; ++i)
+      if (act_out[i]) {
+        const Ten& t = u->tens[u->act_ids[i]];
+        DH_CHECK_HIP(hipMemcpyAsync(act_out[i], u->aptr(u->act_ids[i]), (size_t)B * t.rows * t.C * 2,
+                                    hipMemcpyDeviceToDevice, st));
+      }
+  }
+  u->saved_batch = save_for_backward ? B : 0;
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// --------------------------------------------------------------------------------- backward
+namespace {
+struct Bwd {
+  dh_unet* u;
+  int B, dt;
+  hipStream_t st;
+  bool need_text;
+  // dst grad (+)= src (column window copy)
+  void add_into(int t, const unsigned short* src, long lds_, int cols, int col_off = 0) {
+    const Ten& tt = u->tens[t];
+    launch_copy_cols(dt, src, lds_, u->gptr(t) + col_off, tt.C, B * tt.rows, cols, u->gready[t] ? 1 : 0, st);
+  }
+};
+}  // namespace
+
+extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* d_sample, float* d_text,
+                                void* stream) {
+  DH_REQUIRE(u, "null engine");
+  DH_REQUIRE(u->saved_batch > 0, "no saved forward: call dh_unet_forward(save_for_backward=1) first");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = u->saved_batch, dt = u->dtype;
+  const dh_unet_config& c = u->cfg;
+  u->flops_bwd = 0;
+  std::fill(u->gready.begin(), u->gready.end(), 0);
+  if (d_act)
+    for (int i = 0; i < 3; ++i)
+      if (d_act[i]) {
+        const Ten& t = u->tens[u->act_ids[i]];
+        DH_CHECK_HIP(hipMemcpyAsync(u->gptr(u->act_ids[i]), d_act[i], (size_t)B * t.rows * t.C * 2,
+                                    hipMemcpyDeviceToDevice, st));
+        u->gready[u->act_ids[i]] = 1;
+      }
+  Bwd bw{u, B, dt, st, d_text != nullptr};
+  bool text_grad_written = false;
+  for (int oi = (int)u->ops.size() - 1; oi >= 0; --oi) {
+    const Op& o = u->ops[oi];
+    switch (o.type) {
+      case OP_CONV_OUT: {
+        if (!d_eps) break;
+        const Wt& w = u->wts[o.wt];
+        // dX[C] <- d_eps[4]: few-in kernel with the flipped/transposed weights (write)
+        launch_conv_small_bwd(dt, d_eps, 1, u->pf + w.bwd_off, u->gptr(o.in0), 0, 0, B, o.Hin, o.Hin, w.N, o.Cin, st);
+        u->gready[o.in0] = 1;
+        u->flops_bwd += 2.0 * B * o.Hin * o.Hin * w.N * w.K;
+        break;
+      }
+      case OP_CONV_IN: {
+        if (!d_sample || !u->gready[o.out]) break;
+        const Wt& w = u->wts[o.wt];
+        launch_conv_small_bwd(dt, u->gptr(o.out), 0, u->pf + w.bwd_off, d_sample, 1, 0, B, o.Hin, o.Hin, w.N, o.Cin, st);
+        u->flops_bwd += 2.0 * B * o.Hin * o.Hin * w.N * w.K;
+        break;
+      }
+      case OP_GEMM: {
+        if (!u->tens[o.out].req_grad || !u->gready[o.out]) break;
+        const Ten& to = u->tens[o.out];
+        const Ten& ti = u->tens[o.in0];
+        const Wt& w = u->wts[o.wt];
+        if (o.res >= 0 && u->tens[o.res].req_grad) {
+          bw.add_into(o.res, u->gptr(o.out), to.C, to.C);
+          u->gready[o.res] = 1;
+        }
+        if (!ti.req_grad || !w.has_bwd) break;
+        if (o.in0 == u->t_text && !bw.need_text) break;
+        GemmArgs g;
+        g.A = u->gptr(o.out); g.lda = to.C;
+        g.W = u->w16 + w.bwd_off;
+        g.partial = u->partial; g.partial_elems = u->partial_elems;
+        if (o.mode == A_DENSE) {
+          g.mode = A_DENSE;
+          g.M = B * to.rows; g.N = w.K; g.K = w.N;
+          g.C = u->gptr(o.in0) + o.in_col; g.ldc = ti.C;
+          if (u->gready[o.in0]) { g.R = g.C; g.ldr = ti.C; }
+          u->flops_bwd += launch_gemm(dt, g, st);
+          u->gready[o.in0] = 1;
+        } else if (o.up) {
+          // gradient w.r.t. the upsampled image, then 2x2 sum back to the source resolution
+          g.mode = A_CONV3; g.stride = 1; g.up = 0;
+          g.Hin = o.Hout; g.Win = o.Wout; g.Cin = w.N; g.Hout = o.Hout; g.Wout = o.Wout;
+          g.M = B * o.Hout * o.Wout; g.N = o.Cin; g.K = 9 * w.N;
+          g.C = u->scratch; g.ldc = o.Cin;
+          u->flops_bwd += launch_gemm(dt, g, st);
+          launch_pool2x2_sum(dt, u->scratch, u->gptr(o.in0), B, o.Hin, o.Win, o.Cin, u->gready[o.in0] ? 1 : 0, st);
+          u->gready[o.in0] = 1;
+        } else {
+          g.mode = o.stride == 2 ? A_CONVT2 : A_CONV3;
+          g.stride = 1; g.up = 0;
+          g.Hin = o.Hout; g.Win = o.Wout; g.Cin = w.N;          // source = dY
+          g.Hout = o.Hin; g.Wout = o.Win;                        // output = dX
+          g.M = B * o.Hin * o.Win; g.N = o.Cin; g.K = 9 * w.N;
+          g.C = u->gptr(o.in0); g.ldc = ti.C;
+          if (u->gready[o.in0]) { g.R = g.C; g.ldr = ti.C; }
+          u->flops_bwd += launch_gemm(dt, g, st);
+          u->gready[o.in0] = 1;
+        }
+        if (o.in0 == u->t_text) text_grad_written = true;
+        break;
+      }
+      case OP_GN: {
+        if (!u->gready[o.out]) break;
+        const Ten& t = u->tens[o.in0];
+        launch_groupnorm_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->pf + o.gamma_off, u->pf + o.beta_off,
+                             u->f32a + o.stats_off, u->gptr(o.in0), u->small, B, t.rows, t.C, o.groups, o.silu,
+                             u->gready[o.in0] ? 1 : 0, st);
+        u->gready[o.in0] = 1;
+        break;
+      }
+      case OP_LN: {
+        if (!u->gready[o.out]) break;
+        const Ten& t = u->tens[o.in0];
+        launch_layernorm_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->pf + o.gamma_off, u->f32a + o.stats_off,
+                             u->gready[o.in0] ? u->gptr(o.in0) : nullptr, u->gptr(o.in0), B * t.rows, t.C, st);
+        u->gready[o.in0] = 1;
+        break;
+      }
+      case OP_GEGLU: {
+        if (!u->gready[o.out]) break;
+        const Ten& t = u->tens[o.out];
+        launch_geglu_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->gptr(o.in0), B * t.rows, t.C, st);
+        u->gready[o.in0] = 1;
+        break;
+      }
+      case OP_ATTN: {
+        if (!u->gready[o.out]) break;
+        const Ten& tq = u->tens[o.in0];
+        const int C = u->tens[o.out].C;
+        float* delta = u->small;
+        launch_attention_delta(dt, u->aptr(o.out), C, u->gptr(o.out), C, delta, B, o.heads, o.Nq, st);
+        if (!o.cross) {
+          const unsigned short* qkv = u->aptr(o.in0);
+          unsigned short* dqkv = u->gptr(o.in0);
+          launch_attention_bwd_dq(dt, qkv, tq.C, qkv + C, qkv + 2 * C, tq.C, u->gptr(o.out), C, u->f32a + o.lse_off,
+                                  delta, dqkv, tq.C, B, o.heads, o.Nq, o.Nk, st);
+          launch_attention_bwd_dkv(dt, qkv, tq.C, qkv + C, qkv + 2 * C, tq.C, u->gptr(o.out), C, u->f32a + o.lse_off,
+                                   delta, dqkv + C, dqkv + 2 * C, tq.C, B, o.heads, o.Nq, o.Nk, st);
+          u->flops_bwd += 14.0 * B * o.heads * (double)o.Nq * o.Nk * 64;
+        } else {
+          const Ten& tkv = u->tens[o.in1];
+          const unsigned short* kv = u->aptr(o.in1) + o.kv_col;
+          launch_attention_bwd_dq(dt, u->aptr(o.in0), tq.C, kv, kv + C, tkv.C, u->gptr(o.out), C, u->f32a + o.lse_off,
+                                  delta, u->gptr(o.in0), tq.C, B, o.heads, o.Nq, o.Nk, st);
+          u->flops_bwd += 6.0 * B * o.heads * (double)o.Nq * o.Nk * 64;
+          if (bw.need_text) {
+            unsigned short* dkv = u->gptr(o.in1) + o.kv_col;
+            launch_attention_bwd_dkv(dt, u->aptr(o.in0), tq.C, kv, kv + C, tkv.C, u->gptr(o.out), C,
+                                     u->f32a + o.lse_off, delta, dkv, dkv + C, tkv.C, B, o.heads, o.Nq, o.Nk, st);
+            u->gready[o.in1] = 1;
+            u->flops_bwd += 8.0 * B * o.heads * (double)o.Nq * o.Nk * 64;
+          }
+        }
+        u->gready[o.in0] = 1;
+        break;
+      }
+      case OP_CONCAT: {
+        if (!u->gready[o.out]) break;
+        const Ten &a = u->tens[o.in0], &t = u->tens[o.out];
+        bw.add_into(o.in0, u->gptr(o.out), t.C, a.C);
+        u->gready[o.in0] = 1;
+        bw.add_into(o.in1, u->gptr(o.out) + a.C, t.C, u->tens[o.in1].C);
+        u->gready[o.in1] = 1;
+        break;
+      }
+      default: break;
+    }
+  }
+  if (d_text) {
+    const size_t n = (size_t)B * c.text_len * c.cross_attention_dim;
+    if (text_grad_written) launch_t_to_f32(dt, u->gptr(u->t_text), d_text, n, 0, st);
+    else DH_CHECK_HIP(hipMemsetAsync(d_text, 0, n * 4, st));
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_unet_stats(const dh_unet* u, double* flops_fwd, double* flops_bwd, int64_t* launches) {
+  DH_REQUIRE(u, "null engine");
+  if (flops_fwd) *flops_fwd = u->flops_fwd;
+  if (flops_bwd) *flops_bwd = u->flops_bwd;
+  if (launches) *launches = (int64_t)u->ops.size();
+  return DH_OK;
+}

@@ -1,0 +1,73 @@
+// Launchers of the U-Net kernels (unet_kernels.hip / attention.hip).  All activations are
+// channels-last 16-bit ([rows][C], dtype = DH_DTYPE_F16 or DH_DTYPE_BF16), f32 accumulate.
+#pragma once
+#include "common.h"
+
+namespace dh {
+
+enum { A_DENSE = 0, A_CONV3 = 1, A_CONVT2 = 2 };
+
+struct GemmArgs {
+  const void* A = nullptr; long lda = 0;   // dense: row stride; conv: pixel stride (elements)
+  const void* W = nullptr;                 // [N][K], K contiguous
+  int M = 0, N = 0, K = 0;
+  int mode = A_DENSE;
+  int Hin = 0, Win = 0, Cin = 0;           // source tensor spatial size, channels per tap
+  int Hout = 0, Wout = 0;                  // output spatial size (M = B*Hout*Wout)
+  int stride = 1, up = 0;
+  const float* bias = nullptr;             // [N]
+  const float* rowvec = nullptr; int rowvec_ld = 0; int rows_per_batch = 1;
+  const void* R = nullptr; long ldr = 0;   // residual added after everything else
+  void* C = nullptr; long ldc = 0;
+  int act_silu = 0;
+  float* partial = nullptr; size_t partial_elems = 0;   // split-K scratch (f32)
+};
+// D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
+double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+
+// direct small convolutions (conv_in: Cin=5 -> C; conv_out: C -> 4) and their input-gradients
+void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* w, const float* bias, void* y,
+                           int y_is_f32, int B, int H, int W, int Cin, int Cout, hipStream_t st);
+void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float* w, void* dx, int dx_is_f32,
+                           int accumulate, int B, int H, int W, int Cin, int Cout, hipStream_t st);
+
+// GroupNorm (+SiLU): y = act(gn(x));  stats = [B*G][2] (mean, rstd) saved for backward
+void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                          float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st);
+// dx (=|+=) d gn-act / d x
+void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
+                          const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
+                          int accumulate, hipStream_t st);
+// LayerNorm over C per row; stats [rows][2]
+void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                          int rows, int C, float eps, hipStream_t st);
+// dx = ln_bwd(dy) (+ add)   (add may alias nothing; dx written)
+void launch_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
+                          const void* add, void* dx, int rows, int C, hipStream_t st);
+// GEGLU: y[m][j] = h * gelu(g), h = x[m][j], g = x[m][F + j]
+void launch_geglu_fwd(int dtype, const void* x, void* y, int rows, int F, hipStream_t st);
+void launch_geglu_bwd(int dtype, const void* x, const void* dy, void* dx, int rows, int F, hipStream_t st);
+// misc
+void launch_copy_cols(int dtype, const void* src, long lds, void* dst, long ldd, int rows, int cols, int accumulate,
+                      hipStream_t st);                       // dst[r][0..cols) (=|+=) src[r][0..cols)
+void launch_pool2x2_sum(int dtype, const void* src, void* dst, int B, int h, int w, int C, int accumulate,
+                        hipStream_t st);                     // dst[b][y][x] (=|+=) sum of the 2x2 block of src
+void launch_f32_to_t(int dtype, const float* src, void* dst, size_t n, hipStream_t st);
+void launch_t_to_f32(int dtype, const void* src, float* dst, size_t n, int accumulate, hipStream_t st);
+void launch_timestep_embedding(int dtype, float t, int dim, int B, void* out, hipStream_t st);   // [B][dim] = [cos|sin]
+
+// flash attention, head dim 64.  q [B*Nq][ldq], k/v [B*Nk][ldk] (head h at column h*64),
+// o [B*Nq][ldo]; lse [B][H][Nq] f32 (natural log)
+void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
+                          long ldo, float* lse, int B, int H, int Nq, int Nk, hipStream_t st);
+// delta[b][h][q] = sum_d dO*O
+void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o, long lddo, float* delta, int B,
+                            int H, int Nq, hipStream_t st);
+void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk,
+                             const void* d_o, long lddo, const float* lse, const float* delta, void* dq, long lddq,
+                             int B, int H, int Nq, int Nk, hipStream_t st);
+void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk,
+                              const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv,
+                              long lddk, int B, int H, int Nq, int Nk, hipStream_t st);
+
+}  // namespace dh

@@ -1,0 +1,521 @@
+// Non-GEMM U-Net kernels: the two tiny-channel convolutions, GroupNorm(+SiLU) and
+// LayerNorm forward/backward, GEGLU forward/backward, concat/split copies, 2x2 sum pooling,
+// dtype conversion and the sinusoidal timestep embedding.  Channels-last 16-bit storage,
+// f32 math.
+#include "unet_kernels.h"
+
+namespace dh {
+
+// ------------------------------------------------------------- tiny-channel convolutions
+// few input channels (<= 8), many outputs: y[p][co] = b[co] + sum_{tap,ci} x[p+off][ci] w[co][tap][ci]
+template <class T>
+__global__ void k_conv_few_in(const float* x, const float* w, const float* bias, T* y, int B, int H, int W, int Ci,
+                              int Co) {
+  const int p = blockIdx.x;   // pixel over B*H*W
+  const int b = p / (H * W), r = p - b * H * W, oy = r / W, ox = r - oy * W;
+  __shared__ float patch[9 * 8];
+  if (threadIdx.x < 9 * Ci) {
+    const int tap = threadIdx.x / Ci, ci = threadIdx.x - tap * Ci;
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    patch[threadIdx.x] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * H + iy) * W + ix) * Ci + ci] : 0.f;
+  }
+  __syncthreads();
+  const int K = 9 * Ci;
+  for (int co = threadIdx.x; co < Co; co += blockDim.x) {
+    float acc = bias ? bias[co] : 0.f;
+    const float* wr = w + (size_t)co * K;
+    for (int k = 0; k < K; ++k) acc += patch[k] * wr[k];
+    y[(size_t)p * Co + co] = from_f32<T>(acc);
+  }
+}
+
+// many input channels, few outputs (<= 8): one wave per pixel, lanes split K = 9*Ci
+template <class T>
+__global__ void k_conv_few_out(const T* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ci,
+                               int Co, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= B * H * W) return;
+  const int b = p / (H * W), r = p - b * H * W, oy = r / W, ox = r - oy * W;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const T* xp = x + (((size_t)b * H + iy) * W + ix) * Ci;
+    for (int ci = lane; ci < Ci; ci += 64) {
+      const float xv = to_f32<T>(xp[ci]);
+#pragma unroll
+      for (int co = 0; co < 8; ++co)
+        if (co < Co) acc[co] += xv * w[((size_t)co * 9 + tap) * Ci + ci];
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < 8; ++co) {
+    if (co >= Co) break;
+    float s = wave_sum(acc[co]);
+    if (lane == 0) {
+      s += bias ? bias[co] : 0.f;
+      float* o = y + (size_t)p * Co + co;
+      *o = accumulate ? *o + s : s;
+    }
+  }
+}
+
+void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* w, const float* bias, void* y,
+                           int y_is_f32, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+  if (x_is_f32) {   // few-in
+    if (dtype == DH_DTYPE_F16)
+      hipLaunchKernelGGL((k_conv_few_in<f16>), dim3(B * H * W), dim3(256), 0, st, (const float*)x, w, bias, (f16*)y, B, H, W, Cin, Cout);
+    else
+      hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(B * H * W), dim3(256), 0, st, (const float*)x, w, bias, (bf16*)y, B, H, W, Cin, Cout);
+  } else {
+    if (dtype == DH_DTYPE_F16)
+      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const f16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
+    else
+      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const bf16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
+  }
+}
+
+// input-gradients reuse the two kernels with the flipped/transposed weights prepared at load
+void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float* w, void* dx, int dx_is_f32,
+                           int accumulate, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+  // Cin/Cout here are those of the GRADIENT convolution: dy has Cin channels, dx has Cout
+  if (dy_is_f32) {
+    if (dtype == DH_DTYPE_F16)
+      hipLaunchKernelGGL((k_conv_few_in<f16>), dim3(B * H * W), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (f16*)dx, B, H, W, Cin, Cout);
+    else
+      hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(B * H * W), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (bf16*)dx, B, H, W, Cin, Cout);
+  } else {
+    if (dtype == DH_DTYPE_F16)
+      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const f16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
+    else
+      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const bf16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
+  }
+}
+
+// ----------------------------------------------------------------------------- GroupNorm
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_grad(float z) {
+  const float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+
+// one workgroup per (batch, group): mean and rstd, two-pass (mean first, then centred sumsq)
+template <class T>
+__global__ void __launch_bounds__(512) k_gn_stats(const T* x, float* stats, int HW, int C, int G, float eps) {
+  __shared__ float sm[8];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, cpg = C / G;
+  const T* xb = x + (size_t)b * HW * C + g * cpg;
+  const int n = HW * cpg;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int p = i / cpg, c = i - p * cpg;
+    s += to_f32<T>(xb[(size_t)p * C + c]);
+  }
+  const float mean = block_sum(s, sm) / (float)n;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int p = i / cpg, c = i - p * cpg;
+    const float d = to_f32<T>(xb[(size_t)p * C + c]) - mean;
+    v += d * d;
+  }
+  const float var = block_sum(v, sm) / (float)n;
+  if (threadIdx.x == 0) {
+    stats[2 * blockIdx.x] = mean;
+    stats[2 * blockIdx.x + 1] = rsqrtf(var + eps);
+  }
+}
+
+// thread = 8 consecutive channels of one pixel
+template <class T>
+__global__ void k_gn_apply(const T* x, const float* gamma, const float* beta, const float* stats, T* y, int B, int HW,
+                           int C, int G, int silu) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cchunks = C / 8;
+  if (idx >= (size_t)B * HW * cchunks) return;
+  const size_t row = idx / cchunks;
+  const int c0 = (int)(idx - row * cchunks) * 8;
+  const int b = (int)(row / HW), cpg = C / G;
+  uint4 raw = *reinterpret_cast<const uint4*>(x + row * C + c0);
+  const T* xv = reinterpret_cast<const T*>(&raw);
+  T o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i, g = c / cpg;
+    const float mean = stats[2 * (b * G + g)], rstd = stats[2 * (b * G + g) + 1];
+    float z = (to_f32<T>(xv[i]) - mean) * rstd * gamma[c] + beta[c];
+    if (silu) z = silu_f(z);
+    o[i] = from_f32<T>(z);
+  }
+  *reinterpret_cast<uint4*>(y + row * C + c0) = *reinterpret_cast<uint4*>(o);
+}
+
+void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                          float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)B * HW * (C / 8) + 255) / 256);
+  if (dtype == DH_DTYPE_F16) {
+    hipLaunchKernelGGL((k_gn_stats<f16>), dim3(B * G), dim3(512), 0, st, (const f16*)x, stats, HW, C, G, eps);
+    hipLaunchKernelGGL((k_gn_apply<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, gamma, beta, stats, (f16*)y, B, HW, C, G, silu);
+  } else {
+    hipLaunchKernelGGL((k_gn_stats<bf16>), dim3(B * G), dim3(512), 0, st, (const bf16*)x, stats, HW, C, G, eps);
+    hipLaunchKernelGGL((k_gn_apply<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, gamma, beta, stats, (bf16*)y, B, HW, C, G, silu);
+  }
+}
+
+// backward sums per (batch, group): s[0] = mean(dxhat), s[1] = mean(dxhat * xhat)
+template <class T>
+__global__ void __launch_bounds__(512) k_gn_bwd_stats(const T* x, const T* dy, const float* gamma, const float* beta,
+                                                      const float* stats, float* sums, int HW, int C, int G, int silu) {
+  __shared__ float sm[8];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, cpg = C / G;
+  const size_t base = (size_t)b * HW * C + g * cpg;
+  const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+  const int n = HW * cpg;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int p = i / cpg, c = i - p * cpg;
+    const size_t o = base + (size_t)p * C + c;
+    const float xh = (to_f32<T>(x[o]) - mean) * rstd;
+    const float gm = gamma[g * cpg + c];
+    float d = to_f32<T>(dy[o]);
+    if (silu) d *= silu_grad(xh * gm + beta[g * cpg + c]);
+    d *= gm;
+    s1 += d;
+    s2 += d * xh;
+  }
+  s1 = block_sum(s1, sm);
+  s2 = block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    sums[2 * blockIdx.x] = s1 / (float)n;
+    sums[2 * blockIdx.x + 1] = s2 / (float)n;
+  }
+}
+
+template <class T>
+__global__ void k_gn_bwd_apply(const T* x, const T* dy, const float* gamma, const float* beta, const float* stats,
+                               const float* sums, T* dx, int B, int HW, int C, int G, int silu, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cchunks = C / 8;
+  if (idx >= (size_t)B * HW * cchunks) return;
+  const size_t row = idx / cchunks;
+  const int c0 = (int)(idx - row * cchunks) * 8;
+  const int b = (int)(row / HW), cpg = C / G;
+  uint4 rx = *reinterpret_cast<const uint4*>(x + row * C + c0);
+  uint4 rd = *reinterpret_cast<const uint4*>(dy + row * C + c0);
+  uint4 ro = make_uint4(0, 0, 0, 0);
+  if (accumulate) ro = *reinterpret_cast<const uint4*>(dx + row * C + c0);
+  const T* xv = reinterpret_cast<const T*>(&rx);
+  const T* dv = reinterpret_cast<const T*>(&rd);
+  const T* ov = reinterpret_cast<const T*>(&ro);
+  T o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i, g = c / cpg, sg = b * G + g;
+    const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
+    const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
+    float d = to_f32<T>(dv[i]);
+    if (silu) d *= silu_grad(xh * gamma[c] + beta[c]);
+    d *= gamma[c];
+    float r = rstd * (d - sums[2 * sg] - xh * sums[2 * sg + 1]);
+    if (accumulate) r += to_f32<T>(ov[i]);
+    o[i] = from_f32<T>(r);
+  }
+  *reinterpret_cast<uint4*>(dx + row * C + c0) = *reinterpret_cast<uint4*>(o);
+}
+
+void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
+                          const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
+                          int accumulate, hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)B * HW * (C / 8) + 255) / 256);
+  if (dtype == DH_DTYPE_F16) {
+    hipLaunchKernelGGL((k_gn_bwd_stats<f16>), dim3(B * G), dim3(512), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, silu);
+    hipLaunchKernelGGL((k_gn_bwd_apply<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, B, HW, C, G, silu, accumulate);
+  } else {
+    hipLaunchKernelGGL((k_gn_bwd_stats<bf16>), dim3(B * G), dim3(512), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, silu);
+    hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, B, HW, C, G, silu, accumulate);
+  }
+}
+
+// ----------------------------------------------------------------------------- LayerNorm
+// one wave per row; C/8 sixteen-byte chunks spread over the lanes (C <= 4096)
+constexpr int LN_MAXCH = 8;
+
+template <class T>
+__global__ void k_ln_fwd(const T* x, const float* gamma, const float* beta, T* y, float* stats, int rows, int C,
+                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C / 8;
+  uint4 raw[LN_MAXCH];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      raw[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * C + ch * 8);
+      const T* v = reinterpret_cast<const T*>(&raw[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += to_f32<T>(v[i]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      const T* v = reinterpret_cast<const T*>(&raw[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = to_f32<T>(v[i]) - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0 && stats) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      const T* v = reinterpret_cast<const T*>(&raw[k]);
+      T o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = ch * 8 + i;
+        o[i] = from_f32<T>((to_f32<T>(v[i]) - mean) * rstd * gamma[c] + beta[c]);
+      }
+      *reinterpret_cast<uint4*>(y + (size_t)row * C + ch * 8) = *reinterpret_cast<uint4*>(o);
+    }
+  }
+}
+
+template <class T>
+__global__ void k_ln_bwd(const T* x, const T* dy, const float* gamma, const float* stats, const T* add, T* dx,
+                         int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C / 8;
+  const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+  uint4 rx[LN_MAXCH], rd[LN_MAXCH];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      rx[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * C + ch * 8);
+      rd[k] = *reinterpret_cast<const uint4*>(dy + (size_t)row * C + ch * 8);
+      const T* xv = reinterpret_cast<const T*>(&rx[k]);
+      const T* dv = reinterpret_cast<const T*>(&rd[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
+        const float d = to_f32<T>(dv[i]) * gamma[ch * 8 + i];
+        s1 += d;
+        s2 += d * xh;
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      const T* xv = reinterpret_cast<const T*>(&rx[k]);
+      const T* dv = reinterpret_cast<const T*>(&rd[k]);
+      uint4 ra = make_uint4(0, 0, 0, 0);
+      if (add) ra = *reinterpret_cast<const uint4*>(add + (size_t)row * C + ch * 8);
+      const T* av = reinterpret_cast<const T*>(&ra);
+      T o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
+        const float d = to_f32<T>(dv[i]) * gamma[ch * 8 + i];
+        float r = rstd * (d - s1 - xh * s2);
+        if (add) r += to_f32<T>(av[i]);
+        o[i] = from_f32<T>(r);
+      }
+      *reinterpret_cast<uint4*>(dx + (size_t)row * C + ch * 8) = *reinterpret_cast<uint4*>(o);
+    }
+  }
+}
+
+void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                          int rows, int C, float eps, hipStream_t st) {
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_ln_fwd<f16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const f16*)x, gamma, beta, (f16*)y, stats, rows, C, eps);
+  else
+    hipLaunchKernelGGL((k_ln_fwd<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, stats, rows, C, eps);
+}
+void launch_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
+                          const void* add, void* dx, int rows, int C, hipStream_t st) {
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_ln_bwd<f16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, stats, (const f16*)add, (f16*)dx, rows, C);
+  else
+    hipLaunchKernelGGL((k_ln_bwd<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, stats, (const bf16*)add, (bf16*)dx, rows, C);
+}
+
+// --------------------------------------------------------------------------------- GEGLU
+__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float g) {
+  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+template <class T>
+__global__ void k_geglu_fwd(const T* x, T* y, size_t rows, int F) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int fch = F / 8;
+  if (idx >= rows * fch) return;
+  const size_t row = idx / fch;
+  const int j0 = (int)(idx - row * fch) * 8;
+  uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + j0);
+  uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + F + j0);
+  const T* h = reinterpret_cast<const T*>(&rh);
+  const T* g = reinterpret_cast<const T*>(&rg);
+  T o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = from_f32<T>(to_f32<T>(h[i]) * gelu_f(to_f32<T>(g[i])));
+  *reinterpret_cast<uint4*>(y + row * F + j0) = *reinterpret_cast<uint4*>(o);
+}
+
+template <class T>
+__global__ void k_geglu_bwd(const T* x, const T* dy, T* dx, size_t rows, int F) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int fch = F / 8;
+  if (idx >= rows * fch) return;
+  const size_t row = idx / fch;
+  const int j0 = (int)(idx - row * fch) * 8;
+  uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + j0);
+  uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + F + j0);
+  uint4 rd = *reinterpret_cast<const uint4*>(dy + row * F + j0);
+  const T* h = reinterpret_cast<const T*>(&rh);
+  const T* g = reinterpret_cast<const T*>(&rg);
+  const T* d = reinterpret_cast<const T*>(&rd);
+  T oh[8], og[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float gv = to_f32<T>(g[i]), dv = to_f32<T>(d[i]);
+    oh[i] = from_f32<T>(dv * gelu_f(gv));
+    og[i] = from_f32<T>(dv * to_f32<T>(h[i]) * gelu_grad(gv));
+  }
+  *reinterpret_cast<uint4*>(dx + row * 2 * F + j0) = *reinterpret_cast<uint4*>(oh);
+  *reinterpret_cast<uint4*>(dx + row * 2 * F + F + j0) = *reinterpret_cast<uint4*>(og);
+}
+
+void launch_geglu_fwd(int dtype, const void* x, void* y, int rows, int F, hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)rows * (F / 8) + 255) / 256);
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_geglu_fwd<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, (f16*)y, (size_t)rows, F);
+  else hipLaunchKernelGGL((k_geglu_fwd<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (bf16*)y, (size_t)rows, F);
+}
+void launch_geglu_bwd(int dtype, const void* x, const void* dy, void* dx, int rows, int F, hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)rows * (F / 8) + 255) / 256);
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_geglu_bwd<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, (const f16*)dy, (f16*)dx, (size_t)rows, F);
+  else hipLaunchKernelGGL((k_geglu_bwd<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, (size_t)rows, F);
+}
+
+// ---------------------------------------------------------------------------------- misc
+template <class T>
+__global__ void k_copy_cols(const T* src, long lds_, T* dst, long ldd, size_t rows, int cols, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cch = cols / 8;
+  if (idx >= rows * cch) return;
+  const size_t row = idx / cch;
+  const int c0 = (int)(idx - row * cch) * 8;
+  uint4 v = *reinterpret_cast<const uint4*>(src + row * lds_ + c0);
+  if (accumulate) {
+    uint4 o = *reinterpret_cast<const uint4*>(dst + row * ldd + c0);
+    const T* a = reinterpret_cast<const T*>(&v);
+    const T* b = reinterpret_cast<const T*>(&o);
+    T r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]));
+    v = *reinterpret_cast<uint4*>(r);
+  }
+  *reinterpret_cast<uint4*>(dst + row * ldd + c0) = v;
+}
+void launch_copy_cols(int dtype, const void* src, long lds_, void* dst, long ldd, int rows, int cols, int accumulate,
+                      hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)rows * (cols / 8) + 255) / 256);
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_copy_cols<f16>), dim3(nb), dim3(256), 0, st, (const f16*)src, lds_, (f16*)dst, ldd, (size_t)rows, cols, accumulate);
+  else hipLaunchKernelGGL((k_copy_cols<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)src, lds_, (bf16*)dst, ldd, (size_t)rows, cols, accumulate);
+}
+
+template <class T>
+__global__ void k_pool2x2(const T* src, T* dst, int B, int h, int w, int C, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cch = C / 8;
+  if (idx >= (size_t)B * h * w * cch) return;
+  const size_t pix = idx / cch;
+  const int c0 = (int)(idx - pix * cch) * 8;
+  const int b = (int)(pix / ((size_t)h * w));
+  const int r = (int)(pix - (size_t)b * h * w), y = r / w, x = r - y * w;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      uint4 v = *reinterpret_cast<const uint4*>(src + (((size_t)b * 2 * h + 2 * y + dy) * 2 * w + 2 * x + dx) * C + c0);
+      const T* a = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(a[i]);
+    }
+  if (accumulate) {
+    uint4 v = *reinterpret_cast<const uint4*>(dst + pix * C + c0);
+    const T* a = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(a[i]);
+  }
+  T o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = from_f32<T>(acc[i]);
+  *reinterpret_cast<uint4*>(dst + pix * C + c0) = *reinterpret_cast<uint4*>(o);
+}
+void launch_pool2x2_sum(int dtype, const void* src, void* dst, int B, int h, int w, int C, int accumulate,
+                        hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)B * h * w * (C / 8) + 255) / 256);
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_pool2x2<f16>), dim3(nb), dim3(256), 0, st, (const f16*)src, (f16*)dst, B, h, w, C, accumulate);
+  else hipLaunchKernelGGL((k_pool2x2<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, B, h, w, C, accumulate);
+}
+
+template <class T>
+__global__ void k_f32_to_t(const float* s, T* d, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = from_f32<T>(s[i]);
+}
+template <class T>
+__global__ void k_t_to_f32(const T* s, float* d, size_t n, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = accumulate ? d[i] + to_f32<T>(s[i]) : to_f32<T>(s[i]);
+}
+void launch_f32_to_t(int dtype, const float* src, void* dst, size_t n, hipStream_t st) {
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_f32_to_t<f16>), dim3(nb), dim3(256), 0, st, src, (f16*)dst, n);
+  else hipLaunchKernelGGL((k_f32_to_t<bf16>), dim3(nb), dim3(256), 0, st, src, (bf16*)dst, n);
+}
+void launch_t_to_f32(int dtype, const void* src, float* dst, size_t n, int accumulate, hipStream_t st) {
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_t_to_f32<f16>), dim3(nb), dim3(256), 0, st, (const f16*)src, dst, n, accumulate);
+  else hipLaunchKernelGGL((k_t_to_f32<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)src, dst, n, accumulate);
+}
+
+// Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos(t f_i) | sin(t f_i)], f_i = 10000^(-i/half)
+template <class T>
+__global__ void k_timestep(float t, int dim, int B, T* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * dim) return;
+  const int j = i % dim, k = j < half ? j : j - half;
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t * f;
+  out[i] = from_f32<T>(j < half ? cosf(a) : sinf(a));
+}
+void launch_timestep_embedding(int dtype, float t, int dim, int B, void* out, hipStream_t st) {
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_timestep<f16>), dim3(cdiv(B * dim, 256)), dim3(256), 0, st, t, dim, B, (f16*)out);
+  else hipLaunchKernelGGL((k_timestep<bf16>), dim3(cdiv(B * dim, 256)), dim3(256), 0, st, t, dim, B, (bf16*)out);
+}
+
+}  // namespace dh

@@ -1,0 +1,178 @@
+"""Python handle of the native SD-2-depth U-Net engine (csrc/unet_engine.cpp).
+
+`HipUNet` mirrors the call surface the reference uses on its patched diffusers U-Net
+(model/unet_2d_condition.py:809-1198): `unet(sample, t, encoder_hidden_states=...,
+return_dict=False)` returns the 7-tuple `(eps, None, None, None, act0, act1, act2)`;
+with `return_dict=True` it returns `{'sample': eps}`.  On top of that it exposes the
+explicit `forward` / `backward` pair the guided loop drives (no autograd graph).
+Activations are channels-last 16-bit tensors; the [B,C,h,w] tensors handed out are views.
+"""
+import ctypes
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib
+
+SD2_DEPTH = dict(in_channels=5, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                 layers_per_block=2, heads=(5, 10, 20, 20), cross_attention_dim=1024,
+                 norm_groups=32, sample_size=64, text_len=77)
+
+
+class HipUNet:
+    def __init__(self, cfg=None, dtype=torch.float16, max_batch=2, device=None):
+        _lib.require_gpu()
+        self.cfg = dict(SD2_DEPTH if cfg is None else cfg)
+        self.cfg.setdefault("text_len", 77)
+        self.dtype = dtype
+        self.max_batch = int(max_batch)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        c = _lib.UNetConfig()
+        c.in_channels, c.out_channels, c.n_levels = self.cfg["in_channels"], self.cfg["out_channels"], 4
+        for i in range(4):
+            c.block_out_channels[i] = self.cfg["block_out_channels"][i]
+            c.heads[i] = self.cfg["heads"][i]
+        c.layers_per_block = self.cfg["layers_per_block"]
+        c.cross_attention_dim = self.cfg["cross_attention_dim"]
+        c.norm_groups = self.cfg["norm_groups"]
+        c.sample_size = self.cfg["sample_size"]
+        c.text_len = self.cfg["text_len"]
+        c.max_batch = self.max_batch
+        c.dtype = _lib.DTYPE_CODE[dtype]
+        self._L = _lib.lib()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dh_unet_create(ctypes.byref(c), ctypes.byref(h)), "dh_unet_create")
+        self._h = h
+        self.config = SimpleNamespace(in_channels=c.in_channels, out_channels=c.out_channels,
+                                      sample_size=c.sample_size)
+        self.sample_size = c.sample_size
+        self._table = None
+        ch, s = self.cfg["block_out_channels"], c.sample_size
+        self.act_shapes = [(s // 2, s // 2, ch[2]), (s, s, ch[1]), (s, s, ch[0])]   # (h, w, C) of act0..2
+        self._saved_batch = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.dh_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------
+    def param_table(self):
+        if self._table is None:
+            n = self._L.dh_unet_num_params(self._h)
+            tab = []
+            for i in range(n):
+                name = ctypes.c_char_p()
+                nd = ctypes.c_int()
+                shp = (ctypes.c_int64 * 4)()
+                _lib.check(self._L.dh_unet_param_info(self._h, i, ctypes.byref(name), ctypes.byref(nd), shp))
+                tab.append((name.value.decode(), tuple(int(shp[k]) for k in range(nd.value))))
+            self._table = tab
+        return self._table
+
+    def load_state_dict(self, sd, strict=True):
+        """sd: diffusers-named tensors in torch layout (any float dtype / device)."""
+        names = {n for n, _ in self.param_table()}
+        missing = names - set(sd.keys())
+        if strict and missing:
+            raise KeyError(f"missing parameters: {sorted(missing)[:5]} ... ({len(missing)})")
+        st = _lib.stream_ptr()
+        for i, (name, shape) in enumerate(self.param_table()):
+            if name not in sd:
+                continue
+            t = sd[name].detach()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+            t = t.to(self.device, torch.float32).contiguous()
+            _lib.check(self._L.dh_unet_load_param(self._h, i, _lib.ptr(t), st), f"load {name}")
+        torch.cuda.synchronize(self.device)
+
+    def init_synthetic(self, seed=0):
+        """Seeded random weights of the exact architecture (no checkpoint needed):
+        matrices N(0, 1/fan_in), norm gains 1 + 0.1 N, other vectors 0.02 N."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        st = _lib.stream_ptr()
+        for i, (name, shape) in enumerate(self.param_table()):
+            if len(shape) >= 2:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                t = torch.randn(shape, generator=g, device=self.device) * (1.0 / math.sqrt(fan_in))
+            elif "norm" in name and name.endswith("weight"):
+                t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=self.device)
+            else:
+                t = 0.02 * torch.randn(shape, generator=g, device=self.device)
+            t = t.float().contiguous()
+            _lib.check(self._L.dh_unet_load_param(self._h, i, _lib.ptr(t), st), f"load {name}")
+        torch.cuda.synchronize(self.device)
+
+    def weight_bytes(self):
+        return int(self._L.dh_unet_weight_bytes(self._h))
+
+    def workspace_bytes(self):
+        return int(self._L.dh_unet_workspace_bytes(self._h))
+
+    # ---- compute ------------------------------------------------------------------------
+    def forward(self, sample_nhwc, timestep, text, save_for_backward=False, want_acts=True):
+        """sample_nhwc [B,H,W,Cin] f32, text [B,L,D] f32 (device, contiguous).
+        Returns eps [B,H,W,Cout] f32 and a list of 3 channels-last activations [B,h,w,C]."""
+        B = sample_nhwc.shape[0]
+        s = self.sample_size
+        eps = torch.empty((B, s, s, self.cfg["out_channels"]), dtype=torch.float32, device=self.device)
+        acts = None
+        arr = None
+        if want_acts:
+            acts = [torch.empty((B,) + shp, dtype=self.dtype, device=self.device) for shp in self.act_shapes]
+            arr = (ctypes.c_void_p * 3)(*[a.data_ptr() for a in acts])
+        _lib.check(self._L.dh_unet_forward(self._h, _lib.ptr(sample_nhwc), float(timestep), _lib.ptr(text), B,
+                                           1 if save_for_backward else 0, _lib.ptr(eps), arr, _lib.stream_ptr()),
+                   "dh_unet_forward")
+        self._saved_batch = B if save_for_backward else 0
+        return eps, acts
+
+    def backward(self, d_acts=None, d_eps=None, want_sample_grad=True, want_text_grad=False):
+        """Gradients of the last saved forward.  d_acts: list of 3 (or None entries) channels-last
+        tensors in the engine dtype; d_eps [B,H,W,Cout] f32.  Returns (d_sample, d_text)."""
+        B = self._saved_batch
+        if B == 0:
+            raise RuntimeError("backward() needs a forward(save_for_backward=True) first")
+        s = self.sample_size
+        arr = None
+        if d_acts is not None:
+            ptrs = []
+            for a, shp in zip(d_acts, self.act_shapes):
+                if a is None:
+                    ptrs.append(None)
+                else:
+                    assert a.dtype == self.dtype and a.is_contiguous() and tuple(a.shape) == (B,) + shp
+                    ptrs.append(a.data_ptr())
+            arr = (ctypes.c_void_p * 3)(*ptrs)
+        d_sample = torch.empty((B, s, s, self.cfg["in_channels"]), dtype=torch.float32, device=self.device) \
+            if want_sample_grad else None
+        d_text = torch.empty((B, self.cfg["text_len"], self.cfg["cross_attention_dim"]), dtype=torch.float32,
+                             device=self.device) if want_text_grad else None
+        _lib.check(self._L.dh_unet_backward(self._h, arr, _lib.ptr(d_eps), _lib.ptr(d_sample), _lib.ptr(d_text),
+                                            _lib.stream_ptr()), "dh_unet_backward")
+        return d_sample, d_text
+
+    def stats(self):
+        f, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._L.dh_unet_stats(self._h, ctypes.byref(f), ctypes.byref(b), ctypes.byref(n)))
+        return dict(flops_fwd=f.value, flops_bwd=b.value, ops=n.value)
+
+    # reference-style call (NCHW in, 7-tuple out)
+    def __call__(self, sample, timestep, encoder_hidden_states, cross_attention_kwargs=None, return_dict=True):
+        x = sample.detach().to(self.device, torch.float32).permute(0, 2, 3, 1).contiguous()
+        txt = encoder_hidden_states.detach().to(self.device, torch.float32).contiguous()
+        t = float(timestep.item()) if isinstance(timestep, torch.Tensor) else float(timestep)
+        eps, acts = self.forward(x, t, txt, save_for_backward=False, want_acts=not return_dict)
+        eps = eps.permute(0, 3, 1, 2)
+        if return_dict:
+            return {"sample": eps}
+        a = [t_.permute(0, 3, 1, 2) for t_ in acts]
+        return (eps, None, None, None, a[0], a[1], a[2])

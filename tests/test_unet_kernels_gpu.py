@@ -1,0 +1,187 @@
+"""GPU parity of each U-Net kernel (through the debug C-ABI hooks) against plain PyTorch
+fp32 references of the same op.  Tolerances are fp16/bf16-storage tolerances: the kernels
+read 16-bit inputs, accumulate in f32 and round the output once."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {torch.float16: 0, torch.bfloat16: 1}
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def L():
+    from diffusionhandles_amd import _lib
+    return _lib
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def close(got, ref, rtol, atol, what=""):
+    err = (got.float() - ref.float()).abs()
+    tol = atol + rtol * ref.float().abs()
+    bad = (err > tol).float().mean().item()
+    assert bad < 1e-4, f"{what}: max err {err.max().item():.4g}, frac bad {bad:.3g}, ref max {ref.abs().max().item():.3g}"
+
+
+def run_gemm(dtype, A, lda, W, M, N, K, mode=0, geo=(0, 0, 0, 0, 0, 1, 0), bias=None, rowvec=None, rpb=1, R=None, silu=0,
+             split=True):
+    lib = L().lib()
+    C = torch.empty((M, N), dtype=dtype, device=dev())
+    part = torch.empty(16 << 20, dtype=torch.float32, device=dev()) if split else None
+    Hin, Win, Cin, Hout, Wout, stride, up = geo
+    rc = lib.dh_dbg_gemm(DT[dtype], P(A), lda, P(W), M, N, K, mode, Hin, Win, Cin, Hout, Wout, stride, up, P(bias),
+                         P(rowvec), rowvec.shape[1] if rowvec is not None else 0, rpb, P(R), N, P(C), N, silu, P(part),
+                         part.numel() if part is not None else 0, L().stream_ptr())
+    L().check(rc, "dh_dbg_gemm")
+    return C
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (1024, 640, 2560), (256, 1280, 1280), (64, 1280, 1280),
+                                     (77, 2560, 1024), (3, 1280, 320), (4096, 2560, 320), (200, 128, 6400)])
+def test_gemm_dense(dtype, M, N, K):
+    g = torch.Generator(device=dev()).manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g, device=dev()).to(dtype)
+    W = (torch.randn(N, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+    bias = torch.randn(N, generator=g, device=dev())
+    R = torch.randn(M, N, generator=g, device=dev()).to(dtype)
+    ref = A.float() @ W.float().t() + bias + R.float()
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    for split in (True, False):
+        C = run_gemm(dtype, A, K, W, M, N, K, bias=bias, R=R, split=split)
+        close(C, ref, tol, tol, f"gemm {M}x{N}x{K} split={split}")
+    # asymmetric operands catch a transposed output: also check silu + rowvec path
+    rv = torch.randn(2, N, generator=g, device=dev())
+    if M % 2 == 0:
+        C = run_gemm(dtype, A, K, W, M, N, K, rowvec=rv, rpb=M // 2, silu=1)
+        z = A.float() @ W.float().t() + rv.repeat_interleave(M // 2, dim=0)
+        close(C, F.silu(z), tol, tol, "gemm silu/rowvec")
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,Cin,Cout,H,stride,up", [(1, 320, 320, 64, 1, 0), (2, 640, 320, 32, 1, 0), (1, 320, 320, 64, 2, 0),
+                                                     (1, 1280, 1280, 8, 1, 1), (2, 64, 128, 16, 1, 0), (1, 1920, 640, 32, 1, 0),
+                                                     (2, 128, 128, 16, 2, 0), (1, 640, 640, 32, 1, 1)])
+def test_conv3_forward_and_input_gradient(dtype, B, Cin, Cout, H, stride, up):
+    g = torch.Generator(device=dev()).manual_seed(Cin + Cout + H + stride + up)
+    x = torch.randn(B, Cin, H, H, generator=g, device=dev()).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g, device=dev()) / (9 * Cin) ** 0.5).to(dtype)
+    bias = torch.randn(Cout, generator=g, device=dev())
+    xr = x.float().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2.0, mode="nearest") if up else xr
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1)
+    Ho = ref.shape[-1]
+    wf = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()                      # [Cout][tap][Cin]
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    C = run_gemm(dtype, nhwc(x), Cin, wf, B * Ho * Ho, Cout, 9 * Cin, mode=1, geo=(H, H, Cin, Ho, Ho, stride, up), bias=bias)
+    close(C.view(B, Ho, Ho, Cout), nhwc(ref), tol, tol, "conv fwd")
+    # input gradient through the same kernel with flipped / transposed weights
+    dy = torch.randn(ref.shape, generator=g, device=dev()).to(dtype)
+    gref, = torch.autograd.grad(ref, xr, dy.float())
+    wb = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()           # [Cin][tap'][Cout]
+    if up:
+        hi = run_gemm(dtype, nhwc(dy), Cout, wb, B * Ho * Ho, Cin, 9 * Cout, mode=1, geo=(Ho, Ho, Cout, Ho, Ho, 1, 0))
+        dx = torch.empty((B, H, H, Cin), dtype=dtype, device=dev())
+        L().check(L().lib().dh_dbg_pool2x2(DT[dtype], P(hi), P(dx), B, H, H, Cin, 0, L().stream_ptr()))
+    elif stride == 2:
+        dx = run_gemm(dtype, nhwc(dy), Cout, wb, B * H * H, Cin, 9 * Cout, mode=2, geo=(Ho, Ho, Cout, H, H, 1, 0)).view(B, H, H, Cin)
+    else:
+        dx = run_gemm(dtype, nhwc(dy), Cout, wb, B * H * H, Cin, 9 * Cout, mode=1, geo=(H, H, Cout, H, H, 1, 0)).view(B, H, H, Cin)
+    close(dx.reshape(B, H, H, Cin), nhwc(gref), tol, tol * gref.abs().max().item(), "conv dX")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,HW,C,silu", [(1, 4096, 320, 1), (2, 1024, 960, 1), (1, 64, 2560, 1), (2, 256, 1280, 0), (1, 4096, 64, 1)])
+def test_groupnorm(dtype, B, HW, C, silu):
+    g = torch.Generator(device=dev()).manual_seed(C + HW)
+    x = (torch.randn(B, HW, C, generator=g, device=dev()) * 2 + 0.5).to(dtype)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g, device=dev())
+    beta = 0.1 * torch.randn(C, generator=g, device=dev())
+    dy = torch.randn(B, HW, C, generator=g, device=dev()).to(dtype)
+    acc0 = torch.randn(B, HW, C, generator=g, device=dev()).to(dtype)
+    xr = x.float().requires_grad_(True)
+    ref = F.group_norm(xr.transpose(1, 2), 32, gamma, beta, eps=1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    gref, = torch.autograd.grad(ref, xr, dy.float())
+    y = torch.empty_like(x); dx = acc0.clone()
+    stats = torch.empty(B * 32 * 2, dtype=torch.float32, device=dev()); scr = torch.empty(B * 32 * 2 + 64, dtype=torch.float32, device=dev())
+    L().check(L().lib().dh_dbg_groupnorm(DT[dtype], P(x), P(gamma), P(beta), P(y), P(stats), P(dy), P(dx), P(scr), B, HW, C, 32,
+                                         1e-5, silu, 1, L().stream_ptr()))
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    close(y, ref, tol, tol, "gn fwd")
+    close(dx, gref + acc0.float(), tol, tol * 2, "gn bwd (accumulate)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (77, 1280), (300, 64)])
+def test_layernorm(dtype, rows, C):
+    g = torch.Generator(device=dev()).manual_seed(C + rows)
+    x = (torch.randn(rows, C, generator=g, device=dev()) * 1.5 - 0.3).to(dtype)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g, device=dev()); beta = 0.1 * torch.randn(C, generator=g, device=dev())
+    dy = torch.randn(rows, C, generator=g, device=dev()).to(dtype); add = torch.randn(rows, C, generator=g, device=dev()).to(dtype)
+    xr = x.float().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    gref, = torch.autograd.grad(ref, xr, dy.float())
+    y = torch.empty_like(x); dx = torch.empty_like(x); stats = torch.empty(rows * 2, dtype=torch.float32, device=dev())
+    L().check(L().lib().dh_dbg_layernorm(DT[dtype], P(x), P(gamma), P(beta), P(y), P(stats), P(dy), P(add), P(dx), rows, C, 1e-5, L().stream_ptr()))
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    close(y, ref, tol, tol, "ln fwd")
+    close(dx, gref + add.float(), tol, tol * 2, "ln bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_geglu(dtype):
+    g = torch.Generator(device=dev()).manual_seed(5)
+    rows, Fd = 1000, 1280
+    x = torch.randn(rows, 2 * Fd, generator=g, device=dev()).to(dtype); dy = torch.randn(rows, Fd, generator=g, device=dev()).to(dtype)
+    xr = x.float().requires_grad_(True)
+    h, gt = xr.chunk(2, dim=-1)
+    ref = h * F.gelu(gt)
+    gref, = torch.autograd.grad(ref, xr, dy.float())
+    y = torch.empty(rows, Fd, dtype=dtype, device=dev()); dx = torch.empty_like(x)
+    L().check(L().lib().dh_dbg_geglu(DT[dtype], P(x), P(y), P(dy), P(dx), rows, Fd, L().stream_ptr()))
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    close(y, ref, tol, tol, "geglu fwd"); close(dx, gref, tol, tol, "geglu bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 5, 1024, 1024), (2, 2, 256, 256), (1, 20, 64, 64), (2, 5, 1024, 77), (1, 10, 200, 77), (1, 2, 4096, 4096)])
+def test_attention_forward_backward(dtype, B, H, Nq, Nk):
+    g = torch.Generator(device=dev()).manual_seed(Nq + Nk + H)
+    C = H * 64
+    q = torch.randn(B, Nq, C, generator=g, device=dev()).to(dtype)
+    k = torch.randn(B, Nk, C, generator=g, device=dev()).to(dtype)
+    v = torch.randn(B, Nk, C, generator=g, device=dev()).to(dtype)
+    # one spiked key per head forces a large running-max jump mid-stream (online softmax rescale)
+    k[:, Nk // 2, :] *= 6.0
+    do = torch.randn(B, Nq, C, generator=g, device=dev()).to(dtype)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t, n: t.view(B, n, H, 64).transpose(1, 2)
+    s = (sp(qr, Nq) @ sp(kr, Nk).transpose(-1, -2)) * 0.125
+    ref = (torch.softmax(s, dim=-1) @ sp(vr, Nk)).transpose(1, 2).reshape(B, Nq, C)
+    lse_ref = torch.logsumexp(s, dim=-1)
+    gq, gk, gv = torch.autograd.grad(ref, (qr, kr, vr), do.float())
+    o = torch.empty_like(q); lse = torch.empty(B, H, Nq, dtype=torch.float32, device=dev()); delta = torch.empty_like(lse)
+    dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    L().check(L().lib().dh_dbg_attention(DT[dtype], P(q), C, P(k), P(v), C, P(o), C, P(lse), P(do), P(delta), P(dq), P(dk), P(dv),
+                                         B, H, Nq, Nk, L().stream_ptr()))
+    tol = 5e-3 if dtype == torch.float16 else 3e-2
+    close(o, ref, tol, tol, "attn fwd")
+    close(lse, lse_ref, 1e-3, 2e-3, "attn lse")
+    for got, r, nm in ((dq, gq, "dq"), (dk, gk, "dk"), (dv, gv, "dv")):
+        close(got, r, 2 * tol, 2 * tol * max(1.0, r.abs().max().item()) * 0.2, "attn " + nm)
