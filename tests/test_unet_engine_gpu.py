@@ -49,7 +49,7 @@ def run_case(cfg, dtype, B, t, tol_f, tol_b, check_text=True):
     ge = torch.randn(out[0].shape, generator=g, device=dev()) * 0.05
     gs16 = [x.to(dtype) for x in gs]
     loss = sum((o * x.float()).sum() for o, x in zip((out[4], out[5], out[6]), gs16)) + (out[0] * ge).sum()
-    gx, gt = torch.autograd.grad(loss, (xs, xt))
+    gx, gt = torch.autograd.grad(loss, (xs, xt), retain_graph=True)
     d_acts = [x.permute(0, 2, 3, 1).contiguous() for x in gs16]
     d_sample, d_text = hip.backward(d_acts, ge.permute(0, 2, 3, 1).contiguous(), True, check_text)
     e1 = rel(d_sample.permute(0, 3, 1, 2), gx)
