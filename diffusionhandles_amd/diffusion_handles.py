@@ -1,0 +1,62 @@
+"""DiffusionHandles facade (reference diffusion_handles.py:15-166) on the native MI355X path."""
+import torch
+
+from . import conf as _conf
+from .depth_transform import normalize_depth, transform_depth
+from .guided_stable_diffuser import GuidedStableDiffuser
+from .stable_null_inverter import StableNullInverter
+
+
+class DiffusionHandles:
+    def __init__(self, conf=None, **diffuser_kwargs):
+        if conf is None:
+            conf = _conf.load_default()
+        self.conf = _conf.Conf.wrap(conf) if isinstance(conf, dict) else conf
+        self.diffuser = GuidedStableDiffuser(conf=self.conf.guided_diffuser, **diffuser_kwargs)
+        self.inverter = StableNullInverter(self.diffuser)
+        self.device = torch.device("cpu")
+
+    def to(self, device=None):
+        self.diffuser.to(device=device)
+        self.inverter.to(device=device)
+        self.device = torch.device(device)
+        return self
+
+    def invert_input_image(self, img, depth, prompt):
+        """-> (null_text_emb [T,1,77,D], init_noise [1,4,h,w])"""
+        disparity = normalize_depth(1.0 / depth)
+        _, init_noise, null_text_emb = self.inverter.invert(target_img=img, depth=disparity, prompt=prompt,
+                                                            num_inner_steps=5, verbose=False)
+        return null_text_emb, init_noise
+
+    def generate_input_image(self, depth, prompt, null_text_emb=None, init_noise=None):
+        """-> (null_text_emb, init_noise, activations [3], latent_image)"""
+        disparity = normalize_depth(1.0 / depth)
+        with torch.no_grad():
+            activations, latent_image, null_text_emb, init_noise = self.diffuser.initial_inference(
+                init_latents=init_noise, depth=disparity, uncond_embeddings=null_text_emb, prompt=prompt)
+        return null_text_emb, init_noise, activations, latent_image
+
+    def set_foreground(self, depth, fg_mask, bg_depth):
+        """Poisson blend of the background depth into the dilated mask hole
+        (reference diffusion_handles.py:90-111 / utils.solve_laplacian_depth) -- SURVEY 8f 'next'."""
+        raise NotImplementedError("set_foreground (Laplacian depth blend) is scheduled after the hot path (SURVEY 8f-1)")
+
+    def transform_foreground(self, depth, prompt, fg_mask, bg_depth, null_text_emb, init_noise, activations,
+                             rot_angle=None, rot_axis=None, translation=None, fg_weight=None, bg_weight=None,
+                             use_input_depth_normalization=False):
+        with torch.no_grad():
+            edited_disparity, correspondences = transform_depth(
+                depth=depth, bg_depth=bg_depth, fg_mask=fg_mask,
+                intrinsics=self.diffuser.get_depth_intrinsics(device=depth.device),
+                rot_angle=rot_angle, rot_axis=rot_axis, translation=translation,
+                use_input_depth_normalization=use_input_depth_normalization,
+                depth_transform_mode=self.conf.depth_transform_mode)
+            results = self.diffuser.guided_inference(
+                latents=init_noise, depth=edited_disparity, uncond_embeddings=null_text_emb, prompt=prompt,
+                activations_orig=activations, correspondences=correspondences, fg_weight=fg_weight,
+                bg_weight=bg_weight, save_denoising_steps=self.conf.guided_diffuser.save_denoising_steps)
+        if self.conf.guided_diffuser.save_denoising_steps:
+            edited_img, denoising_steps = results
+            return edited_img, edited_disparity, denoising_steps
+        return results, edited_disparity

@@ -1,0 +1,296 @@
+"""GuidedStableDiffuser on the native MI355X engine.
+
+Same public surface as the reference class (guided_stable_diffuser.py:22-610): `.unet .vae
+.text_encoder .tokenizer .scheduler .conf .device`, `to`, `get_image_shape`,
+`get_feature_shape`, `init_prompt`, `init_depth`, `get_depth_intrinsics`,
+`initial_inference`, `guided_inference`, `decode_latent_image`, `encode_latent_image`,
+`process_correspondences`, `get_timesteps`, `prepare_extra_step_kwargs`, and
+`StepGuidanceWeightSchedule`.
+
+What differs underneath: the U-Net forward, the guidance energy with its gradient, the
+backward-to-latent, the latent update and the CFG/DDIM step are explicit calls into the HIP
+library (no autograd graph, no per-iteration host sync), activations stay channels-last
+16-bit, and zero-weight energy terms are skipped (exact: 0 * finite = 0).
+N = 0 / N = 1 correspondences are defined (fg term skipped / handled) instead of NaN / TypeError.
+"""
+import inspect
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .guided_diffuser import GuidedDiffuser
+from .losses import energy_and_grad, process_correspondences as _process_correspondences
+from .scheduler import DDIMScheduler
+from .unet import HipUNet, SD2_DEPTH
+
+CFG_SCALE = 7.5
+
+
+class GuidanceWeightSchedule:
+    def __call__(self, denoising_step: int, optimization_step: int):
+        return [1.0] * 3, [1.0] * 3
+
+
+class StepGuidanceWeightSchedule(GuidanceWeightSchedule):
+    """Piecewise-constant lookup: last entry with step <= query, per-layer product
+    (guided_stable_diffuser.py:622-665)."""
+
+    def __init__(self, denoising_steps, optimization_steps):
+        for steps in (denoising_steps, optimization_steps):
+            if not all(len(f) == len(b) for _, f, b in steps):
+                raise ValueError("Number of foreground and background weights do not match.")
+        if len(denoising_steps[0][1]) != len(optimization_steps[0][1]):
+            raise ValueError("Number of denoising and optimization weights do not match.")
+        self.denoising_steps = sorted(denoising_steps, key=lambda s: s[0])
+        self.optimization_steps = sorted(optimization_steps, key=lambda s: s[0])
+
+    @staticmethod
+    def _lookup(table, q):
+        hit = None
+        for step, f, b in table:
+            if q >= step:
+                hit = (f, b)
+        return hit
+
+    def __call__(self, denoising_step: int, optimization_step: int):
+        d = self._lookup(self.denoising_steps, denoising_step)
+        o = self._lookup(self.optimization_steps, optimization_step)
+        if d is None or o is None:
+            raise ValueError(f"Could not find weights for denoising step {denoising_step} and optimization step "
+                             f"{optimization_step}.")
+        return [x * y for x, y in zip(d[0], o[0])], [x * y for x, y in zip(d[1], o[1])]
+
+
+def build_weight_schedule(fg_weight, bg_weight, max_step, kind):
+    """fg/bg_weight are the user-facing values; the x30 happens here (guided_stable_diffuser.py:336-373)."""
+    wf, wb = fg_weight * 30, bg_weight * 30
+    if kind == "constant":
+        ff, fb = np.linspace(wf, wf, max_step), np.linspace(wb, wb, max_step)
+    elif kind == "linear":
+        ff, fb = np.linspace(wf, 0.0, max_step), np.linspace(wb, 0.0, max_step)
+    elif kind == "quadratic":
+        ff, fb = np.linspace(np.sqrt(wf), 0.0, max_step) ** 2, np.linspace(np.sqrt(wb), 0.0, max_step) ** 2
+    else:
+        raise ValueError(f"Unknown guidance schedule type: {kind}")
+    pattern = [([0.0, 0.0, 7.5], [0.0, 0.0, 1.5]), ([0.0, 5.0, 0.0], [0.0, 1.5, 0.0]), ([0.0, 5.0, 7.5], [0.0, 1.5, 1.5])]
+    den = []
+    for t in range(max_step):
+        pf, pb = pattern[t % 3]
+        den.append((t, (np.array(pf) * ff[t]).tolist(), (np.array(pb) * fb[t]).tolist()))
+    den.append((max_step, [0.0] * 3, [0.0] * 3))
+    opt = [(0, [2.5] * 3, [1.25] * 3), (1, [1.25] * 3, [2.5] * 3), (2, [1.25] * 3, [1.25] * 3), (3, [2.5] * 3, [2.5] * 3)]
+    return StepGuidanceWeightSchedule(den, opt)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+class GuidedStableDiffuser(GuidedDiffuser):
+    def __init__(self, conf, unet=None, vae=None, text_encoder=None, tokenizer=None, dtype=torch.float16,
+                 unet_config=None, max_batch=2, synthetic_seed=0):
+        super().__init__(conf=conf)
+        self.scheduler = DDIMScheduler()
+        self.dtype = dtype
+        self._unet_config = dict(SD2_DEPTH if unet_config is None else unet_config)
+        self._max_batch = max(2, int(max_batch))
+        self._synthetic_seed = synthetic_seed
+        self.unet = unet            # built lazily in .to(device): the engine lives on a GPU
+        self.vae = vae
+        self.text_encoder = text_encoder
+        self.tokenizer = tokenizer
+        self.device = torch.device("cpu")
+        # fp16 needs the guidance gradient scaled through the backward pass
+        self.grad_scale = 256.0 if dtype == torch.float16 else 1.0
+
+    # ---- plumbing -----------------------------------------------------------------------
+    def to(self, device=None):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("GuidedStableDiffuser runs on an MI355X HIP device only (no CPU fallback)")
+        _lib.require_gpu()
+        with torch.cuda.device(device):
+            if self.unet is None:
+                self.unet = HipUNet(self._unet_config, dtype=self.dtype, max_batch=self._max_batch, device=device)
+                wdir = os.environ.get("DIFFHANDLES_UNET_SAFETENSORS")
+                if wdir:
+                    from safetensors.torch import load_file
+                    self.unet.load_state_dict(load_file(wdir))
+                else:
+                    self.unet.init_synthetic(self._synthetic_seed)     # no checkpoint offline: seeded weights
+            from .synthetic import SyntheticTextEncoder, SyntheticTokenizer, SyntheticVAE
+            if self.tokenizer is None:
+                self.tokenizer = SyntheticTokenizer()
+            if self.text_encoder is None:
+                self.text_encoder = SyntheticTextEncoder(dim=self._unet_config["cross_attention_dim"])
+            if self.vae is None:
+                self.vae = SyntheticVAE()
+            self.text_encoder = self.text_encoder.to(device)
+            self.vae = self.vae.to(device)
+        self.device = device
+        return self
+
+    def get_image_shape(self):
+        f = self.get_feature_shape()
+        s = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        return (f[0] * s, f[1] * s, 3)
+
+    def get_feature_shape(self):
+        hw = self.unet.sample_size
+        hw = (hw, hw) if isinstance(hw, int) else hw
+        return (hw[0], hw[1], self.unet.config.out_channels)
+
+    def _encode(self, texts):
+        ids = self.tokenizer(texts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                             return_tensors="pt")
+        return self.text_encoder(ids.input_ids.to(self.device))[0].float()
+
+    @torch.no_grad()
+    def init_prompt(self, prompt: str):
+        return torch.cat([self._encode([""]), self._encode([prompt])])
+
+    @torch.no_grad()
+    def init_depth(self, depth):
+        h, w = self.get_feature_shape()[:2]
+        depth = torch.nn.functional.interpolate(depth, size=(h, w), mode="bicubic", align_corners=False)
+        lo = torch.amin(depth, dim=[1, 2, 3], keepdim=True)
+        hi = torch.amax(depth, dim=[1, 2, 3], keepdim=True)
+        return 2.0 * (depth - lo) / (hi - lo) - 1.0
+
+    @staticmethod
+    def get_depth_intrinsics(device=None):
+        f = 1.0 / np.tan(0.5 * 55.0 * (np.pi / 180.0))
+        return torch.tensor([[f, 0, 0], [0, f, 0], [0, 0, 1]], dtype=torch.float32, device=device)
+
+    def encode_latent_image(self, image):
+        raise NotImplementedError
+
+    def decode_latent_image(self, latent_image):
+        image = self.vae.decode(latent_image / self.vae.config.scaling_factor, return_dict=False)[0]
+        return (image / 2 + 0.5).clamp(0, 1)
+
+    def process_correspondences(self, correspondences, img_res, bg_erosion=0):
+        return _process_correspondences(correspondences, img_res, bg_erosion, grid=self.unet.sample_size,
+                                        device=self.device)
+
+    def get_timesteps(self, num_inference_steps, strength):
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        return self.scheduler.timesteps[t_start * self.scheduler.order:], num_inference_steps - t_start
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        keys = set(inspect.signature(self.ddim_step).parameters.keys())
+        kw = {}
+        if "eta" in keys:
+            kw["eta"] = eta
+        if "generator" in keys:
+            kw["generator"] = generator
+        return kw
+
+    # ---- native loop pieces --------------------------------------------------------------
+    def ddim_step(self, x, eps_u, eps_c, t, scale=CFG_SCALE, eta=0.0, generator=None):
+        """x, eps: [B,H,W,4] f32 channels-last.  CFG combine + DDIM step in one kernel."""
+        a_t, a_p = self.scheduler.step_alphas(t)
+        out = torch.empty_like(x)
+        L = _lib.lib()
+        _lib.check(L.dh_ddim_cfg_step(_lib.ptr(out), _lib.ptr(x), _lib.ptr(eps_u), _lib.ptr(eps_c), float(scale), a_t,
+                                      a_p, x.numel(), _lib.stream_ptr()), "dh_ddim_cfg_step")
+        return out
+
+    def _unet_input(self, x, depth_nhwc, reps=1):
+        """x [1,H,W,4], depth [1,H,W,1] -> [reps,H,W,5]"""
+        s = torch.cat([x, depth_nhwc], dim=-1) if self.conf.use_depth else x
+        return s.expand(reps, -1, -1, -1).contiguous() if reps > 1 else s.contiguous()
+
+    def _cfg_eps(self, x, depth_nhwc, t, uncond, cond):
+        sample = self._unet_input(x, depth_nhwc, 2)
+        text = torch.cat([uncond.reshape(1, *cond.shape[1:]).to(self.device, torch.float32), cond]).contiguous()
+        eps, _ = self.unet.forward(sample, float(t), text, save_for_backward=False, want_acts=False)
+        return eps[0:1], eps[1:2]
+
+    # ---- reference API ----------------------------------------------------------------------
+    @torch.no_grad()
+    def initial_inference(self, init_latents, depth, uncond_embeddings, prompt):
+        """Returns (activations [3 x [T,C,h,w]], latents [1,4,H,W], uncond_embeddings, init_latents)."""
+        torch.manual_seed(self.conf.seed)
+        self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
+        timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
+        depth_nhwc = _nhwc(self.init_depth(depth.to(self.device, torch.float32))) if self.conf.use_depth else None
+        cond = self._encode([prompt]).contiguous()
+        if uncond_embeddings is None:
+            uncond_embeddings = self._encode([""])[None].expand(len(timesteps), -1, -1, -1)
+        s = self.unet.sample_size
+        if init_latents is None:
+            nlat = self.unet.config.in_channels - 1 if self.conf.use_depth else self.unet.config.in_channels
+            noise = torch.randn([1, nlat, s, s], dtype=torch.float32).to(self.device)
+            init_latents = self.scheduler.add_noise(torch.zeros_like(noise), noise, timesteps[0])
+        x = _nhwc(init_latents.to(self.device, torch.float32))
+        T = len(timesteps)
+        store = [torch.empty((T,) + shp, dtype=self.dtype, device=self.device) for shp in self.unet.act_shapes]
+        for t_idx, t in enumerate(timesteps):
+            _, acts = self.unet.forward(self._unet_input(x, depth_nhwc), float(t), cond, save_for_backward=False)
+            for k in range(3):
+                store[k][t_idx].copy_(acts[k][0])
+            eu, ec = self._cfg_eps(x, depth_nhwc, t, uncond_embeddings[t_idx], cond)
+            x = self.ddim_step(x, eu, ec, t)
+        activations = [a.permute(0, 3, 1, 2) for a in store]      # [T,C,h,w] views of channels-last storage
+        return activations, x.permute(0, 3, 1, 2), uncond_embeddings, init_latents
+
+    def guided_inference(self, latents, depth, uncond_embeddings, prompt, activations_orig, correspondences,
+                         fg_weight=None, bg_weight=None, save_denoising_steps=False, record=None):
+        fg_weight = self.conf.fg_weight if fg_weight is None else fg_weight
+        bg_weight = self.conf.bg_weight if bg_weight is None else bg_weight
+        with torch.no_grad():
+            torch.manual_seed(self.conf.seed)
+            self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
+            timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
+            pc = self.process_correspondences(correspondences, img_res=depth.shape[-1], bg_erosion=self.conf.bg_erosion)
+            depth_nhwc = _nhwc(self.init_depth(depth.to(self.device, torch.float32))) if self.conf.use_depth else None
+            cond = self._encode([prompt]).contiguous()
+            schedule = build_weight_schedule(fg_weight, bg_weight, self.conf.guidance_max_step,
+                                             self.conf.guidance_schedule_type)
+            denoising_steps = {"opt": [], "post-opt": []} if save_denoising_steps else None
+            # original activations as channels-last engine-dtype storage [T,h,w,C]
+            orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
+            size = (orig[2].shape[1], orig[2].shape[2])
+            n_pairs = len(pc["original_x"])
+            x = _nhwc(latents.to(self.device, torch.float32))
+            L = _lib.lib()
+            for t_idx, t in enumerate(timesteps):
+                if save_denoising_steps:
+                    denoising_steps["opt"].append([])
+                iteration = 0
+                while iteration < self.conf.num_optsteps and t_idx < self.conf.guidance_max_step:
+                    fgw, bgw = schedule(t_idx, iteration)
+                    active = [k for k in range(3) if (fgw[k] != 0.0 and n_pairs > 0) or bgw[k] != 0.0]
+                    if active:
+                        _, acts = self.unet.forward(self._unet_input(x, depth_nhwc), float(t), cond,
+                                                    save_for_backward=True)
+                        d_acts = [None, None, None]
+                        for k in active:
+                            _, g = energy_and_grad(acts[k][0], orig[k][t_idx], pc, fgw[k], bgw[k],
+                                                   self.conf.fg_patch_size, self.conf.bg_patch_size, size,
+                                                   self.conf.bg_loss_type, grad_scale=self.grad_scale)
+                            d_acts[k] = g[None]
+                        d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
+                        g_lat = d_sample[..., : x.shape[-1]].contiguous()
+                        x_new = torch.empty_like(x)
+                        _lib.check(L.dh_latent_update(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(g_lat), 0.1,
+                                                      self.grad_scale, x.numel(), _lib.stream_ptr()), "dh_latent_update")
+                        x = x_new
+                    if record is not None:
+                        record.setdefault("opt", []).append(x.permute(0, 3, 1, 2).clone())
+                    iteration += 1
+                if save_denoising_steps:
+                    denoising_steps["opt"][-1].append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
+                eu, ec = self._cfg_eps(x, depth_nhwc, t, uncond_embeddings[t_idx], cond)
+                x = self.ddim_step(x, eu, ec, t)
+                if record is not None:
+                    record.setdefault("step", []).append(x.permute(0, 3, 1, 2).clone())
+                if save_denoising_steps:
+                    denoising_steps["opt"][-1].append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
+            self.last_latents = x.permute(0, 3, 1, 2)
+            image = self.decode_latent_image(self.last_latents)
+        return (image, denoising_steps) if save_denoising_steps else image

@@ -1,0 +1,135 @@
+"""Null-text inversion on the native engine (reference stable_null_inverter.py:12-181).
+
+DDIM inversion (50 no-grad forwards) followed by the per-timestep Adam optimisation of the
+unconditional embedding.  The gradient d mse / d uncond is obtained from ONE explicit
+backward pass of the engine per inner step (eps -> text embedding, through the hoisted
+K|V projection), seeded with the closed-form d mse / d eps_uncond.
+"""
+import torch
+
+from . import _lib
+from .null_inverter import NullInverter
+
+VAE_SCALE = 0.18215
+
+
+class StableNullInverter(NullInverter):
+    def __init__(self, model, num_ddim_steps: int = 50, guidance_scale: float = 7.5):
+        super().__init__(model=model)
+        self.num_ddim_steps = num_ddim_steps
+        self.guidance_scale = guidance_scale
+        self.model.scheduler.set_timesteps(self.num_ddim_steps)
+        # the eps cotangent is ~1e-6: scale it through the 16-bit backward pass
+        self.eps_grad_scale = 65536.0 if model.dtype == torch.float16 else 1.0
+
+    def to(self, device):
+        self.model.to(device)
+        return self
+
+    @property
+    def scheduler(self):
+        return self.model.scheduler
+
+    def _step(self, x, eps_u, eps_c, scale, a_from, a_to):
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().dh_ddim_cfg_step(_lib.ptr(out), _lib.ptr(x), _lib.ptr(eps_u), _lib.ptr(eps_c), float(scale),
+                                               a_from, a_to, x.numel(), _lib.stream_ptr()), "dh_ddim_cfg_step")
+        return out
+
+    def prev_step(self, model_output, timestep, sample):
+        a_t, a_p = self.scheduler.step_alphas(timestep)
+        return self._step(sample, None, model_output, 1.0, a_t, a_p)
+
+    def next_step(self, model_output, timestep, sample):
+        a_from, a_to = self.scheduler.inversion_alphas(timestep)
+        return self._step(sample, None, model_output, 1.0, a_from, a_to)
+
+    def get_noise_pred_single(self, latents, t, context, depth=None, save=False):
+        sample = self.model._unet_input(latents, depth)
+        eps, _ = self.model.unet.forward(sample, float(t), context.contiguous(), save_for_backward=save, want_acts=False)
+        return eps
+
+    @torch.no_grad()
+    def latent2image(self, latents_nchw):
+        image = self.model.vae.decode(1 / VAE_SCALE * latents_nchw.detach())["sample"]
+        return (image + 1) / 2
+
+    @torch.no_grad()
+    def image2latent(self, image):
+        return self.model.vae.encode(image * 2 - 1)["latent_dist"].mean * VAE_SCALE
+
+    @torch.no_grad()
+    def ddim_loop(self, latent, context, depth):
+        _, cond = context.chunk(2)
+        all_latent = [latent]
+        x = latent.clone()
+        ts = self.scheduler.timesteps
+        for i in range(self.num_ddim_steps):
+            t = ts[len(ts) - i - 1]
+            eps = self.get_noise_pred_single(x, t, cond, depth)
+            x = self.next_step(eps, t, x)
+            all_latent.append(x)
+        return all_latent
+
+    @torch.no_grad()
+    def ddim_inversion(self, image, context, depth):
+        latent = self.image2latent(image)
+        image_rec = self.latent2image(latent)
+        lat_nhwc = latent.permute(0, 2, 3, 1).contiguous()
+        return image_rec, self.ddim_loop(lat_nhwc, context, depth)
+
+    @torch.no_grad()
+    def null_optimization(self, latents, context, depth, num_inner_steps, epsilon, max_timesteps=None):
+        L = _lib.lib()
+        uncond, cond = context.chunk(2)
+        uncond = uncond.clone().contiguous()
+        cond = cond.contiguous()
+        out = []
+        cur = latents[-1]
+        n = cur.numel()
+        loss_dev = torch.zeros(1, dtype=torch.float32, device=cur.device)
+        d_rec = torch.empty_like(cur)
+        S = self.eps_grad_scale
+        steps = self.num_ddim_steps if max_timesteps is None else max_timesteps
+        for i in range(steps):
+            m = torch.zeros_like(uncond)
+            v = torch.zeros_like(uncond)
+            lr = 1e-2 * (1.0 - i / 100.0)
+            target = latents[len(latents) - i - 2]
+            t = self.scheduler.timesteps[i]
+            a_t, a_p = self.scheduler.step_alphas(t)
+            # d rec / d eps_u = (1 - w) * (sqrt(1-a_p) - sqrt(a_p) sqrt(1-a_t) / sqrt(a_t))
+            k = (1.0 - self.guidance_scale) * ((1 - a_p) ** 0.5 - (a_p ** 0.5) * ((1 - a_t) ** 0.5) / (a_t ** 0.5))
+            eps_c = self.get_noise_pred_single(cur, t, cond, depth)
+            for j in range(num_inner_steps):
+                eps_u = self.get_noise_pred_single(cur, t, uncond, depth, save=True)
+                rec = self._step(cur, eps_u, eps_c, self.guidance_scale, a_t, a_p)
+                _lib.check(L.dh_mse_fwd_bwd(_lib.ptr(rec), _lib.ptr(target), n, _lib.ptr(loss_dev), _lib.ptr(d_rec),
+                                            _lib.stream_ptr()), "dh_mse_fwd_bwd")
+                d_eps = (d_rec * (k * S)).contiguous()
+                _, d_text = self.model.unet.backward(None, d_eps, want_sample_grad=False, want_text_grad=True)
+                g = (d_text / S).contiguous()
+                _lib.check(L.dh_adam_step(_lib.ptr(uncond), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), lr, 0.9, 0.999, 1e-8,
+                                          j + 1, uncond.numel(), _lib.stream_ptr()), "dh_adam_step")
+                if loss_dev.item() < epsilon + i * 2e-5:       # the reference's early stop (one sync per inner step)
+                    break
+            out.append(uncond[:1].clone())
+            eu, ec = self.model._cfg_eps(cur, depth, t, uncond, cond)
+            cur = self._step(cur, eu, ec, self.guidance_scale, a_t, a_p)
+        return torch.stack(out, dim=0)
+
+    def invert(self, target_img, depth, prompt, num_inner_steps=10, early_stop_epsilon=1e-5, verbose=False,
+               max_timesteps=None):
+        dev = self.model.device
+        depth64 = self.model.init_depth(depth.to(dev, torch.float32))
+        depth_nhwc = depth64.permute(0, 2, 3, 1).contiguous() if self.model.conf.use_depth else None
+        context = self.model.init_prompt(prompt)
+        if verbose:
+            print("DDIM inversion...")
+        recon_img, ddim_latents = self.ddim_inversion(target_img.to(dev, torch.float32), context, depth_nhwc)
+        if verbose:
+            print("Null-text optimization...")
+        uncond = self.null_optimization(ddim_latents, context, depth_nhwc, num_inner_steps, early_stop_epsilon,
+                                        max_timesteps)
+        self.last_ddim_latents = ddim_latents
+        return (target_img, recon_img), ddim_latents[-1].permute(0, 3, 1, 2), uncond

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Quick timing of the native U-Net at the full SD-2-depth size (run on the GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffusionhandles_amd.unet import HipUNet
+
+dt = torch.float16
+u = HipUNet(dtype=dt, max_batch=2)
+u.init_synthetic(0)
+print("weights GB", u.weight_bytes() / 1e9, "workspace GB", u.workspace_bytes() / 1e9)
+dev = u.device
+g = torch.Generator(device=dev).manual_seed(0)
+for B in (1, 2):
+    x = torch.randn(B, 64, 64, 5, generator=g, device=dev)
+    txt = torch.randn(B, 77, 1024, generator=g, device=dev)
+    da = [None, torch.randn((B,) + u.act_shapes[1], generator=g, device=dev).to(dt) * 1e-2,
+          torch.randn((B,) + u.act_shapes[2], generator=g, device=dev).to(dt) * 1e-2]
+    for _ in range(3):
+        u.forward(x, 500.0, txt, save_for_backward=True)
+        u.backward(da, None)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.time()
+    for _ in range(n):
+        u.forward(x, 500.0, txt, save_for_backward=True)
+    torch.cuda.synchronize()
+    tf = (time.time() - t0) / n
+    t0 = time.time()
+    for _ in range(n):
+        u.backward(da, None)
+    torch.cuda.synchronize()
+    tb = (time.time() - t0) / n
+    s = u.stats()
+    print(f"B={B}: fwd {tf*1e3:.2f} ms ({s['flops_fwd']/tf/1e12:.1f} TF/s)  bwd {tb*1e3:.2f} ms ({s['flops_bwd']/tb/1e12:.1f} TF/s)  ops {s['ops']}")
