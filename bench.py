@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: guided-denoise steps/sec at 512x512 (SD2-depth), whole job over N GPUs.
+
+One "step" = one iteration of the guided-inference loop in its guided phase
+(reference guided_stable_diffuser.py:377-479): 3 x {U-Net forward B=1 with activation capture,
+guidance energy + gradient, backward-to-latent, latent update} + the CFG U-Net forward (B=2)
++ the DDIM step.  Workload = BASELINE.json configs[1] (single 512x512 edit, SD2-depth fp16):
+synthetic scene, seeded random weights of the exact architecture, the per-image identity
+(original activations, null-text list, initial noise) resident in HBM before the timed region.
+N > 1: one process per GPU, each an independent edit, no collective on the data path
+(weak scaling); torch.distributed is used only for the timing barrier and the MAX reduction.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEP_TFLOP = 6.99          # algorithmic TFLOP of one guided-denoise step at 512^2
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra steps run with the HIP-event GEMM bracket")
+    return ap.parse_args()
+
+
+def cpu_baseline(corr, disp_e, prompt_seed=1):
+    """The oracle (torch fp32 CPU restatement, kind 'port') timed on this host's cores on a bounded
+    sample: ONE of the three identical optimisation iterations (U-Net fwd + energy + autograd
+    backward-to-latent) + ONE CFG forward (B=2) at the full SD-2-depth size; step = 3*it + cfg."""
+    from types import SimpleNamespace
+    from oracle import guidance_ref as G
+    from oracle import loop_ref as L
+    from oracle import unet_torch as U
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    t0 = time.time()
+    unet = U.init_synthetic_(U.UNetTorch(U.SD2_DEPTH), seed=0).eval()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(prompt_seed)
+    cond = torch.randn(1, 77, 1024, generator=g)
+    unc = torch.randn(1, 77, 1024, generator=g)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    depth64 = L.init_depth(disp_e.cpu(), (64, 64))
+    cells = G.cells_from_correspondences(corr.numpy(), 512, 0)
+    acts_orig = [torch.randn(c, h, h, generator=g) for c, h in ((1280, 32), (640, 64), (320, 64))]
+    build_s = time.time() - t0
+    fgw, bgw = G.guidance_weights(2, 0, 1.5, 1.25, 38)
+    t0 = time.time()
+    with torch.enable_grad():
+        xi = x.clone().requires_grad_(True)
+        out = unet(torch.cat([xi, depth64], dim=1), torch.tensor(940), encoder_hidden_states=cond, return_dict=False)
+        loss = 0.0
+        for k in range(3):
+            loss = loss + fgw[k] * G.foreground_energy(out[4 + k][0], acts_orig[k], cells, 1, (64, 64))
+            loss = loss + bgw[k] * G.background_energy(out[4 + k][0], acts_orig[k], cells, 1, (64, 64))
+        gr, = torch.autograd.grad(loss, [xi])
+    t_it = time.time() - t0
+    t0 = time.time()
+    with torch.no_grad():
+        L._eps_cfg(unet, x, depth64, torch.tensor(940), unc, cond)
+    t_cfg = time.time() - t0
+    step_s = 3 * t_it + t_cfg
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle torch-CPU fp32, full SD2-depth U-Net: 1 optimisation iteration (fwd+energy+bwd-to-latent) "
+                      f"{t_it:.2f}s + 1 CFG forward (B=2) {t_cfg:.2f}s measured; step = 3*iteration + CFG = {step_s:.2f}s "
+                      f"(model build {build_s:.1f}s not counted)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from diffusionhandles_amd import DiffusionHandles, _lib
+    from diffusionhandles_amd import conf as C
+    from diffusionhandles_amd.depth_transform import normalize_depth, transform_depth
+    from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
+
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    conf = C.load_default()
+    dh = DiffusionHandles(conf, dtype=dtype).to(dev)
+    gd = dh.diffuser
+    depth, bg_depth, mask = (t.to(dev) for t in make_scene(512))
+    prompt = "a sphere on a plane"
+    disparity = normalize_depth(1.0 / depth)
+    T = conf.guided_diffuser.num_timesteps
+    uncond = gd._encode([""])[None].expand(T, -1, -1, -1).contiguous()
+    torch.manual_seed(conf.guided_diffuser.seed)
+    noise = torch.randn(1, 4, 64, 64).to(dev)
+    # per-image identity, resident in HBM before the timed region
+    acts, _, _, init_noise = gd.initial_inference(noise, disparity, uncond, prompt)
+    ang, tr = TRANSFORMS[2 + rank % 4]
+    disp_e, corr = transform_depth(depth, bg_depth, mask, gd.get_depth_intrinsics(), rot_angle=ang,
+                                   rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor(tr))
+    st = gd.prepare_guidance(disp_e, prompt, acts, corr)
+    gd.scheduler.set_timesteps(T)
+    timesteps = gd.scheduler.timesteps
+    x0 = init_noise.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous()
+    gmax = conf.guided_diffuser.guidance_max_step
+
+    state = {"x": x0, "i": 0}
+
+    def one_step():
+        t_idx = state["i"] % gmax
+        if t_idx == 0:
+            state["x"] = x0
+        state["x"] = gd.guided_step(st, state["x"], t_idx, timesteps[t_idx], uncond[t_idx])
+        state["i"] += 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(state["x"]).all(), "latents diverged"
+
+    # roofline of the dominant kernel (k_gemm: MFMA implicit GEMM), HIP events on its stream
+    import ctypes
+    L = _lib.lib()
+    roof = None
+    if rank == 0:
+        with torch.no_grad():
+            _lib.check(L.dh_gemm_profile_begin())
+            for _ in range(max(1, args.profile_steps)):
+                one_step()
+            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.check(L.dh_gemm_profile_end(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "k_gemm (MFMA implicit GEMM: conv3x3 + linear, fwd + input-gradient)",
+                "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_step": int(n.value // max(1, args.profile_steps)),
+                "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
+                "flops_per_launch": round(fl.value / max(1, n.value) / 1e9, 3),
+                "step_tflop_algorithmic": STEP_TFLOP,
+                "step_frac_of_mfma_peak": round(world * args.steps / elapsed * STEP_TFLOP / MFMA_PEAK_TFLOPS / world, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(corr, disp_e)
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "guided-denoise steps/sec at 512x512 (SD2-depth)",
+            "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
+            "config": {"workload": "single 512x512 edit per GPU, SD2-depth (865.7M params, seeded random weights), guided "
+                                   "phase: 3 x (fwd + energy + bwd-to-latent) + CFG fwd (B=2) + DDIM step",
+                       "resolution": 512, "edits_per_gpu": 1, "correspondences": int(corr.shape[0]),
+                       "parallelism": "independent edits, one process per GPU, no collectives"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,9 +14,20 @@
 // output row m and 4 consecutive n per accumulator group: 8-byte stores, per-lane row
 // scalars.  f32 accumulate; optional split-K through f32 partial slabs + a reduce kernel
 // that applies the same epilogue.
+#include <vector>
+
 #include "unet_kernels.h"
 
 namespace dh {
+
+// optional HIP-event bracket around every k_gemm launch (bench.py roofline measurement)
+struct GemmProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  double flops = 0;
+};
+static GemmProf g_prof;
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef __bf16 v8b __attribute__((ext_vector_type(8)));
@@ -255,9 +266,22 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
   k.splits = splits;
   k.k_per_split = tiles_per_split * BK;
   dim3 grid(tm, tn, splits);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+      const size_t old = g_prof.ev.size();
+      g_prof.ev.resize(old + 4096);
+      for (size_t i = old; i < g_prof.ev.size(); ++i) (void)hipEventCreate(&g_prof.ev[i]);
+    }
+    e0 = g_prof.ev[g_prof.used++];
+    e1 = g_prof.ev[g_prof.used++];
+    g_prof.flops += 2.0 * (double)k.M * (double)k.N * (double)k.K;
+    (void)hipEventRecord(e0, st);
+  }
   if (BM == 64) hipLaunchKernelGGL((k_gemm<T, 64, 64>), grid, dim3(256), 0, st, k);
   else if (BN == 128) hipLaunchKernelGGL((k_gemm<T, 128, 128>), grid, dim3(256), 0, st, k);
   else hipLaunchKernelGGL((k_gemm<T, 128, 64>), grid, dim3(256), 0, st, k);
+  if (e1) (void)hipEventRecord(e1, st);
   if (splits > 1) {
     const size_t groups = (size_t)k.M * k.N / 4;
     hipLaunchKernelGGL((k_splitk_reduce<T>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, k);
@@ -279,3 +303,25 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace dh
+
+extern "C" int dh_gemm_profile_begin(void) {
+  dh::g_prof.on = true;
+  dh::g_prof.used = 0;
+  dh::g_prof.flops = 0;
+  return DH_OK;
+}
+extern "C" int dh_gemm_profile_end(double* ms_total, int64_t* launches, double* flops) {
+  using namespace dh;
+  g_prof.on = false;
+  double ms = 0;
+  if (g_prof.used >= 2) DH_CHECK_HIP(hipEventSynchronize(g_prof.ev[g_prof.used - 1]));
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    float t = 0;
+    DH_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+    ms += t;
+  }
+  if (ms_total) *ms_total = ms;
+  if (launches) *launches = (int64_t)(g_prof.used / 2);
+  if (flops) *flops = g_prof.flops;
+  return DH_OK;
+}

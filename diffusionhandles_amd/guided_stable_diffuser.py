@@ -238,59 +238,67 @@ class GuidedStableDiffuser(GuidedDiffuser):
         activations = [a.permute(0, 3, 1, 2) for a in store]      # [T,C,h,w] views of channels-last storage
         return activations, x.permute(0, 3, 1, 2), uncond_embeddings, init_latents
 
-    def guided_inference(self, latents, depth, uncond_embeddings, prompt, activations_orig, correspondences,
-                         fg_weight=None, bg_weight=None, save_denoising_steps=False, record=None):
+    def prepare_guidance(self, depth, prompt, activations_orig, correspondences, fg_weight=None, bg_weight=None):
+        """Everything of guided_inference that is constant over the denoising loop."""
+        from types import SimpleNamespace
         fg_weight = self.conf.fg_weight if fg_weight is None else fg_weight
         bg_weight = self.conf.bg_weight if bg_weight is None else bg_weight
+        st = SimpleNamespace()
+        st.pc = self.process_correspondences(correspondences, img_res=depth.shape[-1], bg_erosion=self.conf.bg_erosion)
+        st.depth_nhwc = _nhwc(self.init_depth(depth.to(self.device, torch.float32))) if self.conf.use_depth else None
+        st.cond = self._encode([prompt]).contiguous()
+        st.schedule = build_weight_schedule(fg_weight, bg_weight, self.conf.guidance_max_step,
+                                            self.conf.guidance_schedule_type)
+        # original activations as channels-last engine-dtype storage [T,h,w,C]
+        st.orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
+        st.size = (st.orig[2].shape[1], st.orig[2].shape[2])
+        st.n_pairs = len(st.pc["original_x"])
+        return st
+
+    def guided_step(self, st, x, t_idx, t, uncond, record=None):
+        """One guided-denoise step (guided_stable_diffuser.py:377-479): up to num_optsteps x
+        {U-Net forward, energy + gradient, backward-to-latent, latent update}, then the CFG
+        forward (B=2) and the DDIM step.  x: [1,H,W,4] f32 channels-last."""
+        L = _lib.lib()
+        iteration = 0
+        while iteration < self.conf.num_optsteps and t_idx < self.conf.guidance_max_step:
+            fgw, bgw = st.schedule(t_idx, iteration)
+            active = [k for k in range(3) if (fgw[k] != 0.0 and st.n_pairs > 0) or bgw[k] != 0.0]
+            if active:
+                _, acts = self.unet.forward(self._unet_input(x, st.depth_nhwc), float(t), st.cond, save_for_backward=True)
+                d_acts = [None, None, None]
+                for k in active:
+                    _, g = energy_and_grad(acts[k][0], st.orig[k][t_idx], st.pc, fgw[k], bgw[k], self.conf.fg_patch_size,
+                                           self.conf.bg_patch_size, st.size, self.conf.bg_loss_type,
+                                           grad_scale=self.grad_scale)
+                    d_acts[k] = g[None]
+                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
+                g_lat = d_sample[..., : x.shape[-1]].contiguous()
+                x_new = torch.empty_like(x)
+                _lib.check(L.dh_latent_update(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(g_lat), 0.1, self.grad_scale,
+                                              x.numel(), _lib.stream_ptr()), "dh_latent_update")
+                x = x_new
+            if record is not None:
+                record.setdefault("opt", []).append(x.permute(0, 3, 1, 2).clone())
+            iteration += 1
+        eu, ec = self._cfg_eps(x, st.depth_nhwc, t, uncond, st.cond)
+        return self.ddim_step(x, eu, ec, t)
+
+    def guided_inference(self, latents, depth, uncond_embeddings, prompt, activations_orig, correspondences,
+                         fg_weight=None, bg_weight=None, save_denoising_steps=False, record=None):
         with torch.no_grad():
             torch.manual_seed(self.conf.seed)
             self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
             timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
-            pc = self.process_correspondences(correspondences, img_res=depth.shape[-1], bg_erosion=self.conf.bg_erosion)
-            depth_nhwc = _nhwc(self.init_depth(depth.to(self.device, torch.float32))) if self.conf.use_depth else None
-            cond = self._encode([prompt]).contiguous()
-            schedule = build_weight_schedule(fg_weight, bg_weight, self.conf.guidance_max_step,
-                                             self.conf.guidance_schedule_type)
+            st = self.prepare_guidance(depth, prompt, activations_orig, correspondences, fg_weight, bg_weight)
             denoising_steps = {"opt": [], "post-opt": []} if save_denoising_steps else None
-            # original activations as channels-last engine-dtype storage [T,h,w,C]
-            orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
-            size = (orig[2].shape[1], orig[2].shape[2])
-            n_pairs = len(pc["original_x"])
             x = _nhwc(latents.to(self.device, torch.float32))
-            L = _lib.lib()
             for t_idx, t in enumerate(timesteps):
-                if save_denoising_steps:
-                    denoising_steps["opt"].append([])
-                iteration = 0
-                while iteration < self.conf.num_optsteps and t_idx < self.conf.guidance_max_step:
-                    fgw, bgw = schedule(t_idx, iteration)
-                    active = [k for k in range(3) if (fgw[k] != 0.0 and n_pairs > 0) or bgw[k] != 0.0]
-                    if active:
-                        _, acts = self.unet.forward(self._unet_input(x, depth_nhwc), float(t), cond,
-                                                    save_for_backward=True)
-                        d_acts = [None, None, None]
-                        for k in active:
-                            _, g = energy_and_grad(acts[k][0], orig[k][t_idx], pc, fgw[k], bgw[k],
-                                                   self.conf.fg_patch_size, self.conf.bg_patch_size, size,
-                                                   self.conf.bg_loss_type, grad_scale=self.grad_scale)
-                            d_acts[k] = g[None]
-                        d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
-                        g_lat = d_sample[..., : x.shape[-1]].contiguous()
-                        x_new = torch.empty_like(x)
-                        _lib.check(L.dh_latent_update(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(g_lat), 0.1,
-                                                      self.grad_scale, x.numel(), _lib.stream_ptr()), "dh_latent_update")
-                        x = x_new
-                    if record is not None:
-                        record.setdefault("opt", []).append(x.permute(0, 3, 1, 2).clone())
-                    iteration += 1
-                if save_denoising_steps:
-                    denoising_steps["opt"][-1].append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
-                eu, ec = self._cfg_eps(x, depth_nhwc, t, uncond_embeddings[t_idx], cond)
-                x = self.ddim_step(x, eu, ec, t)
+                x = self.guided_step(st, x, t_idx, t, uncond_embeddings[t_idx], record)
                 if record is not None:
                     record.setdefault("step", []).append(x.permute(0, 3, 1, 2).clone())
-                if save_denoising_steps:
-                    denoising_steps["opt"][-1].append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
+                if save_denoising_steps:      # the reference appends the post-step image to 'opt' (never 'post-opt')
+                    denoising_steps["opt"].append([self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu()])
             self.last_latents = x.permute(0, 3, 1, 2)
             image = self.decode_latent_image(self.last_latents)
         return (image, denoising_steps) if save_denoising_steps else image

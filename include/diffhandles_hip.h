@@ -160,6 +160,11 @@ int dh_unet_forward(dh_unet* u, const float* sample, float timestep, const float
  * NULL).  Outputs (either may be NULL): d_sample [B][H][W][Cin] f32, d_text [B][L][D] f32. */
 int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* d_sample, float* d_text,
                      void* stream);
+/* HIP-event bracket around every launch of the MFMA implicit-GEMM kernel (k_gemm) between begin
+ * and end: total milliseconds, number of launches and their algorithmic flops (2*M*N*K).
+ * Used by bench.py for the roofline figure; not on the product path. */
+int dh_gemm_profile_begin(void);
+int dh_gemm_profile_end(double* ms_total, int64_t* launches, double* flops);
 /* per-kernel-class accumulated launch counts / algorithmic flops of the last forward */
 int dh_unet_stats(const dh_unet* u, double* flops_fwd, double* flops_bwd, int64_t* launches);
 

@@ -1,0 +1,91 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/diffhandles_hip.h
+declares; the ctypes table mirrors the header; product code has no oracle import."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "diffhandles_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diffusionhandles_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.lib()
+    assert lib.dh_missing_symbols == []
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert lib.dh_version() >= 100
+    assert lib.dh_device_count() >= 0
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diffusionhandles_amd import depth_transform as DT
+    from diffusionhandles_amd.synthetic import make_scene
+    depth, bg, mask = make_scene(256)
+    with pytest.raises(RuntimeError):
+        DT.transform_depth(depth, bg, mask, torch.eye(3))
+    from diffusionhandles_amd import DiffusionHandles
+    with pytest.raises(RuntimeError):
+        DiffusionHandles().to("cpu")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "diffusionhandles_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in src or f == "depth_transform.py", f
+
+
+def test_api_surface_matches_reference_names():
+    import inspect
+    import diffusionhandles_amd as pkg
+    from diffusionhandles_amd.depth_transform import transform_depth
+    from diffusionhandles_amd.losses import compute_background_loss, compute_foreground_loss
+    dh = pkg.DiffusionHandles
+    for m in ("to", "invert_input_image", "generate_input_image", "set_foreground", "transform_foreground"):
+        assert hasattr(dh, m)
+    gd = pkg.GuidedStableDiffuser
+    for m in ("to", "get_image_shape", "get_feature_shape", "init_prompt", "init_depth", "get_depth_intrinsics",
+              "initial_inference", "guided_inference", "decode_latent_image", "encode_latent_image",
+              "process_correspondences", "get_timesteps", "prepare_extra_step_kwargs"):
+        assert hasattr(gd, m), m
+    sig = inspect.signature(transform_depth)
+    assert list(sig.parameters)[:4] == ["depth", "bg_depth", "fg_mask", "intrinsics"]
+    assert sig.parameters["depth_transform_mode"].default == "pc"
+    assert list(inspect.signature(compute_foreground_loss).parameters) == [
+        "activations", "activations_orig", "processed_correspondences", "patch_size", "activations_size"]
+    assert inspect.signature(compute_background_loss).parameters["loss_type"].default == "global_avg"
+    sig = inspect.signature(pkg.StableNullInverter.invert)
+    assert sig.parameters["num_inner_steps"].default == 10 and sig.parameters["early_stop_epsilon"].default == 1e-5
+    import diffhandles
+    assert diffhandles.DiffusionHandles is dh
+
+
+def test_ddim_scheduler_scalars_match_oracle():
+    from diffusionhandles_amd.scheduler import DDIMScheduler
+    from oracle import loop_ref as L
+    a, b = DDIMScheduler(), L.DDIM()
+    assert a.timesteps.tolist() == b.timesteps.tolist()
+    for t in (0, 20, 500, 980):
+        at, ap = a.step_alphas(t)
+        assert at == float(b.alpha(t)) and ap == float(b.alpha(t - 20))
+        af, an = a.inversion_alphas(t)
+        assert af == float(b.alpha(min(t - 20, 999))) and an == float(b.alphas_cumprod[t])
