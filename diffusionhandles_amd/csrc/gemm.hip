@@ -14,6 +14,8 @@
 // output row m and 4 consecutive n per accumulator group: 8-byte stores, per-lane row
 // scalars.  f32 accumulate; optional split-K through f32 partial slabs + a reduce kernel
 // that applies the same epilogue.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "unet_kernels.h"
@@ -94,8 +96,8 @@ template <class T, int BM, int BN>
 __global__ void __launch_bounds__(256) k_gemm(const GemmK p) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 tiles per wave along m and n
   constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte chunks per thread per K tile
-  __shared__ __attribute__((aligned(16))) unsigned short sA[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[BN * LDS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDS_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -182,30 +184,39 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (ntiles > 0) load_tile(0);
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) *reinterpret_cast<uint4*>(&sA[buf][(lrow + 32 * j) * LDS_LD + chunk * 8]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) *reinterpret_cast<uint4*>(&sB[buf][(lrow + 32 * j) * LDS_LD + chunk * 8]) = rb[j];
+  };
+  // registers hold tile kt+1 while tile kt is computed from LDS buffer kt&1; one barrier per tile
+  if (ntiles > 0) {
+    load_tile(0);
+    stage(0);
+    if (ntiles > 1) load_tile(1);
+  }
+  __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < RA; ++j) *reinterpret_cast<uint4*>(&sA[(lrow + 32 * j) * LDS_LD + chunk * 8]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) *reinterpret_cast<uint4*>(&sB[(lrow + 32 * j) * LDS_LD + chunk * 8]) = rb[j];
-    __syncthreads();
-    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) stage(cur ^ 1);
+    if (kt + 2 < ntiles) load_tile(kt + 2);
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       const int koff = kk * 16 + (lane >> 5) * 8;
       uint4 fw[TN], fx[TM];
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fw[j] = *reinterpret_cast<const uint4*>(&sB[(wn * (BN / 2) + j * 32 + (lane & 31)) * LDS_LD + koff]);
+        fw[j] = *reinterpret_cast<const uint4*>(&sB[cur][(wn * (BN / 2) + j * 32 + (lane & 31)) * LDS_LD + koff]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fx[i] = *reinterpret_cast<const uint4*>(&sA[(wm * (BM / 2) + i * 32 + (lane & 31)) * LDS_LD + koff]);
+        fx[i] = *reinterpret_cast<const uint4*>(&sA[cur][(wm * (BM / 2) + i * 32 + (lane & 31)) * LDS_LD + koff]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[j], fx[i], acc[i][j]);
     }
+    __syncthreads();
   }
 
   // epilogue: lane owns row m, accumulator group g holds n = 8g + 4*(lane>>5) + 0..3
@@ -218,6 +229,172 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmK p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= p.N) continue;
+        if (p.splits > 1) {
+          float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = o;
+        } else {
+          epilogue_store<T>(p, m, n, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: global_load_lds_dwordx4 fills a ring of ST stages directly (no staging
+// registers), so ST-1 K tiles are in flight per workgroup while tile t is multiplied.
+//   * stage image: A rows then W rows, 128 B per row, UNPADDED (the DMA destination is
+//     wave-uniform base + lane*16); bank conflicts are avoided by an XOR swizzle applied on the
+//     per-lane SOURCE address (16-byte chunk c of row r is stored at chunk c ^ (r & 7)) and
+//     undone on the fragment read.
+//   * the DMA is issued from inline asm (m0 = LDS destination), so hipcc does not see a pending
+//     LDS write and does not drain vmcnt(0) in front of every ds_read; ordering is by hand:
+//     counted s_waitcnt vmcnt(N) -> s_barrier -> ds_read of the landed stage.
+//   * rows outside the matrix / the image read from a 128-byte zero page instead.
+__device__ uint4 g_zero_page[8];
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <class T, int BM, int BN, int ST>
+__global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int NPA = BM / 32, NPB = BN / 32;     // 1-KiB pieces per wave per stage
+  constexpr int NP = NPA + NPB;
+  constexpr int STAGE = (BM + BN) * 128;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, ln = lane & 31, hi = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  int kend = kbeg + p.k_per_split;
+  if (kend > p.K) kend = p.K;
+  const int ntiles = (kend - kbeg) / BK;
+  const T* Ag = reinterpret_cast<const T*>(p.A);
+  const T* Wg = reinterpret_cast<const T*>(p.W);
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  const int prow = lane >> 3;                       // row of this lane inside a piece
+  const int lchunk = (lane & 7) ^ prow;             // logical chunk it fetches (swizzle on the source)
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+
+  bool a_ok[NPA];
+  long a_base[NPA];
+  int a_oy[NPA], a_ox[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int m = m0 + 8 * (wave + 4 * j) + prow;
+    a_ok[j] = m < p.M;
+    if (p.mode == A_DENSE) {
+      a_base[j] = (long)m * p.lda;
+      a_oy[j] = a_ox[j] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int b = m / hw, r = m - b * hw;
+      a_oy[j] = r / p.Wout;
+      a_ox[j] = r - a_oy[j] * p.Wout;
+      a_base[j] = (long)b * p.Hin * p.Win;
+    }
+  }
+  const T* b_ptr[NPB];
+  bool b_ok[NPB];
+#pragma unroll
+  for (int j = 0; j < NPB; ++j) {
+    const int n = n0 + 8 * (wave + 4 * j) + prow;
+    b_ok[j] = n < p.N;
+    b_ptr[j] = Wg + (long)n * p.K + lchunk * 8;
+  }
+  int tap = 0, c0 = 0;
+  if (p.mode != A_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
+
+  auto issue = [&](int kt, int stage) {
+    const int k0 = kbeg + kt * BK;
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 1024);
+    if (p.mode == A_DENSE) {
+#pragma unroll
+      for (int j = 0; j < NPA; ++j) {
+        const void* src = a_ok[j] ? (const void*)(Ag + a_base[j] + k0 + lchunk * 8) : (const void*)zero;
+        dma16(src, sbase + j * 4096);
+      }
+    } else {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int j = 0; j < NPA; ++j) {
+        bool ok = a_ok[j];
+        int sy, sx;
+        if (p.mode == A_CONV3) {
+          const int iy = a_oy[j] * p.stride + ky - 1, ix = a_ox[j] * p.stride + kx - 1;
+          ok = ok && iy >= 0 && ix >= 0 && iy < (p.Hin << p.up) && ix < (p.Win << p.up);
+          sy = iy >> p.up; sx = ix >> p.up;
+        } else {
+          const int ty = a_oy[j] + ky - 1, tx = a_ox[j] + kx - 1;
+          ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < p.Hin && (tx >> 1) < p.Win;
+          sy = ty >> 1; sx = tx >> 1;
+        }
+        const void* src = ok ? (const void*)(Ag + (a_base[j] + (long)sy * p.Win + sx) * p.lda + c0 + lchunk * 8)
+                             : (const void*)zero;
+        dma16(src, sbase + j * 4096);
+      }
+      c0 += BK;
+      if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const void* src = b_ok[j] ? (const void*)(b_ptr[j] + k0) : (const void*)zero;
+      dma16(src, sbase + BM * 128 + j * 4096);
+    }
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (s < ntiles) issue(s, s);
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    // tile kt has landed once at most (ST-2) later tiles' loads are still outstanding
+    if (ntiles - 1 - kt >= ST - 2) wait_vmcnt<NP * (ST - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + ST - 1 < ntiles) issue(kt + ST - 1, (kt + ST - 1) % ST);
+    const unsigned char* sa = smem + (kt % ST) * STAGE;
+    const unsigned char* sb = sa + BM * 128;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int pc = ((2 * kk + hi) ^ (ln & 7)) << 4;
+      uint4 fw[TN], fx[TM];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fw[j] = *reinterpret_cast<const uint4*>(sb + (wn * (BN / 2) + j * 32 + ln) * 128 + pc);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fx[i] = *reinterpret_cast<const uint4*>(sa + (wm * (BM / 2) + i * 32 + ln) * 128 + pc);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[j], fx[i], acc[i][j]);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 32 + ln;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
         if (n >= p.N) continue;
         if (p.splits > 1) {
           float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
@@ -246,15 +423,18 @@ __global__ void k_splitk_reduce(const GemmK p) {
 
 template <class T>
 static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
-  int BM, BN;
-  if (k.M <= 64) { BM = 64; BN = 64; }
-  else if (k.N % 128 == 0) { BM = 128; BN = 128; }
-  else { BM = 128; BN = 64; }
+  // tile / split-K policy (environment overrides are for tuning runs only)
+  static const int kSplitTiles = getenv("DH_SPLITK_TILES") ? atoi(getenv("DH_SPLITK_TILES")) : 200;
+  static const int kSplitMinK = getenv("DH_SPLITK_MINKT") ? atoi(getenv("DH_SPLITK_MINKT")) : 8;
+  static const int kSplitTarget = getenv("DH_SPLITK_TARGET") ? atoi(getenv("DH_SPLITK_TARGET")) : 512;
+  static const int kBigTiles = getenv("DH_BIG_TILES") ? atoi(getenv("DH_BIG_TILES")) : 0;
+  int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
+  if (k.M <= 64 || cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles) { BM = 64; BN = 64; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   const int ktiles = k.K / BK;
   int splits = 1;
-  if (k.partial && tiles < 200 && ktiles >= 8) {
-    splits = 512 / tiles;
+  if (k.partial && tiles < kSplitTiles && ktiles >= kSplitMinK) {
+    splits = kSplitTarget / tiles;
     if (splits > ktiles / 4) splits = ktiles / 4;
     if (splits > 32) splits = 32;
     const size_t fit = partial_elems / ((size_t)k.M * k.N);
@@ -278,9 +458,16 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
     g_prof.flops += 2.0 * (double)k.M * (double)k.N * (double)k.K;
     (void)hipEventRecord(e0, st);
   }
-  if (BM == 64) hipLaunchKernelGGL((k_gemm<T, 64, 64>), grid, dim3(256), 0, st, k);
-  else if (BN == 128) hipLaunchKernelGGL((k_gemm<T, 128, 128>), grid, dim3(256), 0, st, k);
-  else hipLaunchKernelGGL((k_gemm<T, 128, 64>), grid, dim3(256), 0, st, k);
+  static const int kDma = getenv("DH_GEMM_DMA") ? atoi(getenv("DH_GEMM_DMA")) : 1;
+  if (kDma) {
+    if (BM == 64) hipLaunchKernelGGL((k_gemm_dma<T, 64, 64, 4>), grid, dim3(256), 0, st, k);
+    else if (BN == 128) hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((k_gemm_dma<T, 128, 64, 5>), grid, dim3(256), 0, st, k);
+  } else {
+    if (BM == 64) hipLaunchKernelGGL((k_gemm<T, 64, 64>), grid, dim3(256), 0, st, k);
+    else if (BN == 128) hipLaunchKernelGGL((k_gemm<T, 128, 128>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((k_gemm<T, 128, 64>), grid, dim3(256), 0, st, k);
+  }
   if (e1) (void)hipEventRecord(e1, st);
   if (splits > 1) {
     const size_t groups = (size_t)k.M * k.N / 4;

@@ -102,50 +102,76 @@ __device__ __forceinline__ float silu_grad(float z) {
   return s * (1.f + z * (1.f - s));
 }
 
-// one workgroup per (batch, group): mean and rstd, two-pass (mean first, then centred sumsq)
+// GroupNorm statistics in two deterministic stages:
+//   k_gn_partial  grid (B*G, S): block s reduces its slice of rows to (n, mean, M2)   [two-pass, f32]
+//   the apply kernels combine the S slices of their batch item in LDS (Chan's parallel variance
+//   formula, fixed order) before normalising; block x == 0 also publishes (mean, rstd) for backward.
+constexpr int GN_MAXS = 32;
+__host__ __device__ inline int gn_slices(int HW) { int s = HW / 128; return s < 1 ? 1 : (s > GN_MAXS ? GN_MAXS : s); }
+
 template <class T>
-__global__ void __launch_bounds__(512) k_gn_stats(const T* x, float* stats, int HW, int C, int G, float eps) {
-  __shared__ float sm[8];
-  const int b = blockIdx.x / G, g = blockIdx.x - b * G, cpg = C / G;
-  const T* xb = x + (size_t)b * HW * C + g * cpg;
-  const int n = HW * cpg;
-  float s = 0.f;
+__global__ void __launch_bounds__(256) k_gn_partial(const T* x, float* part, int HW, int C, int G, int S) {
+  __shared__ float sm[4];
+  const int bg = blockIdx.x, s = blockIdx.y, b = bg / G, g = bg - b * G, cpg = C / G;
+  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
+  const T* xb = x + ((size_t)b * HW + r0) * C + g * cpg;
+  const int n = (r1 - r0) * cpg;
+  float a = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int p = i / cpg, c = i - p * cpg;
-    s += to_f32<T>(xb[(size_t)p * C + c]);
+    a += to_f32<T>(xb[(size_t)p * C + c]);
   }
-  const float mean = block_sum(s, sm) / (float)n;
+  const float mean = block_sum(a, sm) / (float)n;
   float v = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int p = i / cpg, c = i - p * cpg;
     const float d = to_f32<T>(xb[(size_t)p * C + c]) - mean;
     v += d * d;
   }
-  const float var = block_sum(v, sm) / (float)n;
+  const float m2 = block_sum(v, sm);
   if (threadIdx.x == 0) {
-    stats[2 * blockIdx.x] = mean;
-    stats[2 * blockIdx.x + 1] = rsqrtf(var + eps);
+    float* o = part + ((size_t)bg * S + s) * 3;
+    o[0] = (float)n; o[1] = mean; o[2] = m2;
   }
 }
 
-// thread = 8 consecutive channels of one pixel
+// combine the S slices of every group of batch item b into sm_stats[g] = (mean, rstd)
+__device__ __forceinline__ void gn_combine(const float* part, int b, int G, int S, float eps, float2* sm_stats,
+                                           float* stats_out) {
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    const float* p = part + ((size_t)(b * G + g) * S) * 3;
+    float n = 0.f, mean = 0.f;
+    for (int s = 0; s < S; ++s) { n += p[3 * s]; mean += p[3 * s] * p[3 * s + 1]; }
+    mean /= n;
+    float m2 = 0.f;
+    for (int s = 0; s < S; ++s) { const float d = p[3 * s + 1] - mean; m2 += p[3 * s + 2] + p[3 * s] * d * d; }
+    const float rstd = rsqrtf(m2 / n + eps);
+    sm_stats[g] = make_float2(mean, rstd);
+    if (stats_out) { stats_out[2 * (b * G + g)] = mean; stats_out[2 * (b * G + g) + 1] = rstd; }
+  }
+  __syncthreads();
+}
+
+// thread = 8 consecutive channels of one pixel; grid (chunks of HW*C/8, B)
 template <class T>
-__global__ void k_gn_apply(const T* x, const float* gamma, const float* beta, const float* stats, T* y, int B, int HW,
-                           int C, int G, int silu) {
+__global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma, const float* beta, const float* part,
+                                                  float* stats, T* y, int HW, int C, int G, int S, float eps, int silu) {
+  __shared__ float2 sm_stats[64];
+  const int b = blockIdx.y;
+  gn_combine(part, b, G, S, eps, sm_stats, blockIdx.x == 0 ? stats : nullptr);
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cchunks = C / 8;
-  if (idx >= (size_t)B * HW * cchunks) return;
-  const size_t row = idx / cchunks;
-  const int c0 = (int)(idx - row * cchunks) * 8;
-  const int b = (int)(row / HW), cpg = C / G;
+  if (idx >= (size_t)HW * cchunks) return;
+  const size_t row = (size_t)b * HW + idx / cchunks;
+  const int c0 = (int)(idx % cchunks) * 8, cpg = C / G;
   uint4 raw = *reinterpret_cast<const uint4*>(x + row * C + c0);
   const T* xv = reinterpret_cast<const T*>(&raw);
   T o[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i, g = c / cpg;
-    const float mean = stats[2 * (b * G + g)], rstd = stats[2 * (b * G + g) + 1];
-    float z = (to_f32<T>(xv[i]) - mean) * rstd * gamma[c] + beta[c];
+    const int c = c0 + i;
+    const float2 st = sm_stats[c / cpg];
+    float z = (to_f32<T>(xv[i]) - st.x) * st.y * gamma[c] + beta[c];
     if (silu) z = silu_f(z);
     o[i] = from_f32<T>(z);
   }
@@ -154,25 +180,28 @@ __global__ void k_gn_apply(const T* x, const float* gamma, const float* beta, co
 
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st) {
-  const unsigned nb = (unsigned)(((size_t)B * HW * (C / 8) + 255) / 256);
+  const int S = gn_slices(HW);
+  dim3 g1(B * G, S), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_stats<f16>), dim3(B * G), dim3(512), 0, st, (const f16*)x, stats, HW, C, G, eps);
-    hipLaunchKernelGGL((k_gn_apply<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, gamma, beta, stats, (f16*)y, B, HW, C, G, silu);
+    hipLaunchKernelGGL((k_gn_partial<f16>), g1, dim3(256), 0, st, (const f16*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL((k_gn_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu);
   } else {
-    hipLaunchKernelGGL((k_gn_stats<bf16>), dim3(B * G), dim3(512), 0, st, (const bf16*)x, stats, HW, C, G, eps);
-    hipLaunchKernelGGL((k_gn_apply<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, gamma, beta, stats, (bf16*)y, B, HW, C, G, silu);
+    hipLaunchKernelGGL((k_gn_partial<bf16>), g1, dim3(256), 0, st, (const bf16*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL((k_gn_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu);
   }
 }
 
-// backward sums per (batch, group): s[0] = mean(dxhat), s[1] = mean(dxhat * xhat)
+// backward partial sums per (batch, group, slice): (sum dxhat, sum dxhat * xhat)
 template <class T>
-__global__ void __launch_bounds__(512) k_gn_bwd_stats(const T* x, const T* dy, const float* gamma, const float* beta,
-                                                      const float* stats, float* sums, int HW, int C, int G, int silu) {
-  __shared__ float sm[8];
-  const int b = blockIdx.x / G, g = blockIdx.x - b * G, cpg = C / G;
-  const size_t base = (size_t)b * HW * C + g * cpg;
-  const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
-  const int n = HW * cpg;
+__global__ void __launch_bounds__(256) k_gn_bwd_partial(const T* x, const T* dy, const float* gamma, const float* beta,
+                                                        const float* stats, float* part, int HW, int C, int G, int S,
+                                                        int silu) {
+  __shared__ float sm[4];
+  const int bg = blockIdx.x, s = blockIdx.y, b = bg / G, g = bg - b * G, cpg = C / G;
+  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
+  const size_t base = ((size_t)b * HW + r0) * C + g * cpg;
+  const float mean = stats[2 * bg], rstd = stats[2 * bg + 1];
+  const int n = (r1 - r0) * cpg;
   float s1 = 0.f, s2 = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int p = i / cpg, c = i - p * cpg;
@@ -188,20 +217,30 @@ __global__ void __launch_bounds__(512) k_gn_bwd_stats(const T* x, const T* dy, c
   s1 = block_sum(s1, sm);
   s2 = block_sum(s2, sm);
   if (threadIdx.x == 0) {
-    sums[2 * blockIdx.x] = s1 / (float)n;
-    sums[2 * blockIdx.x + 1] = s2 / (float)n;
+    part[((size_t)bg * S + s) * 2] = s1;
+    part[((size_t)bg * S + s) * 2 + 1] = s2;
   }
 }
 
 template <class T>
-__global__ void k_gn_bwd_apply(const T* x, const T* dy, const float* gamma, const float* beta, const float* stats,
-                               const float* sums, T* dx, int B, int HW, int C, int G, int silu, int accumulate) {
+__global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, const float* gamma, const float* beta,
+                                                      const float* stats, const float* part, T* dx, int HW, int C, int G,
+                                                      int S, int silu, int accumulate) {
+  __shared__ float4 sm_st[64];     // mean, rstd, mean(dxhat), mean(dxhat*xhat)
+  const int b = blockIdx.y, cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    const float* p = part + ((size_t)(b * G + g) * S) * 2;
+    float a = 0.f, c = 0.f;
+    for (int s = 0; s < S; ++s) { a += p[2 * s]; c += p[2 * s + 1]; }
+    const float inv = 1.f / ((float)HW * (float)cpg);
+    sm_st[g] = make_float4(stats[2 * (b * G + g)], stats[2 * (b * G + g) + 1], a * inv, c * inv);
+  }
+  __syncthreads();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cchunks = C / 8;
-  if (idx >= (size_t)B * HW * cchunks) return;
-  const size_t row = idx / cchunks;
-  const int c0 = (int)(idx - row * cchunks) * 8;
-  const int b = (int)(row / HW), cpg = C / G;
+  if (idx >= (size_t)HW * cchunks) return;
+  const size_t row = (size_t)b * HW + idx / cchunks;
+  const int c0 = (int)(idx % cchunks) * 8;
   uint4 rx = *reinterpret_cast<const uint4*>(x + row * C + c0);
   uint4 rd = *reinterpret_cast<const uint4*>(dy + row * C + c0);
   uint4 ro = make_uint4(0, 0, 0, 0);
@@ -212,13 +251,13 @@ __global__ void k_gn_bwd_apply(const T* x, const T* dy, const float* gamma, cons
   T o[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i, g = c / cpg, sg = b * G + g;
-    const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
-    const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
+    const int c = c0 + i;
+    const float4 st = sm_st[c / cpg];
+    const float xh = (to_f32<T>(xv[i]) - st.x) * st.y;
     float d = to_f32<T>(dv[i]);
     if (silu) d *= silu_grad(xh * gamma[c] + beta[c]);
     d *= gamma[c];
-    float r = rstd * (d - sums[2 * sg] - xh * sums[2 * sg + 1]);
+    float r = st.y * (d - st.z - xh * st.w);
     if (accumulate) r += to_f32<T>(ov[i]);
     o[i] = from_f32<T>(r);
   }
@@ -228,13 +267,14 @@ __global__ void k_gn_bwd_apply(const T* x, const T* dy, const float* gamma, cons
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st) {
-  const unsigned nb = (unsigned)(((size_t)B * HW * (C / 8) + 255) / 256);
+  const int S = gn_slices(HW);
+  dim3 g1(B * G, S), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_bwd_stats<f16>), dim3(B * G), dim3(512), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, silu);
-    hipLaunchKernelGGL((k_gn_bwd_apply<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, B, HW, C, G, silu, accumulate);
+    hipLaunchKernelGGL((k_gn_bwd_partial<f16>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_bwd_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate);
   } else {
-    hipLaunchKernelGGL((k_gn_bwd_stats<bf16>), dim3(B * G), dim3(512), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, silu);
-    hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, B, HW, C, G, silu, accumulate);
+    hipLaunchKernelGGL((k_gn_bwd_partial<bf16>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate);
   }
 }
 

@@ -119,7 +119,7 @@ def test_groupnorm(dtype, B, HW, C, silu):
         ref = F.silu(ref)
     gref, = torch.autograd.grad(ref, xr, dy.float())
     y = torch.empty_like(x); dx = acc0.clone()
-    stats = torch.empty(B * 32 * 2, dtype=torch.float32, device=dev()); scr = torch.empty(B * 32 * 2 + 64, dtype=torch.float32, device=dev())
+    stats = torch.empty(B * 32 * 2, dtype=torch.float32, device=dev()); scr = torch.empty(B * 32 * 32 * 3 + 64, dtype=torch.float32, device=dev())
     L().check(L().lib().dh_dbg_groupnorm(DT[dtype], P(x), P(gamma), P(beta), P(y), P(stats), P(dy), P(dx), P(scr), B, HW, C, 32,
                                          1e-5, silu, 1, L().stream_ptr()))
     tol = 4e-3 if dtype == torch.float16 else 2.5e-2
