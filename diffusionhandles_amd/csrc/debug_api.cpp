@@ -1,6 +1,8 @@
 // Test hooks: C-ABI wrappers around the individual kernel launchers so that the GPU parity
 // tests can check each kernel against a torch fp32 reference in isolation.  Not used by the
 // product path.
+#include <stdlib.h>
+
 #include "unet_kernels.h"
 using namespace dh;
 
@@ -8,9 +10,20 @@ extern "C" int dh_dbg_gemm(int dtype, const void* A, long lda, const void* W, in
                            int Win, int Cin, int Hout, int Wout, int stride, int up, const float* bias,
                            const float* rowvec, int rowvec_ld, int rows_per_batch, const void* R, long ldr, void* C,
                            long ldc, int act_silu, float* partial, size_t partial_elems, void* stream) {
-  DH_REQUIRE(A && W && C && K % 64 == 0 && N % 4 == 0, "bad arguments");
+  DH_REQUIRE(A && W && C && K % 64 == 0 && N % 64 == 0, "bad arguments (N, K must be multiples of 64)");
+  // the hook takes plain [N][K] weights and tiles them into a scratch buffer first
+  static void* tiled = nullptr;
+  static size_t tiled_cap = 0;
+  const size_t need = (size_t)N * K * 2;
+  if (need > tiled_cap) {
+    if (tiled) (void)hipFree(tiled);
+    DH_CHECK_HIP(hipMalloc(&tiled, need));
+    tiled_cap = need;
+  }
+  static const bool pretiled = getenv("DH_DBG_PRETILED") != nullptr;   // timing runs: skip the tiling pass
+  if (!pretiled) launch_tile_weights(dtype, W, tiled, N, K, (hipStream_t)stream);
   GemmArgs g;
-  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.mode = mode; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
+  g.A = A; g.lda = lda; g.W = tiled; g.M = M; g.N = N; g.K = K; g.mode = mode; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
   g.Hout = Hout; g.Wout = Wout; g.stride = stride; g.up = up; g.bias = bias; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld;
   g.rows_per_batch = rows_per_batch; g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc; g.act_silu = act_silu;
   g.partial = partial; g.partial_elems = partial_elems;

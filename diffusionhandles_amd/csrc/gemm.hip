@@ -62,7 +62,6 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
 };
 
 constexpr int BK = 64;
-constexpr int LDS_LD = 72;   // halves per LDS row (64 + 8 pad): 144 B, rows 9 sixteen-byte slots apart
 
 template <class T>
 __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, float v0, float v1, float v2, float v3) {
@@ -92,154 +91,6 @@ __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, flo
   *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = *reinterpret_cast<uint2*>(o);
 }
 
-template <class T, int BM, int BN>
-__global__ void __launch_bounds__(256) k_gemm(const GemmK p) {
-  constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 tiles per wave along m and n
-  constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte chunks per thread per K tile
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDS_LD];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * p.k_per_split;
-  int kend = kbeg + p.k_per_split;
-  if (kend > p.K) kend = p.K;
-  const int ntiles = (kend - kbeg) / BK;
-
-  const int lrow = tid >> 3, chunk = tid & 7;
-  const T* Ag = reinterpret_cast<const T*>(p.A);
-  const T* Wg = reinterpret_cast<const T*>(p.W);
-
-  // per-thread A row descriptors
-  bool a_ok[RA];
-  long a_base[RA];      // dense: element offset of the row; conv: pixel index of batch start
-  int a_oy[RA], a_ox[RA];
-#pragma unroll
-  for (int j = 0; j < RA; ++j) {
-    const int m = m0 + lrow + 32 * j;
-    a_ok[j] = m < p.M;
-    if (p.mode == A_DENSE) {
-      a_base[j] = (long)m * p.lda;
-      a_oy[j] = a_ox[j] = 0;
-    } else {
-      const int hw = p.Hout * p.Wout;
-      const int b = m / hw, r = m - b * hw;
-      a_oy[j] = r / p.Wout;
-      a_ox[j] = r - a_oy[j] * p.Wout;
-      a_base[j] = (long)b * p.Hin * p.Win;
-    }
-  }
-  bool b_ok[RB];
-  long b_base[RB];
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int n = n0 + lrow + 32 * j;
-    b_ok[j] = n < p.N;
-    b_base[j] = (long)n * p.K;
-  }
-
-  // running (tap, channel) position of the K tile for the conv gathers
-  int tap = 0, c0 = 0;
-  if (p.mode != A_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
-
-  uint4 ra[RA], rb[RB];
-  auto load_tile = [&](int kt) {
-    const int k0 = kbeg + kt * BK;
-    if (p.mode == A_DENSE) {
-#pragma unroll
-      for (int j = 0; j < RA; ++j)
-        ra[j] = a_ok[j] ? *reinterpret_cast<const uint4*>(Ag + a_base[j] + k0 + chunk * 8) : make_uint4(0, 0, 0, 0);
-    } else {
-      const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-      for (int j = 0; j < RA; ++j) {
-        bool ok = a_ok[j];
-        int sy, sx;
-        if (p.mode == A_CONV3) {
-          const int iy = a_oy[j] * p.stride + ky - 1, ix = a_ox[j] * p.stride + kx - 1;
-          ok = ok && iy >= 0 && ix >= 0 && iy < (p.Hin << p.up) && ix < (p.Win << p.up);
-          sy = iy >> p.up; sx = ix >> p.up;
-        } else {
-          const int ty = a_oy[j] + ky - 1, tx = a_ox[j] + kx - 1;
-          ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < p.Hin && (tx >> 1) < p.Win;
-          sy = ty >> 1; sx = tx >> 1;
-        }
-        ra[j] = ok ? *reinterpret_cast<const uint4*>(Ag + (a_base[j] + (long)sy * p.Win + sx) * p.lda + c0 + chunk * 8)
-                   : make_uint4(0, 0, 0, 0);
-      }
-      c0 += BK;
-      if (c0 >= p.Cin) { c0 = 0; ++tap; }
-    }
-#pragma unroll
-    for (int j = 0; j < RB; ++j)
-      rb[j] = b_ok[j] ? *reinterpret_cast<const uint4*>(Wg + b_base[j] + k0 + chunk * 8) : make_uint4(0, 0, 0, 0);
-  };
-
-  v16f acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) *reinterpret_cast<uint4*>(&sA[buf][(lrow + 32 * j) * LDS_LD + chunk * 8]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) *reinterpret_cast<uint4*>(&sB[buf][(lrow + 32 * j) * LDS_LD + chunk * 8]) = rb[j];
-  };
-  // registers hold tile kt+1 while tile kt is computed from LDS buffer kt&1; one barrier per tile
-  if (ntiles > 0) {
-    load_tile(0);
-    stage(0);
-    if (ntiles > 1) load_tile(1);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < ntiles) stage(cur ^ 1);
-    if (kt + 2 < ntiles) load_tile(kt + 2);
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const int koff = kk * 16 + (lane >> 5) * 8;
-      uint4 fw[TN], fx[TM];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fw[j] = *reinterpret_cast<const uint4*>(&sB[cur][(wn * (BN / 2) + j * 32 + (lane & 31)) * LDS_LD + koff]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fx[i] = *reinterpret_cast<const uint4*>(&sA[cur][(wm * (BM / 2) + i * 32 + (lane & 31)) * LDS_LD + koff]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[j], fx[i], acc[i][j]);
-    }
-    __syncthreads();
-  }
-
-  // epilogue: lane owns row m, accumulator group g holds n = 8g + 4*(lane>>5) + 0..3
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
-        if (n >= p.N) continue;
-        if (p.splits > 1) {
-          float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-          *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = o;
-        } else {
-          epilogue_store<T>(p, m, n, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-      }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA variant: global_load_lds_dwordx4 fills a ring of ST stages directly (no staging
 // registers), so ST-1 K tiles are in flight per workgroup while tile t is multiplied.
@@ -261,7 +112,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <class T, int BM, int BN, int ST>
+enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
+
+template <class T, int BM, int BN, int ST, int MODE>
 __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int NPA = BM / 32, NPB = BN / 32;     // 1-KiB pieces per wave per stage
@@ -277,50 +130,63 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   if (kend > p.K) kend = p.K;
   const int ntiles = (kend - kbeg) / BK;
   const T* Ag = reinterpret_cast<const T*>(p.A);
-  const T* Wg = reinterpret_cast<const T*>(p.W);
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   const int prow = lane >> 3;                       // row of this lane inside a piece
   const int lchunk = (lane & 7) ^ prow;             // logical chunk it fetches (swizzle on the source)
-  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 7) * 8;
 
+  // A rows of this lane: one per piece
   bool a_ok[NPA];
-  long a_base[NPA];
+  long a_off[NPA];      // dense: row offset; conv: offset of the (centre / first) source pixel or batch base
   int a_oy[NPA], a_ox[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
     const int m = m0 + 8 * (wave + 4 * j) + prow;
     a_ok[j] = m < p.M;
-    if (p.mode == A_DENSE) {
-      a_base[j] = (long)m * p.lda;
+    if (MODE == GM_DENSE) {
+      a_off[j] = (long)m * p.lda + lchunk * 8;
       a_oy[j] = a_ox[j] = 0;
     } else {
       const int hw = p.Hout * p.Wout;
       const int b = m / hw, r = m - b * hw;
       a_oy[j] = r / p.Wout;
       a_ox[j] = r - a_oy[j] * p.Wout;
-      a_base[j] = (long)b * p.Hin * p.Win;
+      if (MODE == GM_CONV_S1) a_off[j] = (((long)b * p.Hin + a_oy[j]) * p.Win + a_ox[j]) * p.lda + lchunk * 8;
+      else a_off[j] = (long)b * p.Hin * p.Win;
     }
   }
+  // W pieces: contiguous 1 KiB blocks of the tiled layout (rows 8*(wave+4j).. of the BN-row tile)
+  const T* Wg = reinterpret_cast<const T*>(p.W);
+  const int KT = p.K >> 6;
   const T* b_ptr[NPB];
-  bool b_ok[NPB];
 #pragma unroll
   for (int j = 0; j < NPB; ++j) {
-    const int n = n0 + 8 * (wave + 4 * j) + prow;
-    b_ok[j] = n < p.N;
-    b_ptr[j] = Wg + (long)n * p.K + lchunk * 8;
+    const int row = 8 * (wave + 4 * j);                    // first row of the piece inside the BN tile
+    b_ptr[j] = Wg + ((size_t)((n0 + row) >> 6) * KT) * 4096 + (size_t)(row & 63) * 64 + lane * 8;
   }
   int tap = 0, c0 = 0;
-  if (p.mode != A_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
+  if (MODE != GM_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
 
   auto issue = [&](int kt, int stage) {
     const int k0 = kbeg + kt * BK;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 1024);
-    if (p.mode == A_DENSE) {
+    if (MODE == GM_DENSE) {
 #pragma unroll
       for (int j = 0; j < NPA; ++j) {
-        const void* src = a_ok[j] ? (const void*)(Ag + a_base[j] + k0 + lchunk * 8) : (const void*)zero;
-        dma16(src, sbase + j * 4096);
+        const T* ptr = Ag + a_off[j] + k0;
+        dma16(a_ok[j] ? ptr : zero, sbase + j * 4096);
       }
+    } else if (MODE == GM_CONV_S1) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const long toff = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda + c0;
+#pragma unroll
+      for (int j = 0; j < NPA; ++j) {
+        const bool ok = a_ok[j] && (unsigned)(a_oy[j] + ky - 1) < (unsigned)p.Hin && (unsigned)(a_ox[j] + kx - 1) < (unsigned)p.Win;
+        const T* ptr = Ag + a_off[j] + toff;
+        dma16(ok ? ptr : zero, sbase + j * 4096);
+      }
+      c0 += BK;
+      if (c0 >= p.Cin) { c0 = 0; ++tap; }
     } else {
       const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
@@ -336,18 +202,17 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
           ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < p.Hin && (tx >> 1) < p.Win;
           sy = ty >> 1; sx = tx >> 1;
         }
-        const void* src = ok ? (const void*)(Ag + (a_base[j] + (long)sy * p.Win + sx) * p.lda + c0 + lchunk * 8)
-                             : (const void*)zero;
-        dma16(src, sbase + j * 4096);
+        sy = sy < 0 ? 0 : (sy >= p.Hin ? p.Hin - 1 : sy);
+        sx = sx < 0 ? 0 : (sx >= p.Win ? p.Win - 1 : sx);
+        const T* ptr = Ag + (a_off[j] + (long)sy * p.Win + sx) * p.lda + c0 + lchunk * 8;
+        dma16(ok ? ptr : zero, sbase + j * 4096);
       }
       c0 += BK;
       if (c0 >= p.Cin) { c0 = 0; ++tap; }
     }
+    const size_t wk = (size_t)(k0 >> 6) * 4096;
 #pragma unroll
-    for (int j = 0; j < NPB; ++j) {
-      const void* src = b_ok[j] ? (const void*)(b_ptr[j] + k0) : (const void*)zero;
-      dma16(src, sbase + BM * 128 + j * 4096);
-    }
+    for (int j = 0; j < NPB; ++j) dma16(b_ptr[j] + wk, sbase + BM * 128 + j * 4096);
   };
 
   v16f acc[TM][TN];
@@ -406,6 +271,19 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   }
 }
 
+// plain [N][K] (K contiguous) -> tiled layout, for the test hooks (the engine tiles at load time)
+template <class T>
+__global__ void k_tile_weights(const T* src, T* dst, int N, int K) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * K) return;
+  const int n = (int)(idx / K), k = (int)(idx - (size_t)n * K);
+  dst[wt_index(n, k, K)] = src[idx];
+}
+void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)N * K + 255) / 256);
+  hipLaunchKernelGGL((k_tile_weights<unsigned short>), dim3(nb), dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, N, K);
+}
+
 template <class T>
 __global__ void k_splitk_reduce(const GemmK p) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // index of a 4-wide group
@@ -458,16 +336,19 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
     g_prof.flops += 2.0 * (double)k.M * (double)k.N * (double)k.K;
     (void)hipEventRecord(e0, st);
   }
-  static const int kDma = getenv("DH_GEMM_DMA") ? atoi(getenv("DH_GEMM_DMA")) : 1;
-  if (kDma) {
-    if (BM == 64) hipLaunchKernelGGL((k_gemm_dma<T, 64, 64, 4>), grid, dim3(256), 0, st, k);
-    else if (BN == 128) hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((k_gemm_dma<T, 128, 64, 5>), grid, dim3(256), 0, st, k);
-  } else {
-    if (BM == 64) hipLaunchKernelGGL((k_gemm<T, 64, 64>), grid, dim3(256), 0, st, k);
-    else if (BN == 128) hipLaunchKernelGGL((k_gemm<T, 128, 128>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((k_gemm<T, 128, 64>), grid, dim3(256), 0, st, k);
-  }
+  int gm = GM_GENERIC;
+  if (k.mode == A_DENSE) gm = GM_DENSE;
+  else if (k.mode == A_CONV3 && k.stride == 1 && k.up == 0) gm = GM_CONV_S1;
+#define DH_LAUNCH_GEMM(BM_, BN_, ST_)                                                                         \
+  do {                                                                                                        \
+    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_DENSE>), grid, dim3(256), 0, st, k);        \
+    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1>), grid, dim3(256), 0, st, k); \
+    else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC>), grid, dim3(256), 0, st, k);                    \
+  } while (0)
+  if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
+  else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
+  else DH_LAUNCH_GEMM(128, 64, 5);
+#undef DH_LAUNCH_GEMM
   if (e1) (void)hipEventRecord(e1, st);
   if (splits > 1) {
     const size_t groups = (size_t)k.M * k.N / 4;

@@ -394,17 +394,27 @@ int build(dh_unet& u) {
   return DH_OK;
 }
 
-template <class D>
-__global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, long fwd_ld, long row_off, D* bwd,
-                              long bwd_ld, long col_off, int Nb) {
+// torch layout [N][C][taps] f32 -> forward matrix rows [row_off, row_off+N) x K = taps*C (k = tap*C + c) and
+// the input-gradient matrix rows c x K' = bwd_K (k' = (taps-1-tap)*Nb + col_off + n).  TILED = the swizzled
+// 64x64-tile layout the GEMM streams (wt_index); otherwise plain row-major (the two tiny f32 convolutions).
+template <class D, bool TILED>
+__global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, long fwd_K, long row_off, D* bwd,
+                              long bwd_K, long col_off, int Nb) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * C * taps) return;
   const int tap = (int)(idx % taps);
   const int cc = (int)((idx / taps) % C);
   const int nn = (int)(idx / ((size_t)taps * C));
-  const float v = src[idx];
-  fwd[(size_t)(row_off + nn) * fwd_ld + (size_t)tap * C + cc] = from_f32<D>(v);
-  if (bwd) bwd[(size_t)cc * bwd_ld + (size_t)(taps - 1 - tap) * Nb + col_off + nn] = from_f32<D>(v);
+  const D v = from_f32<D>(src[idx]);
+  const int fr = (int)row_off + nn, fk = tap * C + cc;
+  const int bk = (taps - 1 - tap) * Nb + (int)col_off + nn;
+  if (TILED) {
+    fwd[wt_index(fr, fk, (int)fwd_K)] = v;
+    if (bwd) bwd[wt_index(cc, bk, (int)bwd_K)] = v;
+  } else {
+    fwd[(size_t)fr * fwd_K + fk] = v;
+    if (bwd) bwd[(size_t)cc * bwd_K + bk] = v;
+  }
 }
 
 }  // namespace
@@ -483,17 +493,17 @@ extern "C" int dh_unet_load_param(dh_unet* u, int i, const float* src, void* str
   if (w.f32) {
     float* f = u->pf + w.fwd_off;
     float* b = w.has_bwd ? u->pf + w.bwd_off : nullptr;
-    hipLaunchKernelGGL((k_load_weight<float>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off,
+    hipLaunchKernelGGL((k_load_weight<float, false>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off,
                        b, bwd_ld, (long)p.row_off, w.N);
   } else if (u->dtype == DH_DTYPE_F16) {
     f16* f = (f16*)(u->w16 + w.fwd_off);
     f16* b = w.has_bwd ? (f16*)(u->w16 + w.bwd_off) : nullptr;
-    hipLaunchKernelGGL((k_load_weight<f16>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
+    hipLaunchKernelGGL((k_load_weight<f16, true>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
                        bwd_ld, (long)p.row_off, w.N);
   } else {
     bf16* f = (bf16*)(u->w16 + w.fwd_off);
     bf16* b = w.has_bwd ? (bf16*)(u->w16 + w.bwd_off) : nullptr;
-    hipLaunchKernelGGL((k_load_weight<bf16>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
+    hipLaunchKernelGGL((k_load_weight<bf16, true>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
                        bwd_ld, (long)p.row_off, w.N);
   }
   DH_LAUNCH_CHECK();

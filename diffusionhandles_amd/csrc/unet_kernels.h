@@ -9,7 +9,7 @@ enum { A_DENSE = 0, A_CONV3 = 1, A_CONVT2 = 2 };
 
 struct GemmArgs {
   const void* A = nullptr; long lda = 0;   // dense: row stride; conv: pixel stride (elements)
-  const void* W = nullptr;                 // [N][K], K contiguous
+  const void* W = nullptr;                 // TILED weights: [N/64][K/64] swizzled 64x64 tiles (wt_index in gemm.hip)
   int M = 0, N = 0, K = 0;
   int mode = A_DENSE;
   int Hin = 0, Win = 0, Cin = 0;           // source tensor spatial size, channels per tap
@@ -24,6 +24,14 @@ struct GemmArgs {
 };
 // D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+// plain [N][K] -> tiled weight layout (test hooks); N, K multiples of 64
+void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st);
+// element offset of (n, k) in the tiled weight layout: [N/64][K/64] tiles of 64x64 halves (8 KiB,
+// contiguous), each stored as the swizzled LDS image (16-byte chunk c of row r at chunk c ^ (r & 7))
+__host__ __device__ inline size_t wt_index(int n, int k, int K) {
+  const int r = n & 63, c = (k & 63) >> 3;
+  return ((size_t)(n >> 6) * (K >> 6) + (k >> 6)) * 4096 + (size_t)r * 64 + (size_t)((c ^ (r & 7)) << 3) + (k & 7);
+}
 
 // direct small convolutions (conv_in: Cin=5 -> C; conv_out: C -> 4) and their input-gradients
 void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* w, const float* bias, void* y,
