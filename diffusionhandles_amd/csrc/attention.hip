@@ -52,19 +52,27 @@ __device__ __forceinline__ void load_row_frags(const T* base, long ld, long row,
     f[kk] = ok ? *reinterpret_cast<const uint4*>(base + row * ld + col0 + 16 * kk + 8 * hi) : make_uint4(0, 0, 0, 0);
 }
 
-// stage a 64 x 64 tile (rows row0.., cols col0..col0+63) row-major into `rm` and/or transposed into `tr`
+// a 64 x 64 tile (rows row0.., cols col0..col0+63) travels global -> 2 registers per thread (fetch, issued one
+// tile ahead of its use) -> LDS row-major `rm` and/or transposed `tr` (commit)
+struct TileRegs { uint4 v[2]; };
 template <class T>
-__device__ __forceinline__ void stage_tile(const T* base, long ld, long row0, long rows_total, int col0,
-                                           unsigned short* rm, unsigned short* tr) {
-  const int t = threadIdx.x, chunk = t & 7;
+__device__ __forceinline__ void fetch_tile(const T* base, long ld, long row0, long rows_total, int col0, TileRegs& t) {
+  const int tid = threadIdx.x, chunk = tid & 7;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int r = (t >> 3) + 32 * j;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < rows_total) v = *reinterpret_cast<const uint4*>(base + (row0 + r) * ld + col0 + chunk * 8);
-    if (rm) *reinterpret_cast<uint4*>(&rm[r * TLD + chunk * 8]) = v;
+    const int r = (tid >> 3) + 32 * j;
+    t.v[j] = (row0 + r < rows_total) ? *reinterpret_cast<const uint4*>(base + (row0 + r) * ld + col0 + chunk * 8)
+                                     : make_uint4(0, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void commit_tile(const TileRegs& t, unsigned short* rm, unsigned short* tr) {
+  const int tid = threadIdx.x, chunk = tid & 7;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (tid >> 3) + 32 * j;
+    if (rm) *reinterpret_cast<uint4*>(&rm[r * TLD + chunk * 8]) = t.v[j];
     if (tr) {
-      const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+      const unsigned short* e = reinterpret_cast<const unsigned short*>(&t.v[j]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) tr[(chunk * 8 + i) * TLD + r] = e[i];
     }
@@ -131,11 +139,18 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const T* q, long ldq, const T*
   float m_run = -INFINITY, l_run = 0.f;
   const T* kb = k + (long)b * Nk * ldk;
   const T* vb = v + (long)b * Nk * ldk;
+  TileRegs rk, rv;
+  fetch_tile<T>(kb, ldk, 0, Nk, h * HD, rk);
+  fetch_tile<T>(vb, ldk, 0, Nk, h * HD, rv);
   for (int k0 = 0; k0 < Nk; k0 += 64) {
     __syncthreads();
-    stage_tile<T>(kb, ldk, k0, Nk, h * HD, sK, nullptr);
-    stage_tile<T>(vb, ldk, k0, Nk, h * HD, nullptr, sVt);
+    commit_tile(rk, sK, nullptr);
+    commit_tile(rv, nullptr, sVt);
     __syncthreads();
+    if (k0 + 64 < Nk) {            // next tile's loads fly under this tile's MFMAs
+      fetch_tile<T>(kb, ldk, k0 + 64, Nk, h * HD, rk);
+      fetch_tile<T>(vb, ldk, k0 + 64, Nk, h * HD, rv);
+    }
     v16f s[2];
     float mx = -INFINITY;
 #pragma unroll
@@ -225,11 +240,18 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(const T* q, long ldq, const
   v16f dqacc[2] = {zero16(), zero16()};
   const T* kb = k + (long)b * Nk * ldk;
   const T* vb = v + (long)b * Nk * ldk;
+  TileRegs rk, rv;
+  fetch_tile<T>(kb, ldk, 0, Nk, h * HD, rk);
+  fetch_tile<T>(vb, ldk, 0, Nk, h * HD, rv);
   for (int k0 = 0; k0 < Nk; k0 += 64) {
     __syncthreads();
-    stage_tile<T>(kb, ldk, k0, Nk, h * HD, sK, sKt);
-    stage_tile<T>(vb, ldk, k0, Nk, h * HD, sV, nullptr);
+    commit_tile(rk, sK, sKt);
+    commit_tile(rv, sV, nullptr);
     __syncthreads();
+    if (k0 + 64 < Nk) {
+      fetch_tile<T>(kb, ldk, k0 + 64, Nk, h * HD, rk);
+      fetch_tile<T>(vb, ldk, k0 + 64, Nk, h * HD, rv);
+    }
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       v16f s = tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
@@ -272,10 +294,17 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, cons
   v16f dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
   const T* qb = q + (long)b * Nq * ldq;
   const T* dob = d_o + (long)b * Nq * lddo;
+  TileRegs rq, rdo;
+  fetch_tile<T>(qb, ldq, 0, Nq, h * HD, rq);
+  fetch_tile<T>(dob, lddo, 0, Nq, h * HD, rdo);
   for (int q0 = 0; q0 < Nq; q0 += 64) {
     __syncthreads();
-    stage_tile<T>(qb, ldq, q0, Nq, h * HD, sQ, sQt);
-    stage_tile<T>(dob, lddo, q0, Nq, h * HD, sdO, sdOt);
+    commit_tile(rq, sQ, sQt);
+    commit_tile(rdo, sdO, sdOt);
+    if (q0 + 64 < Nq) {
+      fetch_tile<T>(qb, ldq, q0 + 64, Nq, h * HD, rq);
+      fetch_tile<T>(dob, lddo, q0 + 64, Nq, h * HD, rdo);
+    }
     if (threadIdx.x < 64) {
       const long qr = q0 + threadIdx.x;
       sLse[threadIdx.x] = qr < Nq ? lse[((long)b * H + h) * Nq + qr] * LOG2E : INFINITY;

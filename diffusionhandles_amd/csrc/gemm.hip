@@ -304,7 +304,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
   // tile / split-K policy (environment overrides are for tuning runs only)
   static const int kSplitTiles = getenv("DH_SPLITK_TILES") ? atoi(getenv("DH_SPLITK_TILES")) : 200;
   static const int kSplitMinK = getenv("DH_SPLITK_MINKT") ? atoi(getenv("DH_SPLITK_MINKT")) : 8;
-  static const int kSplitTarget = getenv("DH_SPLITK_TARGET") ? atoi(getenv("DH_SPLITK_TARGET")) : 512;
+  static const int kSplitTarget = getenv("DH_SPLITK_TARGET") ? atoi(getenv("DH_SPLITK_TARGET")) : 256;
   static const int kBigTiles = getenv("DH_BIG_TILES") ? atoi(getenv("DH_BIG_TILES")) : 0;
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
   if (k.M <= 64 || cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles) { BM = 64; BN = 64; }
