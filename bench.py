@@ -118,7 +118,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    with torch.no_grad(), gd.on_stream():
         for _ in range(args.warmup):
             one_step()
         barrier()
@@ -138,7 +138,7 @@ def main():
     L = _lib.lib()
     roof = None
     if rank == 0:
-        with torch.no_grad():
+        with torch.no_grad(), gd.on_stream():
             _lib.check(L.dh_gemm_profile_begin())
             for _ in range(max(1, args.profile_steps)):
                 one_step()

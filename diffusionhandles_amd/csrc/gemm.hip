@@ -30,6 +30,7 @@ struct GemmProf {
   double flops = 0;
 };
 static GemmProf g_prof;
+bool gemm_profiling_on() { return g_prof.on; }
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef __bf16 v8b __attribute__((ext_vector_type(8)));

@@ -12,6 +12,8 @@
 // the 32 text K/V projections and the 22 time-embedding projections are hoisted into one
 // GEMM each, q/k/v of self-attention is one GEMM, weights are stored twice ([N][K] and the
 // transposed / tap-flipped [K][N]) so forward and input-gradient use the same NT kernel.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <map>
 #include <vector>
@@ -85,6 +87,11 @@ struct dh_unet {
   int t_text = -1, t_kv = -1, t_conv_in_out = -1, t_final = -1, act_ids[3] = {-1, -1, -1};
   long temb_f32_off = -1;
   int temb_total = 0, kv_total = 0;
+  // staging buffers (fixed addresses so a captured graph can be replayed) and graph cache
+  float *in_sample = nullptr, *in_text = nullptr, *io_eps = nullptr, *out_dsample = nullptr, *out_dtext = nullptr, *t_dev = nullptr;
+  std::map<unsigned, hipGraphExec_t> graphs;
+  std::map<unsigned, double> graph_flops;
+  bool use_graphs = true;
   // run state
   int saved_batch = 0;
   const float* saved_sample = nullptr;
@@ -451,6 +458,18 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
   if ((e = hipMalloc((void**)&u->partial, u->partial_elems * 4)) != hipSuccess) return fail(e, "hipMalloc split-K");
   if ((e = hipMalloc((void**)&u->scratch, u->scratch_elems * 2)) != hipSuccess) return fail(e, "hipMalloc scratch");
   if ((e = hipMalloc((void**)&u->small, u->small_elems * 4)) != hipSuccess) return fail(e, "hipMalloc small");
+  {
+    const dh_unet_config& c = u->cfg;
+    const size_t ns = (size_t)c.max_batch * c.sample_size * c.sample_size;
+    const size_t nt = (size_t)c.max_batch * c.text_len * c.cross_attention_dim;
+    if ((e = hipMalloc((void**)&u->in_sample, ns * c.in_channels * 4)) != hipSuccess) return fail(e, "hipMalloc staging");
+    if ((e = hipMalloc((void**)&u->out_dsample, ns * c.in_channels * 4)) != hipSuccess) return fail(e, "hipMalloc staging");
+    if ((e = hipMalloc((void**)&u->io_eps, ns * c.out_channels * 4)) != hipSuccess) return fail(e, "hipMalloc staging");
+    if ((e = hipMalloc((void**)&u->in_text, nt * 4)) != hipSuccess) return fail(e, "hipMalloc staging");
+    if ((e = hipMalloc((void**)&u->out_dtext, nt * 4)) != hipSuccess) return fail(e, "hipMalloc staging");
+    if ((e = hipMalloc((void**)&u->t_dev, 64)) != hipSuccess) return fail(e, "hipMalloc staging");
+    u->use_graphs = !(getenv("DH_GRAPH") && atoi(getenv("DH_GRAPH")) == 0);
+  }
   (void)hipMemset(u->w16, 0, u->w16_elems * 2);
   (void)hipMemset(u->pf, 0, u->pf_elems * 4);
   u->gready.assign(u->tens.size(), 0);
@@ -462,6 +481,9 @@ extern "C" void dh_unet_destroy(dh_unet* u) {
   if (!u) return;
   (void)hipFree(u->w16); (void)hipFree(u->pf); (void)hipFree(u->act); (void)hipFree(u->grad);
   (void)hipFree(u->f32a); (void)hipFree(u->partial); (void)hipFree(u->scratch); (void)hipFree(u->small);
+  (void)hipFree(u->in_sample); (void)hipFree(u->in_text); (void)hipFree(u->io_eps); (void)hipFree(u->out_dsample);
+  (void)hipFree(u->out_dtext); (void)hipFree(u->t_dev);
+  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
   delete u;
 }
 
@@ -533,34 +555,29 @@ static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
   g.partial = u->partial; g.partial_elems = u->partial_elems;
 }
 
-extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, const float* text, int batch,
-                               int save_for_backward, float* eps_out, void* const* act_out, void* stream) {
-  DH_REQUIRE(u && sample && text && eps_out, "null pointer");
-  DH_REQUIRE(batch >= 1 && batch <= u->cfg.max_batch, "batch exceeds max_batch");
-  hipStream_t st = (hipStream_t)stream;
-  const int B = batch, dt = u->dtype;
+static void forward_ops(dh_unet* u, int B, hipStream_t st) {
+  const int dt = u->dtype;
   const dh_unet_config& c = u->cfg;
   u->flops_fwd = 0;
-  u->launches = 0;
-  launch_f32_to_t(dt, text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
+  launch_f32_to_t(dt, u->in_text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
   for (const Op& o : u->ops) {
     switch (o.type) {
       case OP_TIMESTEP:
-        launch_timestep_embedding(dt, timestep, c.block_out_channels[0], B, u->aptr(o.out), st);
+        launch_timestep_embedding(dt, u->t_dev, c.block_out_channels[0], B, u->aptr(o.out), st);
         break;
       case OP_T2F:
         launch_t_to_f32(dt, u->aptr(o.in0), u->f32a + u->temb_f32_off, (size_t)B * u->temb_total, 0, st);
         break;
       case OP_CONV_IN: {
         const Wt& w = u->wts[o.wt];
-        launch_conv_small_fwd(dt, sample, 1, u->pf + w.fwd_off, u->pf + o.bias_off, u->aptr(o.out), 0, B, o.Hin, o.Hin,
+        launch_conv_small_fwd(dt, u->in_sample, 1, u->pf + w.fwd_off, u->pf + o.bias_off, u->aptr(o.out), 0, B, o.Hin, o.Hin,
                               o.Cin, w.N, st);
         u->flops_fwd += 2.0 * B * o.Hin * o.Hin * w.N * w.K;
         break;
       }
       case OP_CONV_OUT: {
         const Wt& w = u->wts[o.wt];
-        launch_conv_small_fwd(dt, u->aptr(o.in0), 0, u->pf + w.fwd_off, u->pf + o.bias_off, eps_out, 1, B, o.Hin, o.Hin,
+        launch_conv_small_fwd(dt, u->aptr(o.in0), 0, u->pf + w.fwd_off, u->pf + o.bias_off, u->io_eps, 1, B, o.Hin, o.Hin,
                               o.Cin, w.N, st);
         u->flops_fwd += 2.0 * B * o.Hin * o.Hin * w.N * w.K;
         break;
@@ -612,6 +629,45 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
       }
     }
   }
+}
+
+// run `body` through a cached hipGraph (captured on first use of `key`) or eagerly
+template <class F>
+static int run_graphed(dh_unet* u, unsigned key, hipStream_t st, double* flops_slot, F body) {
+  // the legacy default stream (0) cannot be captured: callers that want graph replay run on a created stream
+  if (!u->use_graphs || st == nullptr || gemm_profiling_on()) { body(); return DH_OK; }
+  auto it = u->graphs.find(key);
+  if (it == u->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    DH_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    body();
+    DH_CHECK_HIP(hipStreamEndCapture(st, &graph));
+    hipGraphExec_t exec = nullptr;
+    DH_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    u->graphs[key] = exec;
+    u->graph_flops[key] = *flops_slot;
+    it = u->graphs.find(key);
+  }
+  *flops_slot = u->graph_flops[key];
+  DH_CHECK_HIP(hipGraphLaunch(it->second, st));
+  return DH_OK;
+}
+
+extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, const float* text, int batch,
+                               int save_for_backward, float* eps_out, void* const* act_out, void* stream) {
+  DH_REQUIRE(u && sample && text && eps_out, "null pointer");
+  DH_REQUIRE(batch >= 1 && batch <= u->cfg.max_batch, "batch exceeds max_batch");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = batch;
+  const dh_unet_config& c = u->cfg;
+  const size_t ns = (size_t)B * c.sample_size * c.sample_size;
+  DH_CHECK_HIP(hipMemcpyAsync(u->in_sample, sample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
+  DH_CHECK_HIP(hipMemcpyAsync(u->in_text, text, (size_t)B * c.text_len * c.cross_attention_dim * 4, hipMemcpyDeviceToDevice, st));
+  launch_set_scalar(u->t_dev, timestep, st);
+  int rc = run_graphed(u, (unsigned)B, st, &u->flops_fwd, [&]() { forward_ops(u, B, st); });
+  if (rc != DH_OK) return rc;
+  DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
   if (act_out) {
     for (int i = 0; i < 3; ++i)
       if (act_out[i]) {
@@ -640,23 +696,17 @@ struct Bwd {
 };
 }  // namespace
 
-extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* d_sample, float* d_text,
-                                void* stream) {
-  DH_REQUIRE(u, "null engine");
-  DH_REQUIRE(u->saved_batch > 0, "no saved forward: call dh_unet_forward(save_for_backward=1) first");
-  hipStream_t st = (hipStream_t)stream;
-  const int B = u->saved_batch, dt = u->dtype;
+static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, bool want_sample, bool want_text,
+                         hipStream_t st) {
+  const int dt = u->dtype;
   const dh_unet_config& c = u->cfg;
+  const float* d_eps = has_eps ? u->io_eps : nullptr;
+  float* d_sample = want_sample ? u->out_dsample : nullptr;
+  float* d_text = want_text ? u->out_dtext : nullptr;
   u->flops_bwd = 0;
   std::fill(u->gready.begin(), u->gready.end(), 0);
-  if (d_act)
-    for (int i = 0; i < 3; ++i)
-      if (d_act[i]) {
-        const Ten& t = u->tens[u->act_ids[i]];
-        DH_CHECK_HIP(hipMemcpyAsync(u->gptr(u->act_ids[i]), d_act[i], (size_t)B * t.rows * t.C * 2,
-                                    hipMemcpyDeviceToDevice, st));
-        u->gready[u->act_ids[i]] = 1;
-      }
+  for (int i = 0; i < 3; ++i)
+    if (act_mask & (1u << i)) u->gready[u->act_ids[i]] = 1;     // seeded by the caller's copy
   Bwd bw{u, B, dt, st, d_text != nullptr};
   bool text_grad_written = false;
   for (int oi = (int)u->ops.size() - 1; oi >= 0; --oi) {
@@ -793,8 +843,36 @@ extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_e
   if (d_text) {
     const size_t n = (size_t)B * c.text_len * c.cross_attention_dim;
     if (text_grad_written) launch_t_to_f32(dt, u->gptr(u->t_text), d_text, n, 0, st);
-    else DH_CHECK_HIP(hipMemsetAsync(d_text, 0, n * 4, st));
+    else (void)hipMemsetAsync(d_text, 0, n * 4, st);
   }
+}
+
+extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* d_sample, float* d_text,
+                                void* stream) {
+  DH_REQUIRE(u, "null engine");
+  DH_REQUIRE(u->saved_batch > 0, "no saved forward: call dh_unet_forward(save_for_backward=1) first");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = u->saved_batch;
+  const dh_unet_config& c = u->cfg;
+  const size_t ns = (size_t)B * c.sample_size * c.sample_size;
+  const size_t nt = (size_t)B * c.text_len * c.cross_attention_dim;
+  unsigned mask = 0;
+  if (d_act)
+    for (int i = 0; i < 3; ++i)
+      if (d_act[i]) {
+        const Ten& t = u->tens[u->act_ids[i]];
+        DH_CHECK_HIP(hipMemcpyAsync(u->gptr(u->act_ids[i]), d_act[i], (size_t)B * t.rows * t.C * 2,
+                                    hipMemcpyDeviceToDevice, st));
+        mask |= 1u << i;
+      }
+  if (d_eps) DH_CHECK_HIP(hipMemcpyAsync(u->io_eps, d_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
+  const unsigned key = 0x1000u | (unsigned)B | (mask << 4) | (d_eps ? 0x100u : 0) | (d_sample ? 0x200u : 0) |
+                       (d_text ? 0x400u : 0);
+  int rc = run_graphed(u, key, st, &u->flops_bwd,
+                       [&]() { backward_ops(u, B, mask, d_eps != nullptr, d_sample != nullptr, d_text != nullptr, st); });
+  if (rc != DH_OK) return rc;
+  if (d_sample) DH_CHECK_HIP(hipMemcpyAsync(d_sample, u->out_dsample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
+  if (d_text) DH_CHECK_HIP(hipMemcpyAsync(d_text, u->out_dtext, nt * 4, hipMemcpyDeviceToDevice, st));
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

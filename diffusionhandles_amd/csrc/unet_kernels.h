@@ -24,6 +24,7 @@ struct GemmArgs {
 };
 // D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+bool gemm_profiling_on();   // HIP-event bracket active (bench roofline pass): graphs are bypassed
 // plain [N][K] -> tiled weight layout (test hooks); N, K multiples of 64
 void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st);
 // element offset of (n, k) in the tiled weight layout: [N/64][K/64] tiles of 64x64 halves (8 KiB,
@@ -62,7 +63,8 @@ void launch_pool2x2_sum(int dtype, const void* src, void* dst, int B, int h, int
                         hipStream_t st);                     // dst[b][y][x] (=|+=) sum of the 2x2 block of src
 void launch_f32_to_t(int dtype, const float* src, void* dst, size_t n, hipStream_t st);
 void launch_t_to_f32(int dtype, const void* src, float* dst, size_t n, int accumulate, hipStream_t st);
-void launch_timestep_embedding(int dtype, float t, int dim, int B, void* out, hipStream_t st);   // [B][dim] = [cos|sin]
+void launch_timestep_embedding(int dtype, const float* t_dev, int dim, int B, void* out, hipStream_t st);   // [B][dim] = [cos|sin]
+void launch_set_scalar(float* p, float v, hipStream_t st);
 
 // flash attention, head dim 64.  q [B*Nq][ldq], k/v [B*Nk][ldk] (head h at column h*64),
 // o [B*Nq][ldo]; lse [B][H][Nq] f32 (natural log)

@@ -544,7 +544,8 @@ void launch_t_to_f32(int dtype, const void* src, float* dst, size_t n, int accum
 
 // Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos(t f_i) | sin(t f_i)], f_i = 10000^(-i/half)
 template <class T>
-__global__ void k_timestep(float t, int dim, int B, T* out) {
+__global__ void k_timestep(const float* tp, int dim, int B, T* out) {
+  const float t = *tp;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int half = dim / 2;
   if (i >= B * dim) return;
@@ -553,7 +554,9 @@ __global__ void k_timestep(float t, int dim, int B, T* out) {
   const float a = t * f;
   out[i] = from_f32<T>(j < half ? cosf(a) : sinf(a));
 }
-void launch_timestep_embedding(int dtype, float t, int dim, int B, void* out, hipStream_t st) {
+__global__ void k_set_scalar(float* p, float v) { *p = v; }
+void launch_set_scalar(float* p, float v, hipStream_t st) { hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, p, v); }
+void launch_timestep_embedding(int dtype, const float* t, int dim, int B, void* out, hipStream_t st) {
   if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_timestep<f16>), dim3(cdiv(B * dim, 256)), dim3(256), 0, st, t, dim, B, (f16*)out);
   else hipLaunchKernelGGL((k_timestep<bf16>), dim3(cdiv(B * dim, 256)), dim3(256), 0, st, t, dim, B, (bf16*)out);
 }

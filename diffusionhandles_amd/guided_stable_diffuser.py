@@ -130,7 +130,29 @@ class GuidedStableDiffuser(GuidedDiffuser):
             self.text_encoder = self.text_encoder.to(device)
             self.vae = self.vae.to(device)
         self.device = device
+        # a created (non-default) stream: the engine replays its passes as hipGraphs, which the legacy
+        # default stream cannot capture
+        self._stream = torch.cuda.Stream(device=device)
         return self
+
+    class _on_stream:
+        """Run a block on the diffuser's stream, ordered after / before the caller's current stream."""
+
+        def __init__(self, gd):
+            self.gd = gd
+
+        def __enter__(self):
+            self.outer = torch.cuda.current_stream(self.gd.device)
+            self.gd._stream.wait_stream(self.outer)
+            self.ctx = torch.cuda.stream(self.gd._stream)
+            self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            self.ctx.__exit__(*a)
+            self.outer.wait_stream(self.gd._stream)
+
+    def on_stream(self):
+        return GuidedStableDiffuser._on_stream(self)
 
     def get_image_shape(self):
         f = self.get_feature_shape()
@@ -214,6 +236,10 @@ class GuidedStableDiffuser(GuidedDiffuser):
     @torch.no_grad()
     def initial_inference(self, init_latents, depth, uncond_embeddings, prompt):
         """Returns (activations [3 x [T,C,h,w]], latents [1,4,H,W], uncond_embeddings, init_latents)."""
+        with self.on_stream():
+            return self._initial_inference(init_latents, depth, uncond_embeddings, prompt)
+
+    def _initial_inference(self, init_latents, depth, uncond_embeddings, prompt):
         torch.manual_seed(self.conf.seed)
         self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
         timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
@@ -286,7 +312,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
 
     def guided_inference(self, latents, depth, uncond_embeddings, prompt, activations_orig, correspondences,
                          fg_weight=None, bg_weight=None, save_denoising_steps=False, record=None):
-        with torch.no_grad():
+        with torch.no_grad(), self.on_stream():
             torch.manual_seed(self.conf.seed)
             self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
             timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)

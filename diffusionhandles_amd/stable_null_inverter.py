@@ -120,6 +120,10 @@ class StableNullInverter(NullInverter):
 
     def invert(self, target_img, depth, prompt, num_inner_steps=10, early_stop_epsilon=1e-5, verbose=False,
                max_timesteps=None):
+        with self.model.on_stream():
+            return self._invert(target_img, depth, prompt, num_inner_steps, early_stop_epsilon, verbose, max_timesteps)
+
+    def _invert(self, target_img, depth, prompt, num_inner_steps, early_stop_epsilon, verbose, max_timesteps):
         dev = self.model.device
         depth64 = self.model.init_depth(depth.to(dev, torch.float32))
         depth_nhwc = depth64.permute(0, 2, 3, 1).contiguous() if self.model.conf.use_depth else None

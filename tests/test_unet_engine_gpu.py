@@ -74,7 +74,8 @@ def run_case(cfg, dtype, B, t, tol_f, tol_b, check_text=True):
 
 def test_engine_tiny_fp16():
     from oracle import unet_torch as U
-    run_case(U.TINY, torch.float16, 2, 480.0, 1e-2, 3e-2)
+    with torch.cuda.stream(torch.cuda.Stream()):      # created stream: exercises the hipGraph replay path
+        run_case(U.TINY, torch.float16, 2, 480.0, 1e-2, 3e-2)
 
 
 def test_engine_tiny_bf16():

@@ -11,6 +11,8 @@ u.init_synthetic(0)
 print("weights GB", u.weight_bytes() / 1e9, "workspace GB", u.workspace_bytes() / 1e9)
 dev = u.device
 g = torch.Generator(device=dev).manual_seed(0)
+side = torch.cuda.Stream()
+torch.cuda.set_stream(side)
 for B in (1, 2):
     x = torch.randn(B, 64, 64, 5, generator=g, device=dev)
     txt = torch.randn(B, 77, 1024, generator=g, device=dev)
