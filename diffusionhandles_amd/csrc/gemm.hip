@@ -115,7 +115,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
 
-template <class T, int BM, int BN, int ST, int MODE>
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
 __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int NPA = BM / 32, NPB = BN / 32;     // 1-KiB pieces per wave per stage
@@ -168,30 +168,24 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   int tap = 0, c0 = 0;
   if (MODE != GM_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
 
-  auto issue = [&](int kt, int stage) {
+  // one 1-KiB piece q (0..NPA-1: A rows, NPA..NP-1: W rows) of K tile kt into ring slot `stage`;
+  // the conv (tap, c0) cursor belongs to the tile currently being issued and advances with next_tile()
+  auto issue_piece = [&](int kt, int stage, int q) {
     const int k0 = kbeg + kt * BK;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 1024);
-    if (MODE == GM_DENSE) {
-#pragma unroll
-      for (int j = 0; j < NPA; ++j) {
+    if (q < NPA) {
+      const int j = q;
+      if (MODE == GM_DENSE) {
         const T* ptr = Ag + a_off[j] + k0;
         dma16(a_ok[j] ? ptr : zero, sbase + j * 4096);
-      }
-    } else if (MODE == GM_CONV_S1) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const long toff = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda + c0;
-#pragma unroll
-      for (int j = 0; j < NPA; ++j) {
+      } else if (MODE == GM_CONV_S1) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const long toff = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda + c0;
         const bool ok = a_ok[j] && (unsigned)(a_oy[j] + ky - 1) < (unsigned)p.Hin && (unsigned)(a_ox[j] + kx - 1) < (unsigned)p.Win;
         const T* ptr = Ag + a_off[j] + toff;
         dma16(ok ? ptr : zero, sbase + j * 4096);
-      }
-      c0 += BK;
-      if (c0 >= p.Cin) { c0 = 0; ++tap; }
-    } else {
-      const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-      for (int j = 0; j < NPA; ++j) {
+      } else {
+        const int ky = tap / 3, kx = tap - ky * 3;
         bool ok = a_ok[j];
         int sy, sx;
         if (p.mode == A_CONV3) {
@@ -208,12 +202,18 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
         const T* ptr = Ag + (a_off[j] + (long)sy * p.Win + sx) * p.lda + c0 + lchunk * 8;
         dma16(ok ? ptr : zero, sbase + j * 4096);
       }
-      c0 += BK;
-      if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    } else {
+      const int j = q - NPA;
+      dma16(b_ptr[j] + (size_t)(k0 >> 6) * 4096, sbase + BM * 128 + j * 4096);
     }
-    const size_t wk = (size_t)(k0 >> 6) * 4096;
+  };
+  auto next_tile = [&]() {
+    if (MODE != GM_DENSE) { c0 += BK; if (c0 >= p.Cin) { c0 = 0; ++tap; } }
+  };
+  auto issue = [&](int kt, int stage) {
 #pragma unroll
-    for (int j = 0; j < NPB; ++j) dma16(b_ptr[j] + wk, sbase + BM * 128 + j * 4096);
+    for (int q = 0; q < NP; ++q) issue_piece(kt, stage, q);
+    next_tile();
   };
 
   v16f acc[TM][TN];
@@ -228,28 +228,41 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   for (int s = 0; s < ST - 1; ++s)
     if (s < ntiles) issue(s, s);
 
+  constexpr int KK = BK / 16;
   for (int kt = 0; kt < ntiles; ++kt) {
     // tile kt has landed once at most (ST-2) later tiles' loads are still outstanding
     if (ntiles - 1 - kt >= ST - 2) wait_vmcnt<NP * (ST - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (kt + ST - 1 < ntiles) issue(kt + ST - 1, (kt + ST - 1) % ST);
+    const bool more = ABL != 2 && kt + ST - 1 < ntiles;
+    const int nkt = kt + ST - 1, nstage = nkt % ST;
+    if (ABL == 1) { if (more) issue(nkt, nstage); continue; }
     const unsigned char* sa = smem + (kt % ST) * STAGE;
     const unsigned char* sb = sa + BM * 128;
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
+    uint4 fw[2][TN], fx[2][TM];
+    auto load_frags = [&](int kk, int buf) {
       const int pc = ((2 * kk + hi) ^ (ln & 7)) << 4;
-      uint4 fw[TN], fx[TM];
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fw[j] = *reinterpret_cast<const uint4*>(sb + (wn * (BN / 2) + j * 32 + ln) * 128 + pc);
+        fw[buf][j] = *reinterpret_cast<const uint4*>(sb + (wn * (BN / 2) + j * 32 + ln) * 128 + pc);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fx[i] = *reinterpret_cast<const uint4*>(sa + (wm * (BM / 2) + i * 32 + ln) * 128 + pc);
+        fx[buf][i] = *reinterpret_cast<const uint4*>(sa + (wm * (BM / 2) + i * 32 + ln) * 128 + pc);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (kk + 1 < KK) load_frags(kk + 1, (kk + 1) & 1);      // next fragments fly under this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[j], fx[i], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[kk & 1][j], fx[kk & 1][i], acc[i][j]);
+      // the DMA of tile kt+ST-1 is issued piecewise behind the MFMAs (address VALU co-issues with the matrix pipe)
+      if (more) {
+#pragma unroll
+        for (int q = kk * NP / KK; q < (kk + 1) * NP / KK; ++q) issue_piece(nkt, nstage, q);
+      }
     }
+    if (more) next_tile();
   }
 
 #pragma unroll
@@ -346,6 +359,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
     else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1>), grid, dim3(256), 0, st, k); \
     else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC>), grid, dim3(256), 0, st, k);                    \
   } while (0)
+  static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
+  if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
+  else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
+  else if (kAbl == 3 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 1>), grid, dim3(256), 0, st, k); }
+  else
   if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
   else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
   else DH_LAUNCH_GEMM(128, 64, 5);
