@@ -317,7 +317,7 @@ template <class T>
 static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
   // tile / split-K policy (environment overrides are for tuning runs only)
   static const int kSplitTiles = getenv("DH_SPLITK_TILES") ? atoi(getenv("DH_SPLITK_TILES")) : 200;
-  static const int kSplitMinK = getenv("DH_SPLITK_MINKT") ? atoi(getenv("DH_SPLITK_MINKT")) : 8;
+  static const int kSplitMinK = getenv("DH_SPLITK_MINKT") ? atoi(getenv("DH_SPLITK_MINKT")) : 24;
   static const int kSplitTarget = getenv("DH_SPLITK_TARGET") ? atoi(getenv("DH_SPLITK_TARGET")) : 256;
   static const int kBigTiles = getenv("DH_BIG_TILES") ? atoi(getenv("DH_BIG_TILES")) : 0;
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
