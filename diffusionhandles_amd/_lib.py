@@ -37,6 +37,8 @@ SIGNATURES = {
                                  ctypes.POINTER(c_d), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "dh_unproject": (c_i, [c_p, c_i, c_p, c_p, c_f, c_f, c_p, c_p]),
     "dh_masked_centroid": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_p]),
+    "dh_laplacian_blend_workspace_bytes": (c_i, [c_i, ctypes.POINTER(c_sz)]),
+    "dh_laplacian_blend": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "dh_cells_workspace_bytes": (c_i, [c_i, c_i, ctypes.POINTER(c_sz)]),
     "dh_cells_from_correspondences": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "dh_energy_workspace_bytes": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_sz)]),

@@ -266,7 +266,7 @@ __global__ void k_normalize(int R2, float* disp, const unsigned int* minmax, con
 __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const uint8_t* inpaint, const int* unk,
                                                   const int* counts, int count_stride, int slot_n, int slot_it,
                                                   double* vx, double* vr, double* vp, double* vq, int max_iter,
-                                                  double tol2, int* counts_out) {
+                                                  double tol2, int* counts_out, const float* rhs_extra) {
   __shared__ double sm[16];
   const int e = blockIdx.x, R2 = res * res;
   const int n = counts[e * count_stride + slot_n];
@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
     if (y < res - 1 && !mk[pix + res]) b += (double)d[pix + res];
     if (xx > 0 && !mk[pix - 1]) b += (double)d[pix - 1];
     if (xx < res - 1 && !mk[pix + 1]) b += (double)d[pix + 1];
+    if (rhs_extra) b -= (double)rhs_extra[(size_t)e * R2 + pix];
     x[pix] = 0.0;
     r[pix] = b;
     p[pix] = b;
@@ -335,6 +336,31 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
     d[pix] = (float)x[pix];
   }
   if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = it;
+}
+
+// cross-element binary dilation (scipy.ndimage.binary_dilation default structure, border 0)
+__global__ void k_dilate_cross(const uint8_t* src, uint8_t* dst, int res) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= res * res) return;
+  int y = p / res, x = p - y * res;
+  int v = src[p];
+  if (y > 0) v |= src[p - res];
+  if (y < res - 1) v |= src[p + res];
+  if (x > 0) v |= src[p - 1];
+  if (x < res - 1) v |= src[p + 1];
+  dst[p] = v ? 1 : 0;
+}
+// 5-point Laplacian with zero padding (scipy.ndimage.convolve(mode='constant')), f64 sum rounded to f32
+__global__ void k_laplacian(const float* img, float* out, int res) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= res * res) return;
+  int y = p / res, x = p - y * res;
+  double a = -4.0 * (double)img[p];
+  if (y > 0) a += (double)img[p - res];
+  if (y < res - 1) a += (double)img[p + res];
+  if (x > 0) a += (double)img[p - 1];
+  if (x < res - 1) a += (double)img[p + 1];
+  out[p] = (float)a;
 }
 
 // OpenCV's classic MORPH_ELLIPSE rows, as (dx, dy) offsets from the anchor
@@ -498,7 +524,49 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
                      clean_mask, w.inpaint);
   compact(w.inpaint, R2, K, R2, w.unk, R2, counts + 2, 4, w.block_counts, st);
   hipLaunchKernelGGL(k_cg_fill, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3, w.vx,
-                     w.vr, w.vp, w.vq, 20000, 1e-24, counts);
+                     w.vr, w.vp, w.vq, 20000, 1e-24, counts, (const float*)nullptr);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_laplacian_blend_workspace_bytes(int res, size_t* bytes) {
+  DH_REQUIRE(res >= 2 && bytes, "bad arguments");
+  const size_t R2 = (size_t)res * res;
+  *bytes = 4 * align_up(R2 * 8, 256) + 3 * align_up(R2, 256) + 2 * align_up(R2 * 4, 256) +
+           (size_t)(cdiv((int)R2, CP_TILE) + 2) * 4 + 4096;
+  return DH_OK;
+}
+
+// DiffusionHandles.set_foreground (diffusion_handles.py:90-111) = utils.solve_laplacian_depth (utils.py:49-102)
+// over binary_dilation(fg_mask, iterations): out = depth outside the dilated mask, inside the solution of
+// 4 x - sum(masked nbrs) = sum(known depth nbrs) - laplacian(bg_depth).
+extern "C" int dh_laplacian_blend(const float* depth, const float* bg_depth, const uint8_t* fg_mask, int res,
+                                  int dilate_iters, float* out, int32_t* counts, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  DH_REQUIRE(depth && bg_depth && fg_mask && out && counts && workspace && res >= 2 && dilate_iters >= 0, "bad arguments");
+  size_t need;
+  dh_laplacian_blend_workspace_bytes(res, &need);
+  DH_REQUIRE(workspace_bytes >= need, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int R2 = res * res;
+  Arena a(workspace, workspace_bytes);
+  double* vx = a.take<double>(R2); double* vr = a.take<double>(R2); double* vp = a.take<double>(R2); double* vq = a.take<double>(R2);
+  uint8_t* m0 = a.take<uint8_t>(R2); uint8_t* m1 = a.take<uint8_t>(R2);
+  float* lap = a.take<float>(R2);
+  int* unk = a.take<int>(R2);
+  int* bc = a.take<int>(cdiv(R2, CP_TILE) + 2);
+  DH_CHECK_HIP(hipMemcpyAsync(m0, fg_mask, R2, hipMemcpyDeviceToDevice, st));
+  uint8_t *src = m0, *dst = m1;
+  for (int i = 0; i < dilate_iters; ++i) {
+    hipLaunchKernelGGL(k_dilate_cross, dim3(cdiv(R2, 256)), dim3(256), 0, st, src, dst, res);
+    uint8_t* t = src; src = dst; dst = t;
+  }
+  hipLaunchKernelGGL(k_laplacian, dim3(cdiv(R2, 256)), dim3(256), 0, st, bg_depth, lap, res);
+  DH_CHECK_HIP(hipMemcpyAsync(out, depth, (size_t)R2 * 4, hipMemcpyDeviceToDevice, st));
+  DH_CHECK_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int), st));
+  compact(src, R2, 1, 0, unk, 0, counts + 2, 1, bc, st);
+  hipLaunchKernelGGL(k_cg_fill, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, vx, vr, vp, vq, 50000,
+                     1e-24, counts, (const float*)lap);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

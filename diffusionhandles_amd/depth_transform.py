@@ -185,3 +185,26 @@ def transform_depth(depth, bg_depth, fg_mask, intrinsics, rot_angle=None, rot_ax
         raise NotImplementedError("depth_transform_mode='mesh' (pytorch3d rasteriser) is not built yet; "
                                   "the z-buffered point path ('pc') replaces it")
     raise ValueError(f"Unknown depth transform mode '{depth_transform_mode}'.")
+
+
+def laplacian_depth_blend(depth, bg_depth, fg_mask, dilate_iterations=15):
+    """set_foreground's background-depth update (diffusion_handles.py:90-111): `depth` everywhere except
+    inside the dilated foreground mask, where the background depth's Laplacian is integrated from the
+    surrounding depth values.  [1,1,H,W] tensors in, [1,1,H,W] float32 out (on depth.device)."""
+    res = depth.shape[-1]
+    if depth.shape[-2] != res:
+        raise RuntimeError("square depth maps only")
+    out_dev = depth.device
+    dev = _compute_device(depth)
+    L = _lib.lib()
+    d = depth.detach().to(dev, torch.float32).contiguous()
+    bg = bg_depth.detach().to(dev, torch.float32).contiguous()
+    m = (fg_mask.detach().to(dev) != 0).to(torch.uint8).contiguous()
+    out = torch.empty((res, res), dtype=torch.float32, device=dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.dh_laplacian_blend_workspace_bytes(res, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    _lib.check(L.dh_laplacian_blend(_lib.ptr(d), _lib.ptr(bg), _lib.ptr(m), res, int(dilate_iterations), _lib.ptr(out),
+                                    _lib.ptr(counts), _lib.ptr(ws), nbytes.value, _lib.stream_ptr()), "dh_laplacian_blend")
+    return out[None, None].to(out_dev)

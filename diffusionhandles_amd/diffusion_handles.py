@@ -2,7 +2,7 @@
 import torch
 
 from . import conf as _conf
-from .depth_transform import normalize_depth, transform_depth
+from .depth_transform import laplacian_depth_blend, normalize_depth, transform_depth
 from .guided_stable_diffuser import GuidedStableDiffuser
 from .stable_null_inverter import StableNullInverter
 
@@ -38,9 +38,9 @@ class DiffusionHandles:
         return null_text_emb, init_noise, activations, latent_image
 
     def set_foreground(self, depth, fg_mask, bg_depth):
-        """Poisson blend of the background depth into the dilated mask hole
-        (reference diffusion_handles.py:90-111 / utils.solve_laplacian_depth) -- SURVEY 8f 'next'."""
-        raise NotImplementedError("set_foreground (Laplacian depth blend) is scheduled after the hot path (SURVEY 8f-1)")
+        """Background depth = input depth with the hole of the (15x cross-dilated) foreground mask in-filled
+        from the background depth's Laplacian (reference diffusion_handles.py:90-111)."""
+        return laplacian_depth_blend(depth, bg_depth, fg_mask, dilate_iterations=15)
 
     def transform_foreground(self, depth, prompt, fg_mask, bg_depth, null_text_emb, init_noise, activations,
                              rot_angle=None, rot_axis=None, translation=None, fg_weight=None, bg_weight=None,

@@ -81,6 +81,15 @@ int dh_masked_centroid(const float* depth, const int32_t* fg_pix, int n_fg, int 
                        const float* grid_x, const float* grid_y, float inv_fx, float inv_fy,
                        float* centroid, void* stream);
 
+/* Laplacian depth blend of DiffusionHandles.set_foreground (diffusion_handles.py:90-111,
+ * utils.solve_laplacian_depth utils.py:49-102): inside binary_dilation(fg_mask, dilate_iters) (cross
+ * element) solve 4x - sum(masked nbrs) = sum(known depth nbrs) - laplacian(bg_depth); elsewhere copy depth.
+ * counts[4] i32: {_, _, n_unknown, cg_iterations}. */
+int dh_laplacian_blend_workspace_bytes(int res, size_t* bytes);
+int dh_laplacian_blend(const float* depth, const float* bg_depth, const uint8_t* fg_mask, int res,
+                       int dilate_iters, float* out, int32_t* counts, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* --------------------------------------------------------------------------------------
  * Correspondences -> grid x grid cell index lists.  Replaces
  * GuidedStableDiffuser.process_correspondences (guided_stable_diffuser.py:490-584),

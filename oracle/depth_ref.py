@@ -298,3 +298,42 @@ def transform_depth_pc(depth, bg_depth, fg_mask, K=None, rot_angle=None, rot_axi
         return out, torch.from_numpy(corr), dict(zmap=zmap, raw_mask=raw_mask, cleaned=cleaned, vis=vis,
                                                    tx=tx, ty=ty, inpaint=inpaint, disparity=disparity)
     return out, torch.from_numpy(corr)
+
+
+def laplacian_blend(fg_depth, bg_depth, mask):
+    """utils.solve_laplacian_depth (utils.py:49-102) restated: harmonic_fill with the background depth's
+    5-point Laplacian (zero padding) on the right-hand side."""
+    import scipy.ndimage
+    fg = np.asarray(fg_depth)
+    mk = np.asarray(mask).astype(bool)
+    lap = scipy.ndimage.convolve(np.asarray(bg_depth), np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]]), mode="constant")
+    ys, xs = np.nonzero(mk)
+    n = ys.size
+    out = fg.copy()
+    if n == 0:
+        return out
+    h, w = fg.shape
+    idx = -np.ones((h, w), dtype=np.int64)
+    idx[ys, xs] = np.arange(n)
+    rows, cols, vals = [np.arange(n)], [np.arange(n)], [np.full(n, 4.0)]
+    b = np.zeros(n)
+    for dy, dx in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+        yy, xx = ys + dy, xs + dx
+        inside = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        yc, xc = np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)
+        unk = inside & mk[yc, xc]
+        known = inside & ~mk[yc, xc]
+        rows.append(np.nonzero(unk)[0]); cols.append(idx[yc[unk], xc[unk]]); vals.append(np.full(unk.sum(), -1.0))
+        b[known] += fg[yc[known], xc[known]]
+    b -= lap[ys, xs]
+    A = scipy.sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    out[ys, xs] = scipy.sparse.linalg.spsolve(A, b)
+    return out
+
+
+def set_foreground(depth, fg_mask, bg_depth):
+    """DiffusionHandles.set_foreground (diffusion_handles.py:90-111) on [1,1,H,W] torch tensors."""
+    import scipy.ndimage
+    m = scipy.ndimage.binary_dilation(fg_mask[0, 0].numpy(), iterations=15)
+    out = laplacian_blend(depth[0, 0].numpy(), bg_depth[0, 0].numpy(), m)
+    return torch.from_numpy(out)[None, None]

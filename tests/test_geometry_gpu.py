@@ -172,3 +172,19 @@ def test_energy_fp16_and_scaling():
     # determinism of the gradient (integer sign sums, single writer per element)
     loss2, grad2 = LS.energy_and_grad(cur.to(dev), org.to(dev), pc, 3.0, 2.0, grad_scale=256.0)
     assert torch.equal(grad, grad2)
+
+
+def test_set_foreground_laplacian_blend_vs_oracle():
+    """set_foreground: f64 CG on the GPU vs the oracle's sparse direct solve; depth values O(1..6) -> 1e-4."""
+    from oracle import depth_ref as D
+    from diffusionhandles_amd import depth_transform as DT
+    depth, bg, mask = make_scene(256)
+    bg = bg + 0.05 * torch.sin(torch.arange(256, dtype=torch.float32) / 9.0)[None, None, None, :]
+    out = DT.laplacian_depth_blend(depth.to(_dev()), bg.to(_dev()), mask.to(_dev()))
+    ref = D.set_foreground(depth, mask, bg)
+    assert out.shape == (1, 1, 256, 256) and out.dtype == torch.float32
+    assert float((out.cpu() - ref).abs().max()) < 1e-4
+    # outside the dilated mask the depth is untouched
+    import scipy.ndimage
+    m = scipy.ndimage.binary_dilation(mask[0, 0].numpy(), iterations=15)
+    assert torch.equal(out.cpu()[0, 0][~torch.from_numpy(m)], depth[0, 0][~torch.from_numpy(m)])

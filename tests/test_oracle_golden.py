@@ -146,3 +146,9 @@ def test_ddim_scheduler_properties():
     # invert_step then step with the same eps is the identity (DDIM is deterministic)
     y = s.invert_step(e, 500, x)
     assert torch.allclose(s.step(e, 500, y), x, atol=1e-5)
+
+
+def test_laplacian_blend_matches_reference(golden):
+    g9 = golden("g9_misc.npz")
+    out = D.laplacian_blend(g9["poisson_img"].copy(), g9["laplacian_bg"], g9["poisson_mask"].astype(bool))
+    assert np.allclose(out, g9["laplacian_out"], atol=1e-9)
