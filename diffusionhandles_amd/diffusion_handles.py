@@ -42,6 +42,18 @@ class DiffusionHandles:
         from the background depth's Laplacian (reference diffusion_handles.py:90-111)."""
         return laplacian_depth_blend(depth, bg_depth, fg_mask, dilate_iterations=15)
 
+    def transform_foreground_batch(self, depth, prompt, fg_mask, bg_depth, null_text_emb, init_noise, activations,
+                                   transforms, fg_weight=None, bg_weight=None, use_input_depth_normalization=False):
+        """K edits of one image in one batched pass (not in the reference; BASELINE config 3).
+        transforms: list of (rot_angle_deg, rot_axis[3], translation[3]).  Returns (images [K,3,H,W], [K disparities])."""
+        from .depth_transform import reproject_edits
+        with torch.no_grad():
+            edits = reproject_edits(depth, bg_depth, fg_mask, self.diffuser.get_depth_intrinsics(device=depth.device),
+                                    transforms, use_input_depth_normalization)
+            imgs = self.diffuser.guided_inference_batch(init_noise, [d for d, _ in edits], null_text_emb, prompt,
+                                                        activations, [c for _, c in edits], fg_weight, bg_weight)
+        return imgs, [d for d, _ in edits]
+
     def transform_foreground(self, depth, prompt, fg_mask, bg_depth, null_text_emb, init_noise, activations,
                              rot_angle=None, rot_axis=None, translation=None, fg_weight=None, bg_weight=None,
                              use_input_depth_normalization=False):

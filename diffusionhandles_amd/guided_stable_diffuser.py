@@ -310,6 +310,63 @@ class GuidedStableDiffuser(GuidedDiffuser):
         eu, ec = self._cfg_eps(x, st.depth_nhwc, t, uncond, st.cond)
         return self.ddim_step(x, eu, ec, t)
 
+    # ---- batched edits: K transforms of ONE image identity in one U-Net batch (BASELINE config 3) ------
+    def guided_step_batch(self, sts, x, t_idx, t, uncond):
+        """x: [K,H,W,4]; sts: K guidance states (same prompt / original activations, different edits)."""
+        L = _lib.lib()
+        K = x.shape[0]
+        depth = torch.cat([st.depth_nhwc for st in sts], dim=0)
+        cond = sts[0].cond.expand(K, -1, -1).contiguous()
+        iteration = 0
+        while iteration < self.conf.num_optsteps and t_idx < self.conf.guidance_max_step:
+            fgw, bgw = sts[0].schedule(t_idx, iteration)
+            active = [k for k in range(3) if fgw[k] != 0.0 or bgw[k] != 0.0]
+            if active:
+                sample = torch.cat([x, depth], dim=-1).contiguous() if self.conf.use_depth else x
+                _, acts = self.unet.forward(sample, float(t), cond, save_for_backward=True)
+                d_acts = [None, None, None]
+                for k in active:
+                    g_all = torch.empty_like(acts[k])
+                    for e, st in enumerate(sts):
+                        fw = fgw[k] if st.n_pairs > 0 else 0.0
+                        _, g = energy_and_grad(acts[k][e], st.orig[k][t_idx], st.pc, fw, bgw[k], self.conf.fg_patch_size,
+                                               self.conf.bg_patch_size, st.size, self.conf.bg_loss_type,
+                                               grad_scale=self.grad_scale)
+                        g_all[e].copy_(g)
+                    d_acts[k] = g_all
+                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
+                g_lat = d_sample[..., : x.shape[-1]].contiguous()
+                x_new = torch.empty_like(x)
+                _lib.check(L.dh_latent_update(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(g_lat), 0.1, self.grad_scale,
+                                              x.numel(), _lib.stream_ptr()), "dh_latent_update")
+                x = x_new
+            iteration += 1
+        sample = torch.cat([x, depth], dim=-1) if self.conf.use_depth else x
+        sample2 = torch.cat([sample, sample], dim=0).contiguous()
+        unc = uncond.reshape(1, *cond.shape[1:]).to(self.device, torch.float32).expand(K, -1, -1)
+        text2 = torch.cat([unc, cond], dim=0).contiguous()
+        eps, _ = self.unet.forward(sample2, float(t), text2, save_for_backward=False, want_acts=False)
+        return self.ddim_step(x, eps[:K].contiguous(), eps[K:].contiguous(), t)
+
+    def guided_inference_batch(self, latents, depths, uncond_embeddings, prompt, activations_orig, correspondences_list,
+                               fg_weight=None, bg_weight=None):
+        """K edits of one image at once.  depths: list of K edited disparities [1,1,H,W]; correspondences_list:
+        K [N_k,4] tensors.  Needs an engine built with max_batch >= 2K.  Returns images [K,3,H,W]."""
+        K = len(depths)
+        if self.unet.max_batch < 2 * K:
+            raise RuntimeError(f"engine max_batch {self.unet.max_batch} < 2*K = {2 * K}")
+        with torch.no_grad(), self.on_stream():
+            torch.manual_seed(self.conf.seed)
+            self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
+            timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
+            sts = [self.prepare_guidance(d, prompt, activations_orig, c, fg_weight, bg_weight)
+                   for d, c in zip(depths, correspondences_list)]
+            x = _nhwc(latents.to(self.device, torch.float32)).expand(K, -1, -1, -1).contiguous()
+            for t_idx, t in enumerate(timesteps):
+                x = self.guided_step_batch(sts, x, t_idx, t, uncond_embeddings[t_idx])
+            self.last_latents = x.permute(0, 3, 1, 2)
+            return self.decode_latent_image(self.last_latents)
+
     def guided_inference(self, latents, depth, uncond_embeddings, prompt, activations_orig, correspondences,
                          fg_weight=None, bg_weight=None, save_denoising_steps=False, record=None):
         with torch.no_grad(), self.on_stream():

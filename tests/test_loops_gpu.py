@@ -111,3 +111,30 @@ def test_null_inversion_matches_oracle(rig):
     e2 = rel(d_p, d_o)
     print("null-text update rel err", e2, "norm", d_o.norm().item())
     assert e2 < 0.2
+
+
+def test_batched_edits_match_single_edits(rig):
+    """BASELINE config 3 shape (K transforms of one image in one U-Net batch), K=2 with the TINY engine:
+    the batched trajectory equals the two single-edit trajectories up to the engine's batch-dependent
+    tile selection (fp16)."""
+    from diffusionhandles_amd.depth_transform import reproject_edits
+    from diffusionhandles_amd.guided_stable_diffuser import GuidedStableDiffuser
+    from diffusionhandles_amd.unet import HipUNet
+    from oracle import unet_torch as U
+    if not hasattr(rig, "acts"):
+        test_initial_inference_matches_oracle(rig)
+    hip4 = HipUNet(dict(U.TINY, text_len=77), dtype=torch.float16, max_batch=4)
+    hip4.load_state_dict(rig.ref.state_dict())
+    gd4 = GuidedStableDiffuser(rig.conf, unet=hip4, unet_config=dict(U.TINY, text_len=77)).to(dev())
+    K = rig.gd.get_depth_intrinsics()
+    tfs = [(TRANSFORMS[i][0], torch.tensor([0.0, 1.0, 0.0]), torch.tensor(TRANSFORMS[i][1])) for i in (2, 4)]
+    edits = reproject_edits(rig.depth.to(dev()), rig.bg.to(dev()), rig.mask.to(dev()), K, tfs)
+    unc = rig.unc0[None].expand(50, -1, -1, -1).contiguous()
+    imgs = gd4.guided_inference_batch(rig.noise.to(dev()), [d for d, _ in edits], unc, rig.prompt, rig.acts, [c for _, c in edits])
+    assert imgs.shape == (2, 3, 512, 512)
+    batched = gd4.last_latents.clone()
+    for e, (d, c) in enumerate(edits):
+        rig.gd.guided_inference(rig.noise.to(dev()), d, unc, rig.prompt, rig.acts, c)
+        err = rel(batched[e:e + 1], rig.gd.last_latents)
+        print("batched vs single edit", e, err)
+        assert err < 5e-2
