@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps run with the HIP-event GEMM bracket")
+    ap.add_argument("--res", type=int, default=512, help="image resolution (512 = headline; 768 = BASELINE config 5)")
+    ap.add_argument("--batch-edits", type=int, default=0, help="also time K edits of one image in one U-Net batch (config 3)")
     return ap.parse_args()
 
 
@@ -84,15 +86,18 @@ def main():
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     conf = C.load_default()
-    dh = DiffusionHandles(conf, dtype=dtype).to(dev)
+    from diffusionhandles_amd.unet import SD2_DEPTH
+    lat = args.res // 8
+    ucfg = dict(SD2_DEPTH, sample_size=lat)
+    dh = DiffusionHandles(conf, dtype=dtype, unet_config=ucfg, max_batch=max(2, 2 * args.batch_edits)).to(dev)
     gd = dh.diffuser
-    depth, bg_depth, mask = (t.to(dev) for t in make_scene(512))
+    depth, bg_depth, mask = (t.to(dev) for t in make_scene(args.res))
     prompt = "a sphere on a plane"
     disparity = normalize_depth(1.0 / depth)
     T = conf.guided_diffuser.num_timesteps
     uncond = gd._encode([""])[None].expand(T, -1, -1, -1).contiguous()
     torch.manual_seed(conf.guided_diffuser.seed)
-    noise = torch.randn(1, 4, 64, 64).to(dev)
+    noise = torch.randn(1, 4, lat, lat).to(dev)
     # per-image identity, resident in HBM before the timed region
     acts, _, _, init_noise = gd.initial_inference(noise, disparity, uncond, prompt)
     ang, tr = TRANSFORMS[2 + rank % 4]
@@ -153,22 +158,44 @@ def main():
                 "step_tflop_algorithmic": STEP_TFLOP,
                 "step_frac_of_mfma_peak": round(world * args.steps / elapsed * STEP_TFLOP / MFMA_PEAK_TFLOPS / world, 4)}
 
+    batch_info = None
+    if rank == 0 and args.batch_edits > 1:
+        from diffusionhandles_amd.depth_transform import reproject_edits
+        K = args.batch_edits
+        tfs = [(TRANSFORMS[i % 8][0], torch.tensor([0.0, 1.0, 0.0]), torch.tensor(TRANSFORMS[i % 8][1])) for i in range(K)]
+        edits = reproject_edits(depth, bg_depth, mask, gd.get_depth_intrinsics(), tfs)
+        sts = [gd.prepare_guidance(d, prompt, acts, c) for d, c in edits]
+        xb = x0.expand(K, -1, -1, -1).contiguous()
+        with torch.no_grad(), gd.on_stream():
+            for i in range(2):
+                gd.guided_step_batch(sts, xb, i, timesteps[i], uncond[i])
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            nb = max(3, args.steps // 4)
+            for i in range(nb):
+                xb2 = gd.guided_step_batch(sts, xb, i % gmax, timesteps[i % gmax], uncond[i % gmax])
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+        batch_info = {"edits_in_batch": K, "ms_per_batched_step": round(tb / nb * 1e3, 2),
+                      "edit_steps_per_s": round(K * nb / tb, 2),
+                      "frac_of_mfma_peak": round(K * nb / tb * STEP_TFLOP / MFMA_PEAK_TFLOPS, 4)}
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.res == 512:
         cpu = cpu_baseline()
 
     if rank == 0:
         value = world * args.steps / elapsed
         out = {
-            "metric": "guided-denoise steps/sec at 512x512 (SD2-depth)",
+            "metric": f"guided-denoise steps/sec at {args.res}x{args.res} (SD2-depth)",
             "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
-            "config": {"workload": "single 512x512 edit per GPU, SD2-depth (865.7M params, seeded random weights), guided "
+            "config": {"workload": f"single {args.res}x{args.res} edit per GPU, SD2-depth (865.7M params, seeded random weights), guided "
                                    "phase: 3 x (fwd + energy + bwd-to-latent) + CFG fwd (B=2) + DDIM step",
-                       "resolution": 512, "edits_per_gpu": 1, "correspondences": int(corr.shape[0]),
+                       "resolution": args.res, "edits_per_gpu": 1, "correspondences": int(corr.shape[0]),
                        "parallelism": "independent edits, one process per GPU, no collectives"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "batched_edits": batch_info,
         }
         print(json.dumps(out))
     if dist is not None:
