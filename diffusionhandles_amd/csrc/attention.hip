@@ -5,9 +5,13 @@
 //                   -> accumulator rows = keys (spread over the 16 registers and the two
 //                      lane halves), column = query = lane & 31
 //   O^T += V^T P^T: the accumulator layout of P^T is, register-for-register, a valid B
-//                   operand (k = keys) as long as the A operand (V^T, read from a transposed
-//                   LDS tile) enumerates the keys in the same order -- slot j of lane half hi
-//                   in MFMA step s is key 16 s + 8 (j >> 2) + 4 hi + (j & 3).
+//                   operand (k = keys) as long as the A operand (V^T) enumerates the keys in
+//                   the same order -- slot j of lane half hi in MFMA step s is key
+//                   16 s + 8 (j >> 2) + 4 hi + (j & 3).
+// V^T (and K^T, Q^T, dO^T in the backward kernels) is never materialised: tiles are staged
+// row-major and the transposed fragments come from ds_read_b64_tr_b16 (each 16-lane group
+// reads a [4 rows][16 cols] block and lane t receives column t), so every LDS write is a
+// 16-byte store and every tile exists once.
 // The backward kernels use the same two product shapes (one with the roles of keys and
 // queries exchanged).  dQ and dK/dV are separate kernels (no atomics, deterministic).
 #include "unet_kernels.h"
@@ -17,6 +21,7 @@ namespace dh {
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef __bf16 v8b __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef short v4s __attribute__((ext_vector_type(4)));
 
 template <class T> struct Mma;
 template <> struct Mma<f16> {
@@ -31,11 +36,12 @@ template <> struct Mma<bf16> {
 };
 
 constexpr int HD = 64;        // head dim
-constexpr int TLD = 72;       // LDS row stride in halves
+constexpr int TLD = 72;       // LDS row stride in halves (144 B: conflict-free b128 and tr_b16 reads)
 constexpr int TILE = 64 * TLD;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr float SCALE = 0.125f;   // 1/sqrt(64)
+constexpr float SCALE = 0.125f;               // 1/sqrt(64)
+constexpr float CEXP = SCALE * LOG2E;         // scores are exponentiated as exp2(s * CEXP - m * CEXP)
 
 __device__ __forceinline__ v16f zero16() {
   v16f z;
@@ -43,6 +49,7 @@ __device__ __forceinline__ v16f zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // 4 register fragments (k = d) of row `row` of a [rows][ld] matrix at column col0: B-operand layout
 template <class T>
@@ -52,31 +59,22 @@ __device__ __forceinline__ void load_row_frags(const T* base, long ld, long row,
     f[kk] = ok ? *reinterpret_cast<const uint4*>(base + row * ld + col0 + 16 * kk + 8 * hi) : make_uint4(0, 0, 0, 0);
 }
 
-// a 64 x 64 tile (rows row0.., cols col0..col0+63) travels global -> 2 registers per thread (fetch, issued one
-// tile ahead of its use) -> LDS row-major `rm` and/or transposed `tr` (commit)
+// a 64 x 64 tile travels global -> 2 registers per thread (fetch, issued one tile ahead of its use) -> LDS (commit)
 struct TileRegs { uint4 v[2]; };
 template <class T>
-__device__ __forceinline__ void fetch_tile(const T* base, long ld, long row0, long rows_total, int col0, TileRegs& t) {
-  const int tid = threadIdx.x, chunk = tid & 7;
+__device__ __forceinline__ void fetch_tile(const T* tile_ptr /* base + col0 + chunk*8, per thread */, long ld, long row0,
+                                           long rows_total, TileRegs& t) {
+  const int r0 = threadIdx.x >> 3;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int r = (tid >> 3) + 32 * j;
-    t.v[j] = (row0 + r < rows_total) ? *reinterpret_cast<const uint4*>(base + (row0 + r) * ld + col0 + chunk * 8)
-                                     : make_uint4(0, 0, 0, 0);
+    const long r = row0 + r0 + 32 * j;
+    t.v[j] = (r < rows_total) ? *reinterpret_cast<const uint4*>(tile_ptr + r * ld) : make_uint4(0, 0, 0, 0);
   }
 }
-__device__ __forceinline__ void commit_tile(const TileRegs& t, unsigned short* rm, unsigned short* tr) {
-  const int tid = threadIdx.x, chunk = tid & 7;
+__device__ __forceinline__ void commit_tile(const TileRegs& t, unsigned short* rm) {
+  const int r0 = threadIdx.x >> 3, chunk = threadIdx.x & 7;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (tid >> 3) + 32 * j;
-    if (rm) *reinterpret_cast<uint4*>(&rm[r * TLD + chunk * 8]) = t.v[j];
-    if (tr) {
-      const unsigned short* e = reinterpret_cast<const unsigned short*>(&t.v[j]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) tr[(chunk * 8 + i) * TLD + r] = e[i];
-    }
-  }
+  for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(&rm[(r0 + 32 * j) * TLD + chunk * 8]) = t.v[j];
 }
 
 // acc = sum_kk mfma(A = rows (rowbase + lane&31) of an LDS row-major tile, B = register fragments)
@@ -91,19 +89,35 @@ __device__ __forceinline__ v16f tile_times_frags(const unsigned short* tile, int
   return acc;
 }
 
-// A operand from a TRANSPOSED tile: row = drow, reduction slots (step s within a 32-block at kbase)
-__device__ __forceinline__ uint4 tr_frag(const unsigned short* tr, int drow, int kbase, int s, int hi) {
-  const uint2 lo = *reinterpret_cast<const uint2*>(&tr[drow * TLD + kbase + 16 * s + 4 * hi]);
-  const uint2 hi2 = *reinterpret_cast<const uint2*>(&tr[drow * TLD + kbase + 16 * s + 8 + 4 * hi]);
-  return make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+// A operand = TRANSPOSE of a row-major tile: fragment row = tile column (cbase + lane&31), reduction slots =
+// tile rows r0.., in the accumulator order (rows r0 + 4 hi + 0..3 and r0 + 8 + 4 hi + 0..3).
+// `tptr` = &tile[(4 hi + (t >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t & 3)], t = lane & 15 (per lane, hoisted)
+__device__ __forceinline__ uint4 tr_frag(const unsigned short* tptr, int cbase, int r0) {
+  typedef __attribute__((address_space(3))) v4s* lp;
+  const unsigned short* a = tptr + r0 * TLD + cbase;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a));
+  const v4s up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a + 8 * TLD));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), u2 = __builtin_bit_cast(uint2, up);
+  return make_uint4(l2.x, l2.y, u2.x, u2.y);
 }
 
 // registers 8s..8s+7 of an accumulator -> B operand (16-bit)
 template <class T>
-__device__ __forceinline__ uint4 pack8(const v16f& p, int s) {
-  T o[8];
+__device__ __forceinline__ uint4 pack8(const v16f& p, int s);
+template <>
+__device__ __forceinline__ uint4 pack8<f16>(const v16f& p, int s) {
+  uint4 o;
+  o.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p[8 * s + 0], p[8 * s + 1]));
+  o.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p[8 * s + 2], p[8 * s + 3]));
+  o.z = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p[8 * s + 4], p[8 * s + 5]));
+  o.w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p[8 * s + 6], p[8 * s + 7]));
+  return o;
+}
+template <>
+__device__ __forceinline__ uint4 pack8<bf16>(const v16f& p, int s) {
+  bf16 o[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(p[8 * s + j]);
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)p[8 * s + j];
   return *reinterpret_cast<uint4*>(o);
 }
 
@@ -128,8 +142,8 @@ template <class T>
 __global__ void __launch_bounds__(256) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
                                                   float* lse, int H, int Nq, int Nk) {
   __shared__ __attribute__((aligned(16))) unsigned short sK[TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short sVt[TILE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5;
+  __shared__ __attribute__((aligned(16))) unsigned short sV[TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
   const bool qok = qrow < Nq;
@@ -137,42 +151,46 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const T* q, long ldq, const T*
   load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
   v16f oacc[2] = {zero16(), zero16()};
   float m_run = -INFINITY, l_run = 0.f;
-  const T* kb = k + (long)b * Nk * ldk;
-  const T* vb = v + (long)b * Nk * ldk;
+  const T* kp = k + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
+  const T* vp = v + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
+  const unsigned short* vt = sV + (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   TileRegs rk, rv;
-  fetch_tile<T>(kb, ldk, 0, Nk, h * HD, rk);
-  fetch_tile<T>(vb, ldk, 0, Nk, h * HD, rv);
+  fetch_tile<T>(kp, ldk, 0, Nk, rk);
+  fetch_tile<T>(vp, ldk, 0, Nk, rv);
   for (int k0 = 0; k0 < Nk; k0 += 64) {
     __syncthreads();
-    commit_tile(rk, sK, nullptr);
-    commit_tile(rv, nullptr, sVt);
+    commit_tile(rk, sK);
+    commit_tile(rv, sV);
     __syncthreads();
     if (k0 + 64 < Nk) {            // next tile's loads fly under this tile's MFMAs
-      fetch_tile<T>(kb, ldk, k0 + 64, Nk, h * HD, rk);
-      fetch_tile<T>(vb, ldk, k0 + 64, Nk, h * HD, rv);
+      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk);
+      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv);
     }
     v16f s[2];
-    float mx = -INFINITY;
+    s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
+    s[1] = tile_times_frags<T>(sK, 32, ln, hi, qf);
+    if (k0 + 64 > Nk) {            // ragged last tile: mask the keys past Nk
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      s[t2] = tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + t2 * 32 + acc_row(r, hi);
-        const float x = key < Nk ? s[t2][r] * (SCALE * LOG2E) : -INFINITY;
-        s[t2][r] = x;
-        mx = fmaxf(mx, x);
-      }
+        for (int r = 0; r < 16; ++r)
+          if (k0 + t2 * 32 + acc_row(r, hi) >= Nk) s[t2][r] = -INFINITY;
     }
+    float mx = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = fast_exp2((m_run - m_new) * CEXP);
+    const float mc = m_new * CEXP;
     float rs = 0.f;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[t2][r] - m_new);
+        const float p = fast_exp2(__builtin_fmaf(s[t2][r], CEXP, -mc));
         s[t2][r] = p;
         rs += p;
       }
@@ -190,12 +208,12 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const T* q, long ldq, const T*
         const uint4 pf = pack8<T>(s[t2], st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          oacc[dt] = Mma<T>::run(tr_frag(sVt, dt * 32 + ln, t2 * 32, st, hi), pf, oacc[dt]);
+          oacc[dt] = Mma<T>::run(tr_frag(vt, dt * 32, t2 * 32 + 16 * st), pf, oacc[dt]);
       }
   }
   if (qok) {
     store_rows_t<T>(o + (long)b * Nq * ldo, ldo, qrow, h * HD, hi, oacc, 1.f / l_run);
-    if (lse && hi == 0) lse[((long)b * H + h) * Nq + qrow] = (m_run + log2f(l_run)) * LN2;
+    if (lse && hi == 0) lse[((long)b * H + h) * Nq + qrow] = (m_run * CEXP + log2f(l_run)) * LN2;
   }
 }
 
@@ -227,8 +245,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(const T* q, long ldq, const
                                                      int H, int Nq, int Nk) {
   __shared__ __attribute__((aligned(16))) unsigned short sK[TILE];
   __shared__ __attribute__((aligned(16))) unsigned short sV[TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short sKt[TILE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
   const bool qok = qrow < Nq;
@@ -238,28 +255,30 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(const T* q, long ldq, const
   const float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;
   const float del_q = qok ? delta[((long)b * H + h) * Nq + qrow] : 0.f;
   v16f dqacc[2] = {zero16(), zero16()};
-  const T* kb = k + (long)b * Nk * ldk;
-  const T* vb = v + (long)b * Nk * ldk;
+  const T* kp = k + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
+  const T* vp = v + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
+  const unsigned short* kt = sK + (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   TileRegs rk, rv;
-  fetch_tile<T>(kb, ldk, 0, Nk, h * HD, rk);
-  fetch_tile<T>(vb, ldk, 0, Nk, h * HD, rv);
+  fetch_tile<T>(kp, ldk, 0, Nk, rk);
+  fetch_tile<T>(vp, ldk, 0, Nk, rv);
   for (int k0 = 0; k0 < Nk; k0 += 64) {
     __syncthreads();
-    commit_tile(rk, sK, sKt);
-    commit_tile(rv, sV, nullptr);
+    commit_tile(rk, sK);
+    commit_tile(rv, sV);
     __syncthreads();
     if (k0 + 64 < Nk) {
-      fetch_tile<T>(kb, ldk, k0 + 64, Nk, h * HD, rk);
-      fetch_tile<T>(vb, ldk, k0 + 64, Nk, h * HD, rv);
+      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk);
+      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv);
     }
+    const bool ragged = k0 + 64 > Nk;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       v16f s = tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
       const v16f dp = tile_times_frags<T>(sV, t2 * 32, ln, hi, dof);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = k0 + t2 * 32 + acc_row(r, hi);
-        const float p = key < Nk ? exp2f(s[r] * (SCALE * LOG2E) - lse_q) : 0.f;
+        float p = fast_exp2(__builtin_fmaf(s[r], CEXP, -lse_q));
+        if (ragged && k0 + t2 * 32 + acc_row(r, hi) >= Nk) p = 0.f;
         s[r] = p * (dp[r] - del_q) * SCALE;
       }
 #pragma unroll
@@ -267,7 +286,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(const T* q, long ldq, const
         const uint4 dsf = pack8<T>(s, st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          dqacc[dt] = Mma<T>::run(tr_frag(sKt, dt * 32 + ln, t2 * 32, st, hi), dsf, dqacc[dt]);
+          dqacc[dt] = Mma<T>::run(tr_frag(kt, dt * 32, t2 * 32 + 16 * st), dsf, dqacc[dt]);
       }
     }
   }
@@ -281,10 +300,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, cons
                                                       long lddk, int H, int Nq, int Nk) {
   __shared__ __attribute__((aligned(16))) unsigned short sQ[TILE];
   __shared__ __attribute__((aligned(16))) unsigned short sdO[TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short sQt[TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short sdOt[TILE];
-  __shared__ float sLse[64], sDel[64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float sLse[64];
+  __shared__ __attribute__((aligned(16))) float sDel[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const long krow = (long)blockIdx.x * 128 + wave * 32 + ln;
   const bool kok = krow < Nk;
@@ -292,18 +310,21 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, cons
   load_row_frags<T>(k + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, kf);
   load_row_frags<T>(v + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, vf);
   v16f dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
-  const T* qb = q + (long)b * Nq * ldq;
-  const T* dob = d_o + (long)b * Nq * lddo;
+  const T* qp = q + (long)b * Nq * ldq + h * HD + (threadIdx.x & 7) * 8;
+  const T* dop = d_o + (long)b * Nq * lddo + h * HD + (threadIdx.x & 7) * 8;
+  const int toff = (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
+  const unsigned short* qt = sQ + toff;
+  const unsigned short* dot = sdO + toff;
   TileRegs rq, rdo;
-  fetch_tile<T>(qb, ldq, 0, Nq, h * HD, rq);
-  fetch_tile<T>(dob, lddo, 0, Nq, h * HD, rdo);
+  fetch_tile<T>(qp, ldq, 0, Nq, rq);
+  fetch_tile<T>(dop, lddo, 0, Nq, rdo);
   for (int q0 = 0; q0 < Nq; q0 += 64) {
     __syncthreads();
-    commit_tile(rq, sQ, sQt);
-    commit_tile(rdo, sdO, sdOt);
+    commit_tile(rq, sQ);
+    commit_tile(rdo, sdO);
     if (q0 + 64 < Nq) {
-      fetch_tile<T>(qb, ldq, q0 + 64, Nq, h * HD, rq);
-      fetch_tile<T>(dob, lddo, q0 + 64, Nq, h * HD, rdo);
+      fetch_tile<T>(qp, ldq, q0 + 64, Nq, rq);
+      fetch_tile<T>(dop, lddo, q0 + 64, Nq, rdo);
     }
     if (threadIdx.x < 64) {
       const long qr = q0 + threadIdx.x;
@@ -317,19 +338,25 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, cons
       const v16f dp = tile_times_frags<T>(sdO, t2 * 32, ln, hi, vf);
       v16f ds;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = t2 * 32 + acc_row(r, hi);
-        const float p = exp2f(s[r] * (SCALE * LOG2E) - sLse[ql]);
-        s[r] = p;
-        ds[r] = p * (dp[r] - sDel[ql]) * SCALE;
+      for (int g = 0; g < 4; ++g) {
+        const float4 l4 = *reinterpret_cast<const float4*>(&sLse[t2 * 32 + 8 * g + 4 * hi]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&sDel[t2 * 32 + 8 * g + 4 * hi]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          const float p = fast_exp2(__builtin_fmaf(s[r], CEXP, -lv[i]));
+          s[r] = p;
+          ds[r] = p * (dp[r] - dv4[i]) * SCALE;
+        }
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
         const uint4 pf = pack8<T>(s, st), dsf = pack8<T>(ds, st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dvacc[dt] = Mma<T>::run(tr_frag(sdOt, dt * 32 + ln, t2 * 32, st, hi), pf, dvacc[dt]);
-          dkacc[dt] = Mma<T>::run(tr_frag(sQt, dt * 32 + ln, t2 * 32, st, hi), dsf, dkacc[dt]);
+          dvacc[dt] = Mma<T>::run(tr_frag(dot, dt * 32, t2 * 32 + 16 * st), pf, dvacc[dt]);
+          dkacc[dt] = Mma<T>::run(tr_frag(qt, dt * 32, t2 * 32 + 16 * st), dsf, dkacc[dt]);
         }
       }
     }
