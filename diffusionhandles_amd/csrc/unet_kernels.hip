@@ -103,48 +103,79 @@ __device__ __forceinline__ float silu_grad(float z) {
 }
 
 // GroupNorm statistics in two deterministic stages:
-//   k_gn_partial  grid (B*G, S): block s reduces its slice of rows to (n, mean, M2)   [two-pass, f32]
-//   the apply kernels combine the S slices of their batch item in LDS (Chan's parallel variance
-//   formula, fixed order) before normalising; block x == 0 also publishes (mean, rstd) for backward.
-constexpr int GN_MAXS = 32;
-__host__ __device__ inline int gn_slices(int HW) { int s = HW / 128; return s < 1 ? 1 : (s > GN_MAXS ? GN_MAXS : s); }
+//   k_gn_partial  grid (S, B): one workgroup per row slice reads whole rows (coalesced 16-byte chunks) and
+//                 leaves (n, mean, M2) per group and slice   [f32, shifted by the slice's first row]
+//   the apply kernel combines the S slices of its batch item (8 lanes per group, fixed-order butterfly,
+//   Chan's formula) before normalising; block x == 0 also publishes (mean, rstd) for backward.
+// partial layout: [b][g][3][S]  (n | mean | M2 planes, slices contiguous)
+constexpr int GN_MAXS = 128;
+__host__ __device__ inline int gn_slices(int HW) { int s = HW / 32; return s < 1 ? 1 : (s > GN_MAXS ? GN_MAXS : s); }
+__host__ __device__ inline int gn_bwd_slices(int HW) { int s = HW / 128; return s < 1 ? 1 : (s > 32 ? 32 : s); }
 
 template <class T>
 __global__ void __launch_bounds__(256) k_gn_partial(const T* x, float* part, int HW, int C, int G, int S) {
-  __shared__ float sm[4];
-  const int bg = blockIdx.x, s = blockIdx.y, b = bg / G, g = bg - b * G, cpg = C / G;
+  extern __shared__ float sm_c[];            // [C] pivot, [RP][C] sum, [RP][C] sumsq
+  const int b = blockIdx.y, s = blockIdx.x, cpg = C / G, cch = C / 8;
+  const int TPR = cch < (int)blockDim.x ? cch : (int)blockDim.x;     // threads walking one row set
+  const int RP = (int)blockDim.x / TPR;                               // row sets in parallel
+  float* piv = sm_c;
+  float* csum = sm_c + C;
+  float* csq = csum + (size_t)RP * C;
   const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
-  const T* xb = x + ((size_t)b * HW + r0) * C + g * cpg;
-  const int n = (r1 - r0) * cpg;
-  float a = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int p = i / cpg, c = i - p * cpg;
-    a += to_f32<T>(xb[(size_t)p * C + c]);
+  const T* xb = x + (size_t)b * HW * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) piv[c] = to_f32<T>(xb[(size_t)r0 * C + c]);
+  __syncthreads();
+  const int rr = threadIdx.x / TPR, lane = threadIdx.x - rr * TPR;
+  if (rr < RP) {
+    for (int ch = lane; ch < cch; ch += TPR) {
+      float a[8], q[8], pv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a[i] = 0.f; q[i] = 0.f; pv[i] = piv[ch * 8 + i]; }
+      for (int r = r0 + rr; r < r1; r += RP) {
+        uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + ch * 8);
+        const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = to_f32<T>(v[i]) - pv[i]; a[i] += d; q[i] += d * d; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { csum[(size_t)rr * C + ch * 8 + i] = a[i]; csq[(size_t)rr * C + ch * 8 + i] = q[i]; }
+    }
   }
-  const float mean = block_sum(a, sm) / (float)n;
-  float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int p = i / cpg, c = i - p * cpg;
-    const float d = to_f32<T>(xb[(size_t)p * C + c]) - mean;
-    v += d * d;
-  }
-  const float m2 = block_sum(v, sm);
-  if (threadIdx.x == 0) {
-    float* o = part + ((size_t)bg * S + s) * 3;
-    o[0] = (float)n; o[1] = mean; o[2] = m2;
+  __syncthreads();
+  const float nrow = (float)(r1 - r0);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      float sc = 0.f, sq = 0.f;
+      for (int k2 = 0; k2 < RP; ++k2) { sc += csum[(size_t)k2 * C + c]; sq += csq[(size_t)k2 * C + c]; }
+      const float mc = piv[c] + sc / nrow;
+      const float m2c = sq - sc * sc / nrow;
+      const float nn = n + nrow, d = mc - mean;
+      mean += d * nrow / nn;
+      m2 += m2c + d * d * n * nrow / nn;
+      n = nn;
+    }
+    float* o = part + ((size_t)(b * G + g) * 3) * S + s;
+    o[0] = n; o[S] = mean; o[2 * S] = m2;
   }
 }
 
 // combine the S slices of every group of batch item b into sm_stats[g] = (mean, rstd)
 __device__ __forceinline__ void gn_combine(const float* part, int b, int G, int S, float eps, float2* sm_stats,
                                            float* stats_out) {
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    const float* p = part + ((size_t)(b * G + g) * S) * 3;
-    float n = 0.f, mean = 0.f;
-    for (int s = 0; s < S; ++s) { n += p[3 * s]; mean += p[3 * s] * p[3 * s + 1]; }
-    mean /= n;
-    float m2 = 0.f;
-    for (int s = 0; s < S; ++s) { const float d = p[3 * s + 1] - mean; m2 += p[3 * s + 2] + p[3 * s] * d * d; }
+  const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  const bool act = g < G;
+  const float* p = part + ((size_t)(b * G + (act ? g : 0)) * 3) * S;
+  float n = 0.f, sm = 0.f;
+  if (act) for (int s = sub; s < S; s += 8) { n += p[s]; sm += p[s] * p[S + s]; }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) { n += __shfl_xor(n, o, 64); sm += __shfl_xor(sm, o, 64); }
+  const float mean = sm / n;
+  float m2 = 0.f;
+  if (act) for (int s = sub; s < S; s += 8) { const float d = p[S + s] - mean; m2 += p[2 * S + s] + p[s] * d * d; }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+  if (act && sub == 0) {
     const float rstd = rsqrtf(m2 / n + eps);
     sm_stats[g] = make_float2(mean, rstd);
     if (stats_out) { stats_out[2 * (b * G + g)] = mean; stats_out[2 * (b * G + g) + 1] = rstd; }
@@ -181,12 +212,14 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st) {
   const int S = gn_slices(HW);
-  dim3 g1(B * G, S), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
+  dim3 g1(S, B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
+  const int tpr = (C / 8) < 256 ? (C / 8) : 256;
+  const size_t lds = (size_t)(1 + 2 * (256 / tpr)) * C * sizeof(float);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_partial<f16>), g1, dim3(256), 0, st, (const f16*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL((k_gn_partial<f16>), g1, dim3(256), lds, st, (const f16*)x, scratch, HW, C, G, S);
     hipLaunchKernelGGL((k_gn_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu);
   } else {
-    hipLaunchKernelGGL((k_gn_partial<bf16>), g1, dim3(256), 0, st, (const bf16*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL((k_gn_partial<bf16>), g1, dim3(256), lds, st, (const bf16*)x, scratch, HW, C, G, S);
     hipLaunchKernelGGL((k_gn_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu);
   }
 }
@@ -267,7 +300,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st) {
-  const int S = gn_slices(HW);
+  const int S = gn_bwd_slices(HW);
   dim3 g1(B * G, S), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
   if (dtype == DH_DTYPE_F16) {
     hipLaunchKernelGGL((k_gn_bwd_partial<f16>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
