@@ -103,60 +103,99 @@ __device__ __forceinline__ float silu_grad(float z) {
 }
 
 // GroupNorm statistics in two deterministic stages:
-//   k_gn_partial  grid (S, B): one workgroup per row slice reads whole rows (coalesced 16-byte chunks) and
-//                 leaves (n, mean, M2) per group and slice   [f32, shifted by the slice's first row]
-//   the apply kernel combines the S slices of its batch item (8 lanes per group, fixed-order butterfly,
-//   Chan's formula) before normalising; block x == 0 also publishes (mean, rstd) for backward.
-// partial layout: [b][g][3][S]  (n | mean | M2 planes, slices contiguous)
-constexpr int GN_MAXS = 128;
-__host__ __device__ inline int gn_slices(int HW) { int s = HW / 32; return s < 1 ? 1 : (s > GN_MAXS ? GN_MAXS : s); }
-__host__ __device__ inline int gn_bwd_slices(int HW) { int s = HW / 128; return s < 1 ? 1 : (s > 32 ? 32 : s); }
+//   k_gn_partial  grid (S, G/4, B): a workgroup owns one row slice x 4 adjacent groups, reads the 4*cpg
+//                 channel window of every row with 16-byte chunks and leaves (n, mean, M2) per group
+//                 [f32, shifted by the slice's first row; fixed-order folds, no atomics]
+//   the apply kernel combines the S <= 16 slices (8 lanes per group, butterfly, Chan's formula) before
+//   normalising; block x == 0 also publishes (mean, rstd) for backward.
+// partial layout: [b][g][3][S]  (n | mean | M2 planes)
+constexpr int GN_GB = 4;       // groups per partial workgroup
+__host__ __device__ inline int gn_slices(int HW) { int s = HW / 4; return s < 1 ? 1 : (s > 16 ? 16 : s); }
 
-template <class T>
-__global__ void __launch_bounds__(256) k_gn_partial(const T* x, float* part, int HW, int C, int G, int S) {
-  extern __shared__ float sm_c[];            // [C] pivot, [RP][C] sum, [RP][C] sumsq
-  const int b = blockIdx.y, s = blockIdx.x, cpg = C / G, cch = C / 8;
-  const int TPR = cch < (int)blockDim.x ? cch : (int)blockDim.x;     // threads walking one row set
-  const int RP = (int)blockDim.x / TPR;                               // row sets in parallel
+template <class T, bool BWD>
+__global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, const float* gamma, const float* beta,
+                                                    const float* stats, float* part, int HW, int C, int G, int S, int silu) {
+  extern __shared__ float sm_c[];            // [W] pivot, [RP][W] a, [RP][W] q     (W = GN_GB * cpg channels)
+  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = C / G;
+  const int W = GN_GB * cpg, nch = W / 8;
+  const int RP = (int)blockDim.x / nch;
   float* piv = sm_c;
-  float* csum = sm_c + C;
-  float* csq = csum + (size_t)RP * C;
+  float* ca = sm_c + W;
+  float* cq = ca + (size_t)RP * W;
   const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
-  const T* xb = x + (size_t)b * HW * C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) piv[c] = to_f32<T>(xb[(size_t)r0 * C + c]);
-  __syncthreads();
-  const int rr = threadIdx.x / TPR, lane = threadIdx.x - rr * TPR;
+  const size_t base = (size_t)b * HW * C + (size_t)g0 * cpg;
+  if (!BWD) {
+    for (int c = threadIdx.x; c < W; c += blockDim.x) piv[c] = to_f32<T>(x[base + (size_t)r0 * C + c]);
+    __syncthreads();
+  }
+  const int rr = threadIdx.x / nch, ch = threadIdx.x - rr * nch;
   if (rr < RP) {
-    for (int ch = lane; ch < cch; ch += TPR) {
-      float a[8], q[8], pv[8];
+    float a[8], q[8], pv[8], gm[8], bt[8], mu[8], rs[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { a[i] = 0.f; q[i] = 0.f; pv[i] = piv[ch * 8 + i]; }
-      for (int r = r0 + rr; r < r1; r += RP) {
-        uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + ch * 8);
-        const T* v = reinterpret_cast<const T*>(&raw);
+    for (int i = 0; i < 8; ++i) { a[i] = 0.f; q[i] = 0.f; pv[i] = BWD ? 0.f : piv[ch * 8 + i]; }
+    if (BWD) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {        // a chunk may straddle two groups: per-element statistics
+        const int sg = b * G + g0 + (ch * 8 + i) / cpg;
+        gm[i] = gamma[g0 * cpg + ch * 8 + i]; bt[i] = beta[g0 * cpg + ch * 8 + i];
+        mu[i] = stats[2 * sg]; rs[i] = stats[2 * sg + 1];
+      }
+    }
+    for (int r = r0 + rr; r < r1; r += RP) {
+      uint4 raw = *reinterpret_cast<const uint4*>(x + base + (size_t)r * C + ch * 8);
+      const T* v = reinterpret_cast<const T*>(&raw);
+      if (!BWD) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float d = to_f32<T>(v[i]) - pv[i]; a[i] += d; q[i] += d * d; }
-      }
+      } else {
+        uint4 rawd = *reinterpret_cast<const uint4*>(dy + base + (size_t)r * C + ch * 8);
+        const T* dv = reinterpret_cast<const T*>(&rawd);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { csum[(size_t)rr * C + ch * 8 + i] = a[i]; csq[(size_t)rr * C + ch * 8 + i] = q[i]; }
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (to_f32<T>(v[i]) - mu[i]) * rs[i];
+          float d = to_f32<T>(dv[i]);
+          if (silu) d *= silu_grad(xh * gm[i] + bt[i]);
+          d *= gm[i];
+          a[i] += d;
+          q[i] += d * xh;
+        }
+      }
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ca[(size_t)rr * W + ch * 8 + i] = a[i]; cq[(size_t)rr * W + ch * 8 + i] = q[i]; }
   }
   __syncthreads();
   const float nrow = (float)(r1 - r0);
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+  {   // fold the row sets per channel (one thread per channel, fixed order), result left in row set 0
+    const int rp_used = (r1 - r0) < RP ? (r1 - r0) : RP;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
       float sc = 0.f, sq = 0.f;
-      for (int k2 = 0; k2 < RP; ++k2) { sc += csum[(size_t)k2 * C + c]; sq += csq[(size_t)k2 * C + c]; }
-      const float mc = piv[c] + sc / nrow;
-      const float m2c = sq - sc * sc / nrow;
-      const float nn = n + nrow, d = mc - mean;
-      mean += d * nrow / nn;
-      m2 += m2c + d * d * n * nrow / nn;
-      n = nn;
+      for (int k2 = 0; k2 < rp_used; ++k2) { sc += ca[(size_t)k2 * W + c]; sq += cq[(size_t)k2 * W + c]; }
+      ca[c] = sc; cq[c] = sq;
     }
-    float* o = part + ((size_t)(b * G + g) * 3) * S + s;
-    o[0] = n; o[S] = mean; o[2 * S] = m2;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < GN_GB && g0 + (int)threadIdx.x < G) {
+    const int gl = threadIdx.x, g = g0 + gl;
+    if (!BWD) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) {
+        const float sc = ca[c], sq = cq[c];
+        const float mc = piv[c] + sc / nrow;
+        const float m2c = sq - sc * sc / nrow;
+        const float nn = n + nrow, d = mc - mean;
+        mean += d * nrow / nn;
+        m2 += m2c + d * d * n * nrow / nn;
+        n = nn;
+      }
+      float* o = part + ((size_t)(b * G + g) * 3) * S + s;
+      o[0] = n; o[S] = mean; o[2 * S] = m2;
+    } else {
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) { s1 += ca[c]; s2 += cq[c]; }
+      part[((size_t)(b * G + g) * S + s) * 2] = s1;
+      part[((size_t)(b * G + g) * S + s) * 2 + 1] = s2;
+    }
   }
 }
 
@@ -211,47 +250,15 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
 
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st) {
-  const int S = gn_slices(HW);
-  dim3 g1(S, B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
-  const int tpr = (C / 8) < 256 ? (C / 8) : 256;
-  const size_t lds = (size_t)(1 + 2 * (256 / tpr)) * C * sizeof(float);
+  const int S = gn_slices(HW), cpg = C / G, W = GN_GB * cpg, RP = 256 / (W / 8);
+  dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
+  const size_t lds = (size_t)(1 + 2 * RP) * W * sizeof(float);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_partial<f16>), g1, dim3(256), lds, st, (const f16*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL((k_gn_partial<f16, false>), g1, dim3(256), lds, st, (const f16*)x, (const f16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu);
   } else {
-    hipLaunchKernelGGL((k_gn_partial<bf16>), g1, dim3(256), lds, st, (const bf16*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL((k_gn_partial<bf16, false>), g1, dim3(256), lds, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu);
-  }
-}
-
-// backward partial sums per (batch, group, slice): (sum dxhat, sum dxhat * xhat)
-template <class T>
-__global__ void __launch_bounds__(256) k_gn_bwd_partial(const T* x, const T* dy, const float* gamma, const float* beta,
-                                                        const float* stats, float* part, int HW, int C, int G, int S,
-                                                        int silu) {
-  __shared__ float sm[4];
-  const int bg = blockIdx.x, s = blockIdx.y, b = bg / G, g = bg - b * G, cpg = C / G;
-  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
-  const size_t base = ((size_t)b * HW + r0) * C + g * cpg;
-  const float mean = stats[2 * bg], rstd = stats[2 * bg + 1];
-  const int n = (r1 - r0) * cpg;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int p = i / cpg, c = i - p * cpg;
-    const size_t o = base + (size_t)p * C + c;
-    const float xh = (to_f32<T>(x[o]) - mean) * rstd;
-    const float gm = gamma[g * cpg + c];
-    float d = to_f32<T>(dy[o]);
-    if (silu) d *= silu_grad(xh * gm + beta[g * cpg + c]);
-    d *= gm;
-    s1 += d;
-    s2 += d * xh;
-  }
-  s1 = block_sum(s1, sm);
-  s2 = block_sum(s2, sm);
-  if (threadIdx.x == 0) {
-    part[((size_t)bg * S + s) * 2] = s1;
-    part[((size_t)bg * S + s) * 2 + 1] = s2;
   }
 }
 
@@ -300,13 +307,14 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st) {
-  const int S = gn_bwd_slices(HW);
-  dim3 g1(B * G, S), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
+  const int S = gn_slices(HW), cpg = C / G, W = GN_GB * cpg, RP = 256 / (W / 8);
+  dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
+  const size_t lds = (size_t)(1 + 2 * RP) * W * sizeof(float);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_bwd_partial<f16>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_partial<f16, true>), g1, dim3(256), lds, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_bwd_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate);
   } else {
-    hipLaunchKernelGGL((k_gn_bwd_partial<bf16>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), lds, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate);
   }
 }
