@@ -359,12 +359,15 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
     else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1>), grid, dim3(256), 0, st, k); \
     else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC>), grid, dim3(256), 0, st, k);                    \
   } while (0)
+  static const int kSt = getenv("DH_GEMM_ST") ? atoi(getenv("DH_GEMM_ST")) : 4;
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
   if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 3 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 1>), grid, dim3(256), 0, st, k); }
   else
   if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
+  else if (BN == 128 && kSt == 2) DH_LAUNCH_GEMM(128, 128, 2);
+  else if (BN == 128 && kSt == 3) DH_LAUNCH_GEMM(128, 128, 3);
   else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
   else DH_LAUNCH_GEMM(128, 64, 5);
 #undef DH_LAUNCH_GEMM
