@@ -150,9 +150,17 @@ def main():
             ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
             _lib.check(L.dh_gemm_profile_end(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # HBM traffic per k_gemm launch: PMC counters cannot be read from inside the process, so this is the
+        # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, gfx950 x2 fetch
+        # correction) of the same U-Net fwd+bwd launch mix; null when the workload differs from the measured one.
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_traffic.json")
+        if os.path.exists(pmc) and args.res == 512 and args.dtype == "fp16":
+            with open(pmc) as fh:
+                traffic = round(json.load(fh)["traffic_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": "k_gemm (MFMA implicit GEMM: conv3x3 + linear, fwd + input-gradient)",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_step": int(n.value // max(1, args.profile_steps)),
+                "traffic": traffic, "traffic_unit": "bytes/launch (offline PMC)", "launches_per_step": int(n.value // max(1, args.profile_steps)),
                 "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
                 "flops_per_launch": round(fl.value / max(1, n.value) / 1e9, 3),
                 "step_tflop_algorithmic": STEP_TFLOP,
