@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <map>
+#include <numeric>
 #include <vector>
 
 #include "unet_kernels.h"
@@ -85,6 +86,8 @@ struct dh_unet {
   float *pf = nullptr, *f32a = nullptr, *partial = nullptr, *small = nullptr;
   // well-known tensors
   int t_text = -1, t_kv = -1, t_conv_in_out = -1, t_final = -1, act_ids[3] = {-1, -1, -1};
+  int act_op_end[3] = {0, 0, 0};   // ops [0, act_op_end[i]) produce captured activation i
+  int saved_ops = 0;                // number of tape ops the saved forward executed
   long temb_f32_off = -1;
   int temb_total = 0, kv_total = 0;
   // staging buffers (fixed addresses so a captured graph can be replayed) and graph cache
@@ -100,7 +103,13 @@ struct dh_unet {
   int64_t launches = 0;
 
   unsigned short* aptr(int t, int B_unused = 0) { return act + tens[t].off; }
-  unsigned short* gptr(int t) { return grad + tens[t].goff; }
+  // gradient buffer of tensor t; a residual input whose gradient is (so far) exactly its consumer's output
+  // gradient shares that buffer instead of receiving a copy (galias, reset per backward)
+  std::vector<int> galias;
+  unsigned short* gptr(int t) {
+    while (galias[t] != t) t = galias[t];
+    return grad + tens[t].goff;
+  }
 };
 
 namespace {
@@ -377,7 +386,10 @@ int build(dh_unet& u) {
       x = b.conv3(x, pre + ".upsamplers.0.conv", co, H, 1, 1, -1, -1);
       H *= 2;
     }
-    if (attn && n_act < 3) u.act_ids[n_act++] = x;
+    if (attn && n_act < 3) {
+      u.act_op_end[n_act] = (int)u.ops.size();
+      u.act_ids[n_act++] = x;
+    }
   }
   x = b.gn(x, "conv_norm_out", 1e-5f, true);
   u.t_final = x;
@@ -473,6 +485,8 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
   (void)hipMemset(u->w16, 0, u->w16_elems * 2);
   (void)hipMemset(u->pf, 0, u->pf_elems * 4);
   u->gready.assign(u->tens.size(), 0);
+  u->galias.resize(u->tens.size());
+  std::iota(u->galias.begin(), u->galias.end(), 0);
   *out = u;
   return DH_OK;
 }
@@ -555,12 +569,13 @@ static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
   g.partial = u->partial; g.partial_elems = u->partial_elems;
 }
 
-static void forward_ops(dh_unet* u, int B, hipStream_t st) {
+static void forward_ops(dh_unet* u, int B, int n_ops, hipStream_t st) {
   const int dt = u->dtype;
   const dh_unet_config& c = u->cfg;
   u->flops_fwd = 0;
   launch_f32_to_t(dt, u->in_text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
-  for (const Op& o : u->ops) {
+  for (int oi = 0; oi < n_ops; ++oi) {
+    const Op& o = u->ops[oi];
     switch (o.type) {
       case OP_TIMESTEP:
         launch_timestep_embedding(dt, u->t_dev, c.block_out_channels[0], B, u->aptr(o.out), st);
@@ -656,7 +671,7 @@ static int run_graphed(dh_unet* u, unsigned key, hipStream_t st, double* flops_s
 
 extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, const float* text, int batch,
                                int save_for_backward, float* eps_out, void* const* act_out, void* stream) {
-  DH_REQUIRE(u && sample && text && eps_out, "null pointer");
+  DH_REQUIRE(u && sample && text, "null pointer");
   DH_REQUIRE(batch >= 1 && batch <= u->cfg.max_batch, "batch exceeds max_batch");
   hipStream_t st = (hipStream_t)stream;
   const int B = batch;
@@ -665,18 +680,28 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   DH_CHECK_HIP(hipMemcpyAsync(u->in_sample, sample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
   DH_CHECK_HIP(hipMemcpyAsync(u->in_text, text, (size_t)B * c.text_len * c.cross_attention_dim * 4, hipMemcpyDeviceToDevice, st));
   launch_set_scalar(u->t_dev, timestep, st);
-  int rc = run_graphed(u, (unsigned)B, st, &u->flops_fwd, [&]() { forward_ops(u, B, st); });
+  // without eps_out the tape stops after the last requested activation (the tail's only consumer is eps)
+  int n_ops = (int)u->ops.size();
+  if (!eps_out) {
+    n_ops = 0;
+    for (int i = 0; i < 3; ++i)
+      if (act_out && act_out[i]) n_ops = std::max(n_ops, u->act_op_end[i]);
+    DH_REQUIRE(n_ops > 0, "nothing requested: eps_out and every act_out are null");
+  }
+  int rc = run_graphed(u, 0x80000000u | (unsigned)B | ((unsigned)n_ops << 8), st, &u->flops_fwd, [&]() { forward_ops(u, B, n_ops, st); });
   if (rc != DH_OK) return rc;
-  DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
+  if (eps_out) DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
   if (act_out) {
     for (int i = 0; i < 3; ++i)
       if (act_out[i]) {
+        DH_REQUIRE(u->act_op_end[i] <= n_ops, "activation requested beyond the truncated tape");
         const Ten& t = u->tens[u->act_ids[i]];
         DH_CHECK_HIP(hipMemcpyAsync(act_out[i], u->aptr(u->act_ids[i]), (size_t)B * t.rows * t.C * 2,
                                     hipMemcpyDeviceToDevice, st));
       }
   }
   u->saved_batch = save_for_backward ? B : 0;
+  u->saved_ops = n_ops;
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
@@ -734,7 +759,8 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
         const Ten& ti = u->tens[o.in0];
         const Wt& w = u->wts[o.wt];
         if (o.res >= 0 && u->tens[o.res].req_grad) {
-          bw.add_into(o.res, u->gptr(o.out), to.C, to.C);
+          if (u->gready[o.res]) bw.add_into(o.res, u->gptr(o.out), to.C, to.C);
+          else u->galias[o.res] = o.out;      // first contribution: share dOut (nobody reads it after this op)
           u->gready[o.res] = 1;
         }
         if (!ti.req_grad || !w.has_bwd) break;
@@ -857,9 +883,12 @@ extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_e
   const size_t ns = (size_t)B * c.sample_size * c.sample_size;
   const size_t nt = (size_t)B * c.text_len * c.cross_attention_dim;
   unsigned mask = 0;
+  std::iota(u->galias.begin(), u->galias.end(), 0);
+  DH_REQUIRE(!d_eps || u->saved_ops == (int)u->ops.size(), "d_eps given but the saved forward did not compute eps");
   if (d_act)
     for (int i = 0; i < 3; ++i)
       if (d_act[i]) {
+        DH_REQUIRE(u->act_op_end[i] <= u->saved_ops, "d_act given for an activation the saved forward did not compute");
         const Ten& t = u->tens[u->act_ids[i]];
         DH_CHECK_HIP(hipMemcpyAsync(u->gptr(u->act_ids[i]), d_act[i], (size_t)B * t.rows * t.C * 2,
                                     hipMemcpyDeviceToDevice, st));

@@ -291,7 +291,8 @@ class GuidedStableDiffuser(GuidedDiffuser):
             fgw, bgw = st.schedule(t_idx, iteration)
             active = [k for k in range(3) if (fgw[k] != 0.0 and st.n_pairs > 0) or bgw[k] != 0.0]
             if active:
-                _, acts = self.unet.forward(self._unet_input(x, st.depth_nhwc), float(t), st.cond, save_for_backward=True)
+                _, acts = self.unet.forward(self._unet_input(x, st.depth_nhwc), float(t), st.cond, save_for_backward=True,
+                                            want_acts=active, want_eps=False)
                 d_acts = [None, None, None]
                 for k in active:
                     _, g = energy_and_grad(acts[k][0], st.orig[k][t_idx], st.pc, fgw[k], bgw[k], self.conf.fg_patch_size,
@@ -323,7 +324,8 @@ class GuidedStableDiffuser(GuidedDiffuser):
             active = [k for k in range(3) if fgw[k] != 0.0 or bgw[k] != 0.0]
             if active:
                 sample = torch.cat([x, depth], dim=-1).contiguous() if self.conf.use_depth else x
-                _, acts = self.unet.forward(sample, float(t), cond, save_for_backward=True)
+                _, acts = self.unet.forward(sample, float(t), cond, save_for_backward=True, want_acts=active,
+                                            want_eps=False)
                 d_acts = [None, None, None]
                 for k in active:
                     g_all = torch.empty_like(acts[k])

@@ -101,3 +101,30 @@ def test_engine_sd2_depth_full_size_fp16():
     from oracle import unet_torch as U
     names = None
     run_case(U.SD2_DEPTH, torch.float16, 1, 500.0, 2e-2, 6e-2)
+
+
+def test_engine_truncated_forward_matches_full():
+    """want_eps=False stops the tape after the last requested activation: that activation and the
+    gradient from it must be bit-identical to the full pass (same kernels, same order)."""
+    from oracle import unet_torch as U
+    cfg = U.TINY
+    _, hip = build(cfg, torch.float16, 2)
+    g = torch.Generator(device=dev()).manual_seed(5)
+    S, D = cfg["sample_size"], cfg["cross_attention_dim"]
+    x = torch.randn(2, S, S, cfg["in_channels"], generator=g, device=dev())
+    text = torch.randn(2, 77, D, generator=g, device=dev())
+    side = torch.cuda.Stream()
+    for stream in (torch.cuda.current_stream(), side):          # eager (null stream) and hipGraph replay
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                eps, full = hip.forward(x, 321.0, text, save_for_backward=True)
+                d1 = (torch.randn(full[1].shape, generator=g, device=dev()) * 1e-2).to(torch.float16)
+                ds_full, _ = hip.backward([None, d1, None], None)
+                none_eps, part = hip.forward(x, 321.0, text, save_for_backward=True, want_acts=[1], want_eps=False)
+                assert none_eps is None and part[0] is None and part[2] is None
+                assert torch.equal(part[1], full[1])
+                ds_part, _ = hip.backward([None, d1, None], None)
+                assert torch.equal(ds_part, ds_full)
+                with pytest.raises(RuntimeError):
+                    hip.backward([None, None, d1.new_zeros(full[2].shape)], None)
+        torch.cuda.synchronize()
