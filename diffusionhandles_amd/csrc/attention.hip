@@ -63,16 +63,16 @@ __device__ __forceinline__ void load_row_frags(const T* base, long ld, long row,
 struct TileRegs { uint4 v[2]; };
 template <class T>
 __device__ __forceinline__ void fetch_tile(const T* tile_ptr /* base + col0 + chunk*8, per thread */, long ld, long row0,
-                                           long rows_total, TileRegs& t) {
-  const int r0 = threadIdx.x >> 3;
+                                           long rows_total, TileRegs& t, int tid = threadIdx.x) {
+  const int r0 = tid >> 3;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const long r = row0 + r0 + 32 * j;
     t.v[j] = (r < rows_total) ? *reinterpret_cast<const uint4*>(tile_ptr + r * ld) : make_uint4(0, 0, 0, 0);
   }
 }
-__device__ __forceinline__ void commit_tile(const TileRegs& t, unsigned short* rm) {
-  const int r0 = threadIdx.x >> 3, chunk = threadIdx.x & 7;
+__device__ __forceinline__ void commit_tile(const TileRegs& t, unsigned short* rm, int tid = threadIdx.x) {
+  const int r0 = tid >> 3, chunk = tid & 7;
 #pragma unroll
   for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(&rm[(r0 + 32 * j) * TLD + chunk * 8]) = t.v[j];
 }
@@ -138,33 +138,48 @@ __device__ __forceinline__ void store_rows_t(T* base, long ld, long row, int col
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // ------------------------------------------------------------------------------- forward
-template <class T>
-__global__ void __launch_bounds__(256) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
-                                                  float* lse, int H, int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) unsigned short sK[TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short sV[TILE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
+// One block = 128 queries x KS key ranges: wave group ks (4 waves, own K/V tiles) runs the online softmax over
+// keys [ks, ks+1) * ceil(tiles / KS) and the groups' (m, l, O) are merged through LDS at the end.  A single
+// image has only Nq/128 * H query tiles (160 at 64x64 latents, 5 heads): splitting the keys inside the block
+// puts KS waves on every SIMD instead of one, so one wave's softmax VALU work hides under another's MFMAs.
+template <class T, int KS>
+__global__ void __launch_bounds__(256 * KS) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
+                                                       float* lse, int H, int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[KS * 2 * TILE];
+  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
+  unsigned short* sK = smem + ks * 2 * TILE;
+  unsigned short* sV = sK + TILE;
   const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
   const bool qok = qrow < Nq;
   uint4 qf[4];
   load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
   v16f oacc[2] = {zero16(), zero16()};
   float m_run = -INFINITY, l_run = 0.f;
-  const T* kp = k + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
-  const T* vp = v + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
+  const T* kp = k + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
+  const T* vp = v + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
   const unsigned short* vt = sV + (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
+  const int tiles = (Nk + 63) >> 6, tps = (tiles + KS - 1) / KS;
+  const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
   TileRegs rk, rv;
-  fetch_tile<T>(kp, ldk, 0, Nk, rk);
-  fetch_tile<T>(vp, ldk, 0, Nk, rv);
-  for (int k0 = 0; k0 < Nk; k0 += 64) {
+  if (t_begin < t_end) {
+    fetch_tile<T>(kp, ldk, t_begin * 64, Nk, rk, tid);
+    fetch_tile<T>(vp, ldk, t_begin * 64, Nk, rv, tid);
+  }
+  for (int it = 0; it < tps; ++it) {
+    const int k0 = (t_begin + it) * 64;
+    const bool act = t_begin + it < t_end;        // uniform per wave group; barriers are block-wide
     __syncthreads();
-    commit_tile(rk, sK);
-    commit_tile(rv, sV);
+    if (act) {
+      commit_tile(rk, sK, tid);
+      commit_tile(rv, sV, tid);
+    }
     __syncthreads();
-    if (k0 + 64 < Nk) {            // next tile's loads fly under this tile's MFMAs
-      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk);
-      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv);
+    if (!act) continue;
+    if (t_begin + it + 1 < t_end) {            // next tile's loads fly under this tile's MFMAs
+      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk, tid);
+      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv, tid);
     }
     v16f s[2];
     s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
@@ -211,6 +226,38 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const T* q, long ldq, const T*
           oacc[dt] = Mma<T>::run(tr_frag(vt, dt * 32, t2 * 32 + 16 * st), pf, oacc[dt]);
       }
   }
+  if (KS > 1) {
+    // pairwise merge of the key ranges: group ks + step hands (O, m, l) to group ks through LDS (f32,
+    // [34 values][64 lanes] per wave: conflict-free), halving the number of live groups per round
+    float* cb = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int step = KS / 2; step >= 1; step >>= 1) {
+      __syncthreads();
+      if (ks >= step && ks < 2 * step) {
+        float* slot = cb + ((ks - step) * 4 + wave) * (34 * 64) + lane;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[(dt * 16 + r) * 64] = oacc[dt][r];
+        slot[32 * 64] = m_run;
+        slot[33 * 64] = l_run;
+      }
+      __syncthreads();
+      if (ks < step) {
+        const float* slot = cb + (ks * 4 + wave) * (34 * 64) + lane;
+        const float m2 = slot[32 * 64], l2 = slot[33 * 64];
+        const float m_new = fmaxf(m_run, m2);
+        const float a1 = fast_exp2((m_run - m_new) * CEXP), a2 = fast_exp2((m2 - m_new) * CEXP);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * a1 + slot[(dt * 16 + r) * 64] * a2;
+        l_run = l_run * a1 + l2 * a2;
+        m_run = m_new;
+      }
+    }
+    if (ks != 0) return;
+  }
   if (qok) {
     store_rows_t<T>(o + (long)b * Nq * ldo, ldo, qrow, h * HD, hi, oacc, 1.f / l_run);
     if (lse && hi == 0) lse[((long)b * H + h) * Nq + qrow] = (m_run * CEXP + log2f(l_run)) * LN2;
@@ -239,36 +286,62 @@ __global__ void k_attn_delta(const T* o, long ldo, const T* d_o, long lddo, floa
 }
 
 // ---------------------------------------------------------------------------- backward dQ
-template <class T>
-__global__ void __launch_bounds__(256) k_attn_bwd_dq(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
-                                                     long lddo, const float* lse, const float* delta, T* dq, long lddq,
-                                                     int H, int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) unsigned short sK[TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short sV[TILE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
+// Same block shape as the forward (128 queries x KS key ranges, dQ partial sums merged through LDS).
+// delta = rowsum(dO * O) is computed here from the row fragments and written for the dK/dV kernel.
+template <class T, int KS>
+__global__ void __launch_bounds__(256 * KS) k_attn_bwd_dq(const T* q, long ldq, const T* k, const T* v, long ldk, const T* o,
+                                                          long ldo, const T* d_o, long lddo, const float* lse, float* delta,
+                                                          T* dq, long lddq, int H, int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[KS * 2 * TILE];
+  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
+  unsigned short* sK = smem + ks * 2 * TILE;
+  unsigned short* sV = sK + TILE;
   const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
   const bool qok = qrow < Nq;
   uint4 qf[4], dof[4];
   load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
   load_row_frags<T>(d_o + (long)b * Nq * lddo, lddo, qrow, qok, h * HD, hi, dof);
+  float del_q = 0.f;
+  {
+    uint4 of[4];
+    load_row_frags<T>(o + (long)b * Nq * ldo, ldo, qrow, qok, h * HD, hi, of);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const T* ov = reinterpret_cast<const T*>(&of[kk]);
+      const T* dv = reinterpret_cast<const T*>(&dof[kk]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) del_q += to_f32<T>(ov[i]) * to_f32<T>(dv[i]);
+    }
+    del_q += __shfl_xor(del_q, 32, 64);
+    if (qok && ks == 0 && hi == 0) delta[((long)b * H + h) * Nq + qrow] = del_q;
+  }
   const float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;
-  const float del_q = qok ? delta[((long)b * H + h) * Nq + qrow] : 0.f;
   v16f dqacc[2] = {zero16(), zero16()};
-  const T* kp = k + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
-  const T* vp = v + (long)b * Nk * ldk + h * HD + (threadIdx.x & 7) * 8;
+  const T* kp = k + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
+  const T* vp = v + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
   const unsigned short* kt = sK + (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
+  const int tiles = (Nk + 63) >> 6, tps = (tiles + KS - 1) / KS;
+  const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
   TileRegs rk, rv;
-  fetch_tile<T>(kp, ldk, 0, Nk, rk);
-  fetch_tile<T>(vp, ldk, 0, Nk, rv);
-  for (int k0 = 0; k0 < Nk; k0 += 64) {
+  if (t_begin < t_end) {
+    fetch_tile<T>(kp, ldk, t_begin * 64, Nk, rk, tid);
+    fetch_tile<T>(vp, ldk, t_begin * 64, Nk, rv, tid);
+  }
+  for (int it = 0; it < tps; ++it) {
+    const int k0 = (t_begin + it) * 64;
+    const bool act = t_begin + it < t_end;
     __syncthreads();
-    commit_tile(rk, sK);
-    commit_tile(rv, sV);
+    if (act) {
+      commit_tile(rk, sK, tid);
+      commit_tile(rv, sV, tid);
+    }
     __syncthreads();
-    if (k0 + 64 < Nk) {
-      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk);
-      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv);
+    if (!act) continue;
+    if (t_begin + it + 1 < t_end) {
+      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk, tid);
+      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv, tid);
     }
     const bool ragged = k0 + 64 > Nk;
 #pragma unroll
@@ -290,48 +363,84 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(const T* q, long ldq, const
       }
     }
   }
+  if (KS > 1) {
+    float* cb = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int step = KS / 2; step >= 1; step >>= 1) {
+      __syncthreads();
+      if (ks >= step && ks < 2 * step) {
+        float* slot = cb + ((ks - step) * 4 + wave) * (32 * 64) + lane;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[(dt * 16 + r) * 64] = dqacc[dt][r];
+      }
+      __syncthreads();
+      if (ks < step) {
+        const float* slot = cb + (ks * 4 + wave) * (32 * 64) + lane;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dqacc[dt][r] += slot[(dt * 16 + r) * 64];
+      }
+    }
+    if (ks != 0) return;
+  }
   if (qok) store_rows_t<T>(dq + (long)b * Nq * lddq, lddq, qrow, h * HD, hi, dqacc, 1.f);
 }
 
 // ------------------------------------------------------------------------- backward dK, dV
-template <class T>
-__global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
-                                                      long lddo, const float* lse, const float* delta, T* dk, T* dv,
-                                                      long lddk, int H, int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) unsigned short sQ[TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short sdO[TILE];
-  __shared__ __attribute__((aligned(16))) float sLse[64];
-  __shared__ __attribute__((aligned(16))) float sDel[64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
+// 128 keys x KS query ranges per block; the groups' dK / dV partial sums are merged through LDS.
+template <class T, int KS>
+__global__ void __launch_bounds__(256 * KS) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
+                                                           long lddo, const float* lse, const float* delta, T* dk, T* dv,
+                                                           long lddk, int H, int Nq, int Nk) {
+  constexpr int GRP = 2 * TILE + 256;     // shorts per group: Q tile, dO tile, 64 lse + 64 delta (f32)
+  __shared__ __attribute__((aligned(16))) unsigned short smem[KS * GRP];
+  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
+  unsigned short* sQ = smem + ks * GRP;
+  unsigned short* sdO = sQ + TILE;
+  float* sLse = reinterpret_cast<float*>(sdO + TILE);
+  float* sDel = sLse + 64;
   const long krow = (long)blockIdx.x * 128 + wave * 32 + ln;
   const bool kok = krow < Nk;
   uint4 kf[4], vf[4];
   load_row_frags<T>(k + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, kf);
   load_row_frags<T>(v + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, vf);
   v16f dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
-  const T* qp = q + (long)b * Nq * ldq + h * HD + (threadIdx.x & 7) * 8;
-  const T* dop = d_o + (long)b * Nq * lddo + h * HD + (threadIdx.x & 7) * 8;
+  const T* qp = q + (long)b * Nq * ldq + h * HD + (tid & 7) * 8;
+  const T* dop = d_o + (long)b * Nq * lddo + h * HD + (tid & 7) * 8;
   const int toff = (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const unsigned short* qt = sQ + toff;
   const unsigned short* dot = sdO + toff;
+  const int tiles = (Nq + 63) >> 6, tps = (tiles + KS - 1) / KS;
+  const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
   TileRegs rq, rdo;
-  fetch_tile<T>(qp, ldq, 0, Nq, rq);
-  fetch_tile<T>(dop, lddo, 0, Nq, rdo);
-  for (int q0 = 0; q0 < Nq; q0 += 64) {
+  if (t_begin < t_end) {
+    fetch_tile<T>(qp, ldq, t_begin * 64, Nq, rq, tid);
+    fetch_tile<T>(dop, lddo, t_begin * 64, Nq, rdo, tid);
+  }
+  for (int it = 0; it < tps; ++it) {
+    const int q0 = (t_begin + it) * 64;
+    const bool act = t_begin + it < t_end;
     __syncthreads();
-    commit_tile(rq, sQ);
-    commit_tile(rdo, sdO);
-    if (q0 + 64 < Nq) {
-      fetch_tile<T>(qp, ldq, q0 + 64, Nq, rq);
-      fetch_tile<T>(dop, lddo, q0 + 64, Nq, rdo);
-    }
-    if (threadIdx.x < 64) {
-      const long qr = q0 + threadIdx.x;
-      sLse[threadIdx.x] = qr < Nq ? lse[((long)b * H + h) * Nq + qr] * LOG2E : INFINITY;
-      sDel[threadIdx.x] = qr < Nq ? delta[((long)b * H + h) * Nq + qr] : 0.f;
+    if (act) {
+      commit_tile(rq, sQ, tid);
+      commit_tile(rdo, sdO, tid);
+      if (t_begin + it + 1 < t_end) {
+        fetch_tile<T>(qp, ldq, q0 + 64, Nq, rq, tid);
+        fetch_tile<T>(dop, lddo, q0 + 64, Nq, rdo, tid);
+      }
+      if (tid < 64) {
+        const long qr = q0 + tid;
+        sLse[tid] = qr < Nq ? lse[((long)b * H + h) * Nq + qr] * LOG2E : INFINITY;
+        sDel[tid] = qr < Nq ? delta[((long)b * H + h) * Nq + qr] : 0.f;
+      }
     }
     __syncthreads();
+    if (!act) continue;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       v16f s = tile_times_frags<T>(sQ, t2 * 32, ln, hi, kf);      // rows = queries, col = key
@@ -361,6 +470,31 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, cons
       }
     }
   }
+  if (KS > 1) {
+    static_assert(KS <= 2, "the dK/dV merge buffer holds one pair of groups");
+    float* cb = reinterpret_cast<float*>(smem);       // 4 waves x 32 x 64 f32 = 32 KiB <= KS * GRP * 2 bytes
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {            // dK, then dV
+      v16f (&acc)[2] = pass == 0 ? dkacc : dvacc;
+      __syncthreads();
+      if (ks == 1) {
+        float* slot = cb + wave * (32 * 64) + lane;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[(dt * 16 + r) * 64] = acc[dt][r];
+      }
+      __syncthreads();
+      if (ks == 0) {
+        const float* slot = cb + wave * (32 * 64) + lane;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[dt][r] += slot[(dt * 16 + r) * 64];
+      }
+    }
+    if (ks != 0) return;
+  }
   if (kok) {
     store_rows_t<T>(dk + (long)b * Nk * lddk, lddk, krow, h * HD, hi, dkacc, 1.f);
     store_rows_t<T>(dv + (long)b * Nk * lddk, lddk, krow, h * HD, hi, dvacc, 1.f);
@@ -368,13 +502,29 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(const T* q, long ldq, cons
 }
 
 // ------------------------------------------------------------------------------ launchers
+template <class T, int KS>
+static void attn_fwd_launch(dim3 grid, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
+                            long ldo, float* lse, int H, int Nq, int Nk) {
+  hipLaunchKernelGGL((k_attn_fwd<T, KS>), grid, dim3(256 * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk, (T*)o, ldo,
+                     lse, H, Nq, Nk);
+}
+// key-range split per block (measured on MI355X, fp16, B=1 H=5 N=4096: fwd 97 -> 57 us at KS=4, dq+dkv 244 -> 160 us
+// at KS=2; still ahead at 9216 keys and B=2, so the choice depends on the loop length only)
+static int attn_key_split(int tiles, int max_ks) {
+  static const int force = getenv("DH_ATTN_KS") ? atoi(getenv("DH_ATTN_KS")) : 0;
+  int ks = tiles >= 16 ? 4 : tiles >= 8 ? 2 : 1;
+  if (force == 1 || force == 2 || force == 4) ks = force;
+  return ks < max_ks ? ks : max_ks;
+}
 void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o, long ldo,
                           float* lse, int B, int H, int Nq, int Nk, hipStream_t st) {
   dim3 grid(cdiv(Nq, 128), H, B);
-  if (dtype == DH_DTYPE_F16)
-    hipLaunchKernelGGL((k_attn_fwd<f16>), grid, dim3(256), 0, st, (const f16*)q, ldq, (const f16*)k, (const f16*)v, ldk, (f16*)o, ldo, lse, H, Nq, Nk);
-  else
-    hipLaunchKernelGGL((k_attn_fwd<bf16>), grid, dim3(256), 0, st, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldk, (bf16*)o, ldo, lse, H, Nq, Nk);
+  const int ks = attn_key_split((Nk + 63) / 64, 4);
+#define DH_ATTN_FWD(T_) \
+  (ks == 4 ? attn_fwd_launch<T_, 4> : ks == 2 ? attn_fwd_launch<T_, 2> : attn_fwd_launch<T_, 1>)(grid, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk)
+  if (dtype == DH_DTYPE_F16) DH_ATTN_FWD(f16);
+  else DH_ATTN_FWD(bf16);
+#undef DH_ATTN_FWD
 }
 
 void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o, long lddo, float* delta, int B, int H,
@@ -387,24 +537,42 @@ void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o,
     hipLaunchKernelGGL((k_attn_delta<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)o, ldo, (const bf16*)d_o, lddo, delta, H, Nq, total);
 }
 
-void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* d_o,
-                             long lddo, const float* lse, const float* delta, void* dq, long lddq, int B, int H, int Nq,
-                             int Nk, hipStream_t st) {
+template <class T, int KS>
+static void attn_dq_launch(dim3 grid, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
+                           const void* o, long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq,
+                           long lddq, int H, int Nq, int Nk) {
+  hipLaunchKernelGGL((k_attn_bwd_dq<T, KS>), grid, dim3(256 * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk,
+                     (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
+}
+void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* o,
+                             long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq, long lddq,
+                             int B, int H, int Nq, int Nk, hipStream_t st) {
   dim3 grid(cdiv(Nq, 128), H, B);
-  if (dtype == DH_DTYPE_F16)
-    hipLaunchKernelGGL((k_attn_bwd_dq<f16>), grid, dim3(256), 0, st, (const f16*)q, ldq, (const f16*)k, (const f16*)v, ldk, (const f16*)d_o, lddo, lse, delta, (f16*)dq, lddq, H, Nq, Nk);
-  else
-    hipLaunchKernelGGL((k_attn_bwd_dq<bf16>), grid, dim3(256), 0, st, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldk, (const bf16*)d_o, lddo, lse, delta, (bf16*)dq, lddq, H, Nq, Nk);
+  const int ks = attn_key_split((Nk + 63) / 64, 2);
+#define DH_ATTN_DQ(T_) \
+  (ks == 2 ? attn_dq_launch<T_, 2> : attn_dq_launch<T_, 1>)(grid, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk)
+  if (dtype == DH_DTYPE_F16) DH_ATTN_DQ(f16);
+  else DH_ATTN_DQ(bf16);
+#undef DH_ATTN_DQ
 }
 
+template <class T, int KS>
+static void attn_dkv_launch(dim3 grid, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
+                            const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk,
+                            int H, int Nq, int Nk) {
+  hipLaunchKernelGGL((k_attn_bwd_dkv<T, KS>), grid, dim3(256 * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk,
+                     (const T*)d_o, lddo, lse, delta, (T*)dk, (T*)dv, lddk, H, Nq, Nk);
+}
 void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* d_o,
                               long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk, int B,
                               int H, int Nq, int Nk, hipStream_t st) {
   dim3 grid(cdiv(Nk, 128), H, B);
-  if (dtype == DH_DTYPE_F16)
-    hipLaunchKernelGGL((k_attn_bwd_dkv<f16>), grid, dim3(256), 0, st, (const f16*)q, ldq, (const f16*)k, (const f16*)v, ldk, (const f16*)d_o, lddo, lse, delta, (f16*)dk, (f16*)dv, lddk, H, Nq, Nk);
-  else
-    hipLaunchKernelGGL((k_attn_bwd_dkv<bf16>), grid, dim3(256), 0, st, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldk, (const bf16*)d_o, lddo, lse, delta, (bf16*)dk, (bf16*)dv, lddk, H, Nq, Nk);
+  const int ks = attn_key_split((Nq + 63) / 64, 2);
+#define DH_ATTN_DKV(T_) \
+  (ks == 2 ? attn_dkv_launch<T_, 2> : attn_dkv_launch<T_, 1>)(grid, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk)
+  if (dtype == DH_DTYPE_F16) DH_ATTN_DKV(f16);
+  else DH_ATTN_DKV(bf16);
+#undef DH_ATTN_DKV
 }
 
 }  // namespace dh

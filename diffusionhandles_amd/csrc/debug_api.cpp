@@ -59,8 +59,8 @@ extern "C" int dh_dbg_attention(int dtype, const void* q, long ldq, const void* 
   hipStream_t st = (hipStream_t)stream;
   launch_attention_fwd(dtype, q, ldq, k, v, ldk, o, ldo, lse, B, H, Nq, Nk, st);
   if (d_o) {
-    launch_attention_delta(dtype, o, ldo, d_o, ldo, delta, B, H, Nq, st);
-    if (dq) launch_attention_bwd_dq(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dq, ldq, B, H, Nq, Nk, st);
+    if (dq) launch_attention_bwd_dq(dtype, q, ldq, k, v, ldk, o, ldo, d_o, ldo, lse, delta, dq, ldq, B, H, Nq, Nk, st);
+    else launch_attention_delta(dtype, o, ldo, d_o, ldo, delta, B, H, Nq, st);
     if (dk && dv) launch_attention_bwd_dkv(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dk, dv, ldk, B, H, Nq, Nk, st);
   }
   DH_LAUNCH_CHECK();

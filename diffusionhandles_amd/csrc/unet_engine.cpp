@@ -828,20 +828,19 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
         const Ten& tq = u->tens[o.in0];
         const int C = u->tens[o.out].C;
         float* delta = u->small;
-        launch_attention_delta(dt, u->aptr(o.out), C, u->gptr(o.out), C, delta, B, o.heads, o.Nq, st);
         if (!o.cross) {
           const unsigned short* qkv = u->aptr(o.in0);
           unsigned short* dqkv = u->gptr(o.in0);
-          launch_attention_bwd_dq(dt, qkv, tq.C, qkv + C, qkv + 2 * C, tq.C, u->gptr(o.out), C, u->f32a + o.lse_off,
-                                  delta, dqkv, tq.C, B, o.heads, o.Nq, o.Nk, st);
+          launch_attention_bwd_dq(dt, qkv, tq.C, qkv + C, qkv + 2 * C, tq.C, u->aptr(o.out), C, u->gptr(o.out), C,
+                                  u->f32a + o.lse_off, delta, dqkv, tq.C, B, o.heads, o.Nq, o.Nk, st);
           launch_attention_bwd_dkv(dt, qkv, tq.C, qkv + C, qkv + 2 * C, tq.C, u->gptr(o.out), C, u->f32a + o.lse_off,
                                    delta, dqkv + C, dqkv + 2 * C, tq.C, B, o.heads, o.Nq, o.Nk, st);
           u->flops_bwd += 14.0 * B * o.heads * (double)o.Nq * o.Nk * 64;
         } else {
           const Ten& tkv = u->tens[o.in1];
           const unsigned short* kv = u->aptr(o.in1) + o.kv_col;
-          launch_attention_bwd_dq(dt, u->aptr(o.in0), tq.C, kv, kv + C, tkv.C, u->gptr(o.out), C, u->f32a + o.lse_off,
-                                  delta, u->gptr(o.in0), tq.C, B, o.heads, o.Nq, o.Nk, st);
+          launch_attention_bwd_dq(dt, u->aptr(o.in0), tq.C, kv, kv + C, tkv.C, u->aptr(o.out), C, u->gptr(o.out), C,
+                                  u->f32a + o.lse_off, delta, u->gptr(o.in0), tq.C, B, o.heads, o.Nq, o.Nk, st);
           u->flops_bwd += 6.0 * B * o.heads * (double)o.Nq * o.Nk * 64;
           if (bw.need_text) {
             unsigned short* dkv = u->gptr(o.in1) + o.kv_col;

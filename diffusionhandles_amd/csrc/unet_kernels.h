@@ -73,8 +73,9 @@ void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, con
 // delta[b][h][q] = sum_d dO*O
 void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o, long lddo, float* delta, int B,
                             int H, int Nq, hipStream_t st);
-void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk,
-                             const void* d_o, long lddo, const float* lse, const float* delta, void* dq, long lddq,
+// dq also WRITES delta[b][h][q] = sum_d dO*O (read by the dkv kernel launched after it)
+void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* o,
+                             long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq, long lddq,
                              int B, int H, int Nq, int Nk, hipStream_t st);
 void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk,
                               const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv,
