@@ -97,7 +97,9 @@ __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, flo
 // registers), so ST-1 K tiles are in flight per workgroup while tile t is multiplied.
 //   * stage image: A rows then W rows, 128 B per row, UNPADDED (the DMA destination is
 //     wave-uniform base + lane*16); bank conflicts are avoided by an XOR swizzle applied on the
-//     per-lane SOURCE address (16-byte chunk c of row r is stored at chunk c ^ (r & 7)) and
+//     per-lane SOURCE address (16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7): gfx950's
+//     ds_read_b128 serves 16 lanes per cycle from a 256-byte bank row = TWO 128-byte tile rows, and its lane
+//     groups {0-3,12-15,20-27} / {4-11,16-19,28-31} then hit 16 distinct 16-byte slots) and
 //     undone on the fragment read.
 //   * the DMA is issued from inline asm (m0 = LDS destination), so hipcc does not see a pending
 //     LDS write and does not drain vmcnt(0) in front of every ds_read; ordering is by hand:
@@ -115,15 +117,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
 
-template <class T, int BM, int BN, int ST, int MODE, int ABL = 0>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
-__global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
+// WG = 2: two groups of four waves share every staged tile; group g multiplies k-steps [g, g+1) * KK/2 of it and
+// issues half of the DMA pieces, and the groups' accumulators are added through LDS before the epilogue.  Same
+// LDS and DMA traffic as WG = 1 but two waves per SIMD, so one wave's ds_read / barrier waits sit under the
+// other's MFMAs (a single image fills the chip with at most one 4-wave block per CU).
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
+__global__ void __launch_bounds__(256 * WG) k_gemm_dma(const GemmK p) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int NPA = BM / 32, NPB = BN / 32;     // 1-KiB pieces per wave per stage
+  constexpr int NPA = BM / 32 / WG, NPB = BN / 32 / WG;     // 1-KiB pieces per wave per stage
   constexpr int NP = NPA + NPB;
   constexpr int STAGE = (BM + BN) * 128;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  const int grp = WG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;     // wave-uniform (feeds m0 through dma16)
   const int wm = wave >> 1, wn = wave & 1, ln = lane & 31, hi = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int kbeg = blockIdx.z * p.k_per_split;
@@ -133,7 +140,8 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   const T* Ag = reinterpret_cast<const T*>(p.A);
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   const int prow = lane >> 3;                       // row of this lane inside a piece
-  const int lchunk = (lane & 7) ^ prow;             // logical chunk it fetches (swizzle on the source)
+  // logical chunk this lane fetches (swizzle on the source): piece rows are 8 (wave + 4 j) + prow, so ((row >> 1) & 7)
+  const int lchunk = (lane & 7) ^ (4 * (wave & 1) + (prow >> 1));
   const T* zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 7) * 8;
 
   // A rows of this lane: one per piece
@@ -142,7 +150,7 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   int a_oy[NPA], a_ox[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
-    const int m = m0 + 8 * (wave + 4 * j) + prow;
+    const int m = m0 + 8 * (wave + 4 * (j * WG + grp)) + prow;
     a_ok[j] = m < p.M;
     if (MODE == GM_DENSE) {
       a_off[j] = (long)m * p.lda + lchunk * 8;
@@ -162,7 +170,7 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   const T* b_ptr[NPB];
 #pragma unroll
   for (int j = 0; j < NPB; ++j) {
-    const int row = 8 * (wave + 4 * j);                    // first row of the piece inside the BN tile
+    const int row = 8 * (wave + 4 * (j * WG + grp));       // first row of the piece inside the BN tile
     b_ptr[j] = Wg + ((size_t)((n0 + row) >> 6) * KT) * 4096 + (size_t)(row & 63) * 64 + lane * 8;
   }
   int tap = 0, c0 = 0;
@@ -177,13 +185,13 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
       const int j = q;
       if (MODE == GM_DENSE) {
         const T* ptr = Ag + a_off[j] + k0;
-        dma16(a_ok[j] ? ptr : zero, sbase + j * 4096);
+        dma16(a_ok[j] ? ptr : zero, sbase + (j * WG + grp) * 4096);
       } else if (MODE == GM_CONV_S1) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const long toff = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda + c0;
         const bool ok = a_ok[j] && (unsigned)(a_oy[j] + ky - 1) < (unsigned)p.Hin && (unsigned)(a_ox[j] + kx - 1) < (unsigned)p.Win;
         const T* ptr = Ag + a_off[j] + toff;
-        dma16(ok ? ptr : zero, sbase + j * 4096);
+        dma16(ok ? ptr : zero, sbase + (j * WG + grp) * 4096);
       } else {
         const int ky = tap / 3, kx = tap - ky * 3;
         bool ok = a_ok[j];
@@ -200,11 +208,11 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
         sy = sy < 0 ? 0 : (sy >= p.Hin ? p.Hin - 1 : sy);
         sx = sx < 0 ? 0 : (sx >= p.Win ? p.Win - 1 : sx);
         const T* ptr = Ag + (a_off[j] + (long)sy * p.Win + sx) * p.lda + c0 + lchunk * 8;
-        dma16(ok ? ptr : zero, sbase + j * 4096);
+        dma16(ok ? ptr : zero, sbase + (j * WG + grp) * 4096);
       }
     } else {
       const int j = q - NPA;
-      dma16(b_ptr[j] + (size_t)(k0 >> 6) * 4096, sbase + BM * 128 + j * 4096);
+      dma16(b_ptr[j] + (size_t)(k0 >> 6) * 4096, sbase + BM * 128 + (j * WG + grp) * 4096);
     }
   };
   auto next_tile = [&]() {
@@ -228,7 +236,8 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
   for (int s = 0; s < ST - 1; ++s)
     if (s < ntiles) issue(s, s);
 
-  constexpr int KK = BK / 16;
+  constexpr int KK = BK / 16 / WG;                // k-steps of a tile multiplied by this wave group
+  const int kk0 = grp * KK;
   for (int kt = 0; kt < ntiles; ++kt) {
     // tile kt has landed once at most (ST-2) later tiles' loads are still outstanding
     if (ntiles - 1 - kt >= ST - 2) wait_vmcnt<NP * (ST - 2)>(); else wait_vmcnt<0>();
@@ -240,7 +249,7 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
     const unsigned char* sb = sa + BM * 128;
     uint4 fw[2][TN], fx[2][TM];
     auto load_frags = [&](int kk, int buf) {
-      const int pc = ((2 * kk + hi) ^ (ln & 7)) << 4;
+      const int pc = ((2 * kk + hi) ^ ((ln >> 1) & 7)) << 4;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         fw[buf][j] = *reinterpret_cast<const uint4*>(sb + (wn * (BN / 2) + j * 32 + ln) * 128 + pc);
@@ -248,10 +257,10 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
       for (int i = 0; i < TM; ++i)
         fx[buf][i] = *reinterpret_cast<const uint4*>(sa + (wm * (BM / 2) + i * 32 + ln) * 128 + pc);
     };
-    load_frags(0, 0);
+    load_frags(kk0, 0);
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      if (kk + 1 < KK) load_frags(kk + 1, (kk + 1) & 1);      // next fragments fly under this step's MFMAs
+      if (kk + 1 < KK) load_frags(kk0 + kk + 1, (kk + 1) & 1);      // next fragments fly under this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -263,6 +272,29 @@ __global__ void __launch_bounds__(256) k_gemm_dma(const GemmK p) {
       }
     }
     if (more) next_tile();
+  }
+
+  if (WG > 1) {
+    // add the second group's partial sums: f32 through the (now idle) stage ring, [value][lane] per wave
+    static_assert(WG <= 2 && TM * TN * 16 * 64 * 4 * 4 <= ST * STAGE, "merge buffer does not fit the stage ring");
+    float* cb = reinterpret_cast<float*>(smem) + wave * (TM * TN * 16 * 64) + lane;
+    __syncthreads();
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cb[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += cb[((i * TN + j) * 16 + r) * 64];
   }
 
 #pragma unroll
@@ -353,24 +385,28 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
   int gm = GM_GENERIC;
   if (k.mode == A_DENSE) gm = GM_DENSE;
   else if (k.mode == A_CONV3 && k.stride == 1 && k.up == 0) gm = GM_CONV_S1;
-#define DH_LAUNCH_GEMM(BM_, BN_, ST_)                                                                         \
-  do {                                                                                                        \
-    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_DENSE>), grid, dim3(256), 0, st, k);        \
-    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1>), grid, dim3(256), 0, st, k); \
-    else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC>), grid, dim3(256), 0, st, k);                    \
+#define DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, WG_)                                                                            \
+  do {                                                                                                                    \
+    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_DENSE, 0, WG_>), grid, dim3(256 * WG_), 0, st, k);        \
+    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1, 0, WG_>), grid, dim3(256 * WG_), 0, st, k); \
+    else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC, 0, WG_>), grid, dim3(256 * WG_), 0, st, k);                    \
   } while (0)
-  static const int kSt = getenv("DH_GEMM_ST") ? atoi(getenv("DH_GEMM_ST")) : 4;
+#define DH_LAUNCH_GEMM(BM_, BN_, ST_)                         \
+  do {                                                        \
+    if (kWg == 2) DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, 2);        \
+    else DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, 1);                 \
+  } while (0)
+  static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 1;
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
   if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 3 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 1>), grid, dim3(256), 0, st, k); }
   else
   if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
-  else if (BN == 128 && kSt == 2) DH_LAUNCH_GEMM(128, 128, 2);
-  else if (BN == 128 && kSt == 3) DH_LAUNCH_GEMM(128, 128, 3);
   else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
   else DH_LAUNCH_GEMM(128, 64, 5);
 #undef DH_LAUNCH_GEMM
+#undef DH_LAUNCH_GEMM_WG
   if (e1) (void)hipEventRecord(e1, st);
   if (splits > 1) {
     const size_t groups = (size_t)k.M * k.N / 4;

@@ -28,10 +28,10 @@ bool gemm_profiling_on();   // HIP-event bracket active (bench roofline pass): g
 // plain [N][K] -> tiled weight layout (test hooks); N, K multiples of 64
 void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st);
 // element offset of (n, k) in the tiled weight layout: [N/64][K/64] tiles of 64x64 halves (8 KiB,
-// contiguous), each stored as the swizzled LDS image (16-byte chunk c of row r at chunk c ^ (r & 7))
+// contiguous), each stored as the swizzled LDS image (16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7))
 __host__ __device__ inline size_t wt_index(int n, int k, int K) {
   const int r = n & 63, c = (k & 63) >> 3;
-  return ((size_t)(n >> 6) * (K >> 6) + (k >> 6)) * 4096 + (size_t)r * 64 + (size_t)((c ^ (r & 7)) << 3) + (k & 7);
+  return ((size_t)(n >> 6) * (K >> 6) + (k >> 6)) * 4096 + (size_t)r * 64 + (size_t)((c ^ ((r >> 1) & 7)) << 3) + (k & 7);
 }
 
 // direct small convolutions (conv_in: Cin=5 -> C; conv_out: C -> 4) and their input-gradients

@@ -41,5 +41,7 @@ shapes = [
 import os
 if os.environ.get('DH_SHAPES') == 'abl':
     shapes = [(4096, 640, 5760, (1, 64, 640)), (256, 1280, 11520, (1, 16, 1280)), (8192, 1280, 11520, (8, 32, 1280))]
+if os.environ.get('DH_SHAPES') == 'b1':
+    shapes = [(4096, 320, 2880, (1, 64, 320)), (4096, 640, 5760, (1, 64, 640)), (4096, 320, 1280, None), (1024, 640, 5760, (1, 32, 640)), (4096, 1280, 320, None)]
 for s in shapes:
     run(*s)
