@@ -393,10 +393,13 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
   } while (0)
 #define DH_LAUNCH_GEMM(BM_, BN_, ST_)                         \
   do {                                                        \
-    if (kWg == 2) DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, 2);        \
+    if (wg == 2) DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, 2);         \
     else DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, 1);                 \
   } while (0)
-  static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 1;
+  // two wave groups per block: measured ahead only on the 128x64 tile with a long K loop (conv 4096x320x2880:
+  // 28.5 -> 24.9 us, x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge)
+  static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 0;
+  const int wg = kWg ? kWg : (BM == 128 && BN == 64 && tiles_per_split >= 16 ? 2 : 1);
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
   if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
