@@ -105,7 +105,8 @@ __device__ __forceinline__ float silu_grad(float z) {
 // GroupNorm statistics in two deterministic stages:
 //   k_gn_partial  grid (S, G/4, B): a workgroup owns one row slice x 4 adjacent groups, reads the 4*cpg
 //                 channel window of every row with 16-byte chunks and leaves (n, mean, M2) per group
-//                 [f32, shifted by the slice's first row; fixed-order folds, no atomics]
+//                 [f32 sums shifted by a per-group pivot = the group's first element of the slice; wave
+//                 butterflies + a fixed-order fold over the 4 waves, no atomics]
 //   the apply kernel combines the S <= 16 slices (8 lanes per group, butterfly, Chan's formula) before
 //   normalising; block x == 0 also publishes (mean, rstd) for backward.
 // partial layout: [b][g][3][S]  (n | mean | M2 planes)
@@ -115,28 +116,33 @@ __host__ __device__ inline int gn_slices(int HW) { int s = HW / 4; return s < 1 
 template <class T, bool BWD>
 __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, const float* gamma, const float* beta,
                                                     const float* stats, float* part, int HW, int C, int G, int S, int silu) {
-  extern __shared__ float sm_c[];            // [W] pivot, [RP][W] a, [RP][W] q     (W = GN_GB * cpg channels)
+  __shared__ float sm_red[4][2 * GN_GB];
   const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = C / G;
   const int W = GN_GB * cpg, nch = W / 8;
   const int RP = (int)blockDim.x / nch;
-  float* piv = sm_c;
-  float* ca = sm_c + W;
-  float* cq = ca + (size_t)RP * W;
   const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
   const size_t base = (size_t)b * HW * C + (size_t)g0 * cpg;
-  if (!BWD) {
-    for (int c = threadIdx.x; c < W; c += blockDim.x) piv[c] = to_f32<T>(x[base + (size_t)r0 * C + c]);
-    __syncthreads();
-  }
   const int rr = threadIdx.x / nch, ch = threadIdx.x - rr * nch;
+  float ga[GN_GB], gq[GN_GB], pg[GN_GB];
+#pragma unroll
+  for (int gl = 0; gl < GN_GB; ++gl) {
+    ga[gl] = 0.f; gq[gl] = 0.f;
+    pg[gl] = (BWD || g0 + gl >= G) ? 0.f : to_f32<T>(x[base + (size_t)r0 * C + gl * cpg]);
+  }
   if (rr < RP) {
+    int gi[8];
     float a[8], q[8], pv[8], gm[8], bt[8], mu[8], rs[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a[i] = 0.f; q[i] = 0.f; pv[i] = BWD ? 0.f : piv[ch * 8 + i]; }
+    for (int i = 0; i < 8; ++i) {          // a chunk may straddle groups: per-element group index
+      gi[i] = (ch * 8 + i) / cpg;
+      a[i] = 0.f; q[i] = 0.f; pv[i] = 0.f;
+#pragma unroll
+      for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
+    }
     if (BWD) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {        // a chunk may straddle two groups: per-element statistics
-        const int sg = b * G + g0 + (ch * 8 + i) / cpg;
+      for (int i = 0; i < 8; ++i) {
+        const int sg = b * G + g0 + gi[i];
         gm[i] = gamma[g0 * cpg + ch * 8 + i]; bt[i] = beta[g0 * cpg + ch * 8 + i];
         mu[i] = stats[2 * sg]; rs[i] = stats[2 * sg + 1];
       }
@@ -162,39 +168,34 @@ __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, con
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ca[(size_t)rr * W + ch * 8 + i] = a[i]; cq[(size_t)rr * W + ch * 8 + i] = q[i]; }
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int gl = 0; gl < GN_GB; ++gl) {
+        ga[gl] += gi[i] == gl ? a[i] : 0.f;
+        gq[gl] += gi[i] == gl ? q[i] : 0.f;
+      }
   }
-  __syncthreads();
-  const float nrow = (float)(r1 - r0);
-  {   // fold the row sets per channel (one thread per channel, fixed order), result left in row set 0
-    const int rp_used = (r1 - r0) < RP ? (r1 - r0) : RP;
-    for (int c = threadIdx.x; c < W; c += blockDim.x) {
-      float sc = 0.f, sq = 0.f;
-      for (int k2 = 0; k2 < rp_used; ++k2) { sc += ca[(size_t)k2 * W + c]; sq += cq[(size_t)k2 * W + c]; }
-      ca[c] = sc; cq[c] = sq;
-    }
+#pragma unroll
+  for (int gl = 0; gl < GN_GB; ++gl) { ga[gl] = wave_sum(ga[gl]); gq[gl] = wave_sum(gq[gl]); }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int gl = 0; gl < GN_GB; ++gl) { sm_red[threadIdx.x >> 6][2 * gl] = ga[gl]; sm_red[threadIdx.x >> 6][2 * gl + 1] = gq[gl]; }
   }
   __syncthreads();
   if ((int)threadIdx.x < GN_GB && g0 + (int)threadIdx.x < G) {
     const int gl = threadIdx.x, g = g0 + gl;
+    float sa = 0.f, sq = 0.f;
+    for (int w = 0; w < 4; ++w) { sa += sm_red[w][2 * gl]; sq += sm_red[w][2 * gl + 1]; }
     if (!BWD) {
-      float n = 0.f, mean = 0.f, m2 = 0.f;
-      for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) {
-        const float sc = ca[c], sq = cq[c];
-        const float mc = piv[c] + sc / nrow;
-        const float m2c = sq - sc * sc / nrow;
-        const float nn = n + nrow, d = mc - mean;
-        mean += d * nrow / nn;
-        m2 += m2c + d * d * n * nrow / nn;
-        n = nn;
-      }
+      const float n = (float)(r1 - r0) * (float)cpg;
+      float piv = 0.f;
+#pragma unroll
+      for (int k = 0; k < GN_GB; ++k) piv = gl == k ? pg[k] : piv;
       float* o = part + ((size_t)(b * G + g) * 3) * S + s;
-      o[0] = n; o[S] = mean; o[2 * S] = m2;
+      o[0] = n; o[S] = piv + sa / n; o[2 * S] = sq - sa * sa / n;
     } else {
-      float s1 = 0.f, s2 = 0.f;
-      for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) { s1 += ca[c]; s2 += cq[c]; }
-      part[((size_t)(b * G + g) * S + s) * 2] = s1;
-      part[((size_t)(b * G + g) * S + s) * 2 + 1] = s2;
+      part[((size_t)(b * G + g) * S + s) * 2] = sa;
+      part[((size_t)(b * G + g) * S + s) * 2 + 1] = sq;
     }
   }
 }
@@ -228,13 +229,14 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
                                                   float* stats, T* y, int HW, int C, int G, int S, float eps, int silu) {
   __shared__ float2 sm_stats[64];
   const int b = blockIdx.y;
-  gn_combine(part, b, G, S, eps, sm_stats, blockIdx.x == 0 ? stats : nullptr);
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cchunks = C / 8;
-  if (idx >= (size_t)HW * cchunks) return;
-  const size_t row = (size_t)b * HW + idx / cchunks;
+  const bool live = idx < (size_t)HW * cchunks;
+  const size_t row = (size_t)b * HW + (live ? idx / cchunks : 0);
   const int c0 = (int)(idx % cchunks) * 8, cpg = C / G;
-  uint4 raw = *reinterpret_cast<const uint4*>(x + row * C + c0);
+  uint4 raw = *reinterpret_cast<const uint4*>(x + row * C + c0);      // in flight under the slice combine
+  gn_combine(part, b, G, S, eps, sm_stats, blockIdx.x == 0 ? stats : nullptr);
+  if (!live) return;
   const T* xv = reinterpret_cast<const T*>(&raw);
   T o[8];
 #pragma unroll
@@ -250,14 +252,13 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
 
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st) {
-  const int S = gn_slices(HW), cpg = C / G, W = GN_GB * cpg, RP = 256 / (W / 8);
+  const int S = gn_slices(HW);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
-  const size_t lds = (size_t)(1 + 2 * RP) * W * sizeof(float);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_partial<f16, false>), g1, dim3(256), lds, st, (const f16*)x, (const f16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_partial<f16, false>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu);
   } else {
-    hipLaunchKernelGGL((k_gn_partial<bf16, false>), g1, dim3(256), lds, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_partial<bf16, false>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu);
   }
 }
@@ -268,6 +269,15 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
                                                       int S, int silu, int accumulate) {
   __shared__ float4 sm_st[64];     // mean, rstd, mean(dxhat), mean(dxhat*xhat)
   const int b = blockIdx.y, cpg = C / G;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cchunks = C / 8;
+  const bool live = idx < (size_t)HW * cchunks;
+  const size_t row = (size_t)b * HW + (live ? idx / cchunks : 0);
+  const int c0 = (int)(idx % cchunks) * 8;
+  uint4 rx = *reinterpret_cast<const uint4*>(x + row * C + c0);       // in flight under the slice combine
+  uint4 rd = *reinterpret_cast<const uint4*>(dy + row * C + c0);
+  uint4 ro = make_uint4(0, 0, 0, 0);
+  if (accumulate) ro = *reinterpret_cast<const uint4*>(dx + row * C + c0);
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     const float* p = part + ((size_t)(b * G + g) * S) * 2;
     float a = 0.f, c = 0.f;
@@ -276,15 +286,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
     sm_st[g] = make_float4(stats[2 * (b * G + g)], stats[2 * (b * G + g) + 1], a * inv, c * inv);
   }
   __syncthreads();
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cchunks = C / 8;
-  if (idx >= (size_t)HW * cchunks) return;
-  const size_t row = (size_t)b * HW + idx / cchunks;
-  const int c0 = (int)(idx % cchunks) * 8;
-  uint4 rx = *reinterpret_cast<const uint4*>(x + row * C + c0);
-  uint4 rd = *reinterpret_cast<const uint4*>(dy + row * C + c0);
-  uint4 ro = make_uint4(0, 0, 0, 0);
-  if (accumulate) ro = *reinterpret_cast<const uint4*>(dx + row * C + c0);
+  if (!live) return;
   const T* xv = reinterpret_cast<const T*>(&rx);
   const T* dv = reinterpret_cast<const T*>(&rd);
   const T* ov = reinterpret_cast<const T*>(&ro);
@@ -307,14 +309,13 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st) {
-  const int S = gn_slices(HW), cpg = C / G, W = GN_GB * cpg, RP = 256 / (W / 8);
+  const int S = gn_slices(HW);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
-  const size_t lds = (size_t)(1 + 2 * RP) * W * sizeof(float);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_partial<f16, true>), g1, dim3(256), lds, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_partial<f16, true>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_bwd_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate);
   } else {
-    hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), lds, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate);
   }
 }
