@@ -188,6 +188,56 @@ def main():
                       "edit_steps_per_s": round(K * nb / tb, 2),
                       "frac_of_mfma_peak": round(K * nb / tb * STEP_TFLOP / MFMA_PEAK_TFLOPS, 4)}
 
+    # HBM-bound pieces of the path: guidance energy fwd+bwd and the batched K=8 reprojection,
+    # timed with events on the stream they are launched on; bytes are the algorithmic figures of BASELINE.md section 3
+    hbm = None
+    if rank == 0:
+        from diffusionhandles_amd.depth_transform import reproject_edits
+        HBM_PEAK = 8000.0
+
+        def timed(fn, n=20, graph=False):
+            for _ in range(3):
+                fn()
+            if graph:       # replay through a captured graph: device time of the launches, no host gaps between them
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+                        fn()
+                    fn = g.replay
+                    fn()
+                except Exception:
+                    pass
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / n * 1e-3
+
+        with torch.no_grad(), gd.on_stream():
+            hbm = []
+            cur = [o[1] for o in st.orig]                    # another timestep's activations stand in for "current"
+            for layers, tag in (((2,), "t%3==0: act2"), ((1,), "t%3==1: act1"), ((1, 2), "t%3==2: act1+act2")):
+                fgw, bgw = st.schedule(2 if len(layers) == 2 else (0 if layers == (2,) else 1), 0)
+                def run():
+                    for k in layers:
+                        gd._energy_grad(st, k, cur[k], 0, fgw[k], bgw[k])
+                sec = timed(run, graph=True)
+                nbytes = sum(3 * cur[k].numel() * cur[k].element_size() for k in layers)
+                hbm.append({"kernel": f"guidance energy fwd+bwd ({tag})", "bound": "hbm", "bytes": nbytes,
+                            "us": round(sec * 1e6, 2), "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK,
+                            "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK, 4)})
+            K = 8
+            tfs8 = [(TRANSFORMS[i % 8][0], torch.tensor([0.0, 1.0, 0.0]), torch.tensor(TRANSFORMS[i % 8][1])) for i in range(K)]
+            sec = timed(lambda: reproject_edits(depth, bg_depth, mask, gd.get_depth_intrinsics(), tfs8), n=5)
+            per_edit = 9e6 * (args.res / 512.0) ** 2
+            hbm.append({"kernel": "batched K=8 unproject -> SE(3) -> z-buffer -> index maps (whole reproject_edits call, "
+                                  "host glue included)", "bound": "hbm", "bytes": int(K * per_edit),
+                        "us": round(sec * 1e6, 1), "achieved": round(K * per_edit / sec / 1e9, 2), "peak": HBM_PEAK,
+                        "unit": "GB/s", "frac": round(K * per_edit / sec / 1e9 / HBM_PEAK, 5)})
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.res == 512:
         cpu = cpu_baseline()
@@ -203,7 +253,7 @@ def main():
                                    "phase: 3 x (fwd + energy + bwd-to-latent) + CFG fwd (B=2) + DDIM step",
                        "resolution": args.res, "edits_per_gpu": 1, "correspondences": int(corr.shape[0]),
                        "parallelism": "independent edits, one process per GPU, no collectives"},
-            "roofline": roof, "cpu_baseline": cpu, "batched_edits": batch_info,
+            "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu, "batched_edits": batch_info,
         }
         print(json.dumps(out))
     if dist is not None:

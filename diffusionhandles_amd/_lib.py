@@ -44,6 +44,11 @@ SIGNATURES = {
     "dh_energy_workspace_bytes": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_sz)]),
     "dh_energy_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i,
                                 c_f, c_f, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_sz, c_p]),
+    "dh_energy_plan_bytes": (c_i, [c_i, c_i, ctypes.POINTER(c_sz)]),
+    "dh_energy_plan_build": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_sz, c_p]),
+    "dh_energy_planned_workspace_bytes": (c_i, [c_i, c_i, ctypes.POINTER(c_sz)]),
+    "dh_energy_fwd_bwd_planned": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_i, c_p, c_i, c_p, c_i, c_f, c_f, c_f,
+                                        c_p, c_p, c_i, c_p, c_sz, c_p]),
     "dh_unet_create": (c_i, [ctypes.POINTER(UNetConfig), ctypes.POINTER(c_p)]),
     "dh_unet_destroy": (None, [c_p]),
     "dh_unet_num_params": (c_i, [c_p]),

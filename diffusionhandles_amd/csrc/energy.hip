@@ -204,20 +204,29 @@ __global__ void k_colsum(const float* X, const int* list, int n, int C, int S, f
   part[(size_t)s * C + c] = acc;
 }
 
-// sgn[c] = sign(m1 - m2), loss_c = |m1 - m2|
-__global__ void k_global_diff(const float* p1, const float* p2, int S, int C, int n1, int n2, float* sgn,
-                              double* loss_part) {
-  __shared__ double sm[4];
+// sgn[c] = sign(m1 - m2), loss_c = |m1 - m2|; one wave per 64 channels, slice partials added in slice order
+constexpr int GD_BLOCK = 64;
+__global__ void __launch_bounds__(GD_BLOCK) k_global_diff(const float* p1, const float* p2, int S, int C, int n1, int n2,
+                                                          float* sgn, double* loss_part) {
+  const int c = blockIdx.x * GD_BLOCK + threadIdx.x;
   double l = 0.0;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  if (c < C) {
     float a = 0.f, b = 0.f;
-    for (int s = 0; s < S; ++s) { a += p1[(size_t)s * C + c]; b += p2[(size_t)s * C + c]; }
-    float d = a / (float)n1 - b / (float)n2;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { va[j] = p1[(size_t)(s + j) * C + c]; vb[j] = p2[(size_t)(s + j) * C + c]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a += va[j]; b += vb[j]; }
+    }
+    for (; s < S; ++s) { a += p1[(size_t)s * C + c]; b += p2[(size_t)s * C + c]; }
+    const float d = a / (float)n1 - b / (float)n2;
     sgn[c] = (float)((d > 0.f) - (d < 0.f));
-    l += (double)fabsf(d);
+    l = (double)fabsf(d);
   }
-  l = block_sum(l, sm);
-  if (threadIdx.x == 0) loss_part[0] = l;
+  l = wave_sum(l);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = l;
 }
 
 __global__ void k_global_apply(const int* list, int n, const float* sgn, int C, float coef, float* acc) {
@@ -293,6 +302,151 @@ static void pair_term(const EnergyWs& w, const int* pairs, int n, int C, int gri
   }
 }
 
+// ---- planned fast path ------------------------------------------------------------------
+// The default configuration (maps already at the cell grid, fg_patch 1, 'global_avg' background) needs no f32
+// staging, no pooling and -- because the correspondences are fixed for an edit -- no CSR rebuild per evaluation:
+//   plan (once per edit)  : CSR target cell -> source cells, flag of the transformed-background cells
+//   per evaluation        : k_colsum16 (both background column sums, same slice order as k_colsum)
+//                           k_global_diff (sign of the mean difference per channel)
+//                           k_energy_grad (pair term + background term -> one 16-byte gradient store per lane)
+//                           k_final_loss  (only when the caller wants the loss values)
+// Same arithmetic, in the same order per element, as the general path above: the gradient is bit-identical.
+struct EnergyPlan {
+  int *off, *src, *cnt, *cursor;
+  uint8_t *bgflag, *w1, *w2;
+};
+static bool carve_plan(Arena& a, int grid, int n_pairs, EnergyPlan& p) {
+  const size_t G2 = (size_t)grid * grid;
+  p.off = a.take<int>(G2 + 1); p.cnt = a.take<int>(G2 + 1); p.cursor = a.take<int>(G2 + 1);
+  p.src = a.take<int>(n_pairs > 0 ? n_pairs : 1);
+  p.bgflag = a.take<uint8_t>(G2); p.w1 = a.take<uint8_t>(G2); p.w2 = a.take<uint8_t>(G2);
+  return a.ok();
+}
+struct PlannedWs {
+  float *part1, *part2, *sgn;
+  double *fg_part, *bg_part;
+};
+static bool carve_planned(Arena& a, int C, int grid, PlannedWs& w) {
+  const size_t G2 = (size_t)grid * grid;
+  w.part1 = a.take<float>((size_t)COLSUM_S * C); w.part2 = a.take<float>((size_t)COLSUM_S * C);
+  w.sgn = a.take<float>(C);
+  w.fg_part = a.take<double>(G2); w.bg_part = a.take<double>(cdiv(C, GD_BLOCK));
+  return a.ok();
+}
+
+__global__ void k_flag_cells(const int* list, int n, uint8_t* flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[list[i]] = 1;
+}
+
+// part[z][s][c] = sum over the s-th slice of list z of X_z[cell][c]; thread = (slice, 8-channel chunk), cells in
+// list order (the order k_colsum adds them in)
+template <class T>
+__global__ void k_colsum16(const T* X1, const int* list1, int n1, float* part1, const T* X2, const int* list2, int n2,
+                           float* part2, int C, int S) {
+  const T* X = blockIdx.y ? X2 : X1;
+  const int* list = blockIdx.y ? list2 : list1;
+  const int n = blockIdx.y ? n2 : n1;
+  float* part = blockIdx.y ? part2 : part1;
+  const int nch = C / 8, idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nch * S) return;
+  const int s = idx / nch, ch = idx - s * nch;
+  const int per = (n + S - 1) / S, b = s * per, e = b + per < n ? b + per : n;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  int k = b;
+  for (; k + 8 <= e; k += 8) {          // 8 gathers in flight; the adds keep the list order
+    int id[8];
+    uint4 raw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) id[j] = list[k + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + (size_t)id[j] * C + ch * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const T* v = reinterpret_cast<const T*>(&raw[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
+    }
+  }
+  for (; k < e; ++k) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(X + (size_t)list[k] * C + ch * 8);
+    const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[(size_t)s * C + ch * 8 + i] = acc[i];
+}
+
+// thread = (target cell, 8-channel chunk); block = 256 / (C/8) cells
+template <class T, class TG>
+__global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur, const int* off, const int* src,
+                                                     const uint8_t* bgflag, const float* sgn, int C, int G2, float coef_fg,
+                                                     float coef_bg, int use_bg, float scale, TG* grad, double* loss_part) {
+  __shared__ double sm[4];
+  const int nch = C / 8, cpb = (int)blockDim.x / nch;
+  const int lc = threadIdx.x / nch, ch = threadIdx.x - lc * nch;
+  const int cell = blockIdx.x * cpb + lc;
+  double la = 0.0;
+  if (lc < cpb && cell < G2) {
+    const uint4 ra = *reinterpret_cast<const uint4*>(cur + (size_t)cell * C + ch * 8);
+    const T* av = reinterpret_cast<const T*>(&ra);
+    float a[8];
+    int sg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = to_f32<T>(av[i]); sg[i] = 0; }
+    const int b = off[cell], e = off[cell + 1];
+    int k = b;
+    for (; k + 8 <= e; k += 8) {        // 8 source rows in flight
+      int id[8];
+      uint4 ro[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) id[j] = src[k + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ro[j] = *reinterpret_cast<const uint4*>(orig + (size_t)id[j] * C + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const T* ov = reinterpret_cast<const T*>(&ro[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = to_f32<T>(ov[i]) - a[i];
+          la += (double)fabsf(d);
+          sg[i] += (d > 0.f) - (d < 0.f);
+        }
+      }
+    }
+    for (; k < e; ++k) {
+      const uint4 ro = *reinterpret_cast<const uint4*>(orig + (size_t)src[k] * C + ch * 8);
+      const T* ov = reinterpret_cast<const T*>(&ro);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = to_f32<T>(ov[i]) - a[i];
+        la += (double)fabsf(d);
+        sg[i] += (d > 0.f) - (d < 0.f);
+      }
+    }
+    const bool bg = use_bg && bgflag[cell];
+    TG o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float g = 0.f;
+      if (b < e) g += -coef_fg * (float)sg[i];
+      if (bg) g += -coef_bg * sgn[ch * 8 + i];
+      o[i] = from_f32<TG>(g * scale);
+    }
+    if (sizeof(TG) == 2) {
+      *reinterpret_cast<uint4*>(grad + (size_t)cell * C + ch * 8) = *reinterpret_cast<uint4*>(o);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) grad[(size_t)cell * C + ch * 8 + i] = o[i];
+    }
+  }
+  la = block_sum(la, sm);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = la;
+}
+
 }  // namespace dh
 
 using namespace dh;
@@ -347,12 +501,12 @@ extern "C" int dh_energy_fwd_bwd(const void* cur, const void* orig, int dtype, i
                          COLSUM_S, w.part1);
       hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 256), COLSUM_S), dim3(256), 0, st, w.cur, bg_trans, n_bg_trans, C,
                          COLSUM_S, w.part2);
-      hipLaunchKernelGGL(k_global_diff, dim3(1), dim3(256), 0, st, w.part1, w.part2, COLSUM_S, C, n_bg_orig,
-                         n_bg_trans, w.sgn, w.bg_part);
+      hipLaunchKernelGGL(k_global_diff, dim3(cdiv(C, GD_BLOCK)), dim3(GD_BLOCK), 0, st, w.part1, w.part2, COLSUM_S, C,
+                         n_bg_orig, n_bg_trans, w.sgn, w.bg_part);
       bg_norm = 1.f / (float)C;
       hipLaunchKernelGGL(k_global_apply, dim3(n_bg_trans), dim3(256), 0, st, bg_trans, n_bg_trans, w.sgn, C,
                          bg_w * bg_norm / (float)n_bg_trans, w.acc);
-      n_bg_part = 1;
+      n_bg_part = cdiv(C, GD_BLOCK);
     }
   } else if (n_bg_both > 0) {
     DH_REQUIRE(bg_both, "null bg list");
@@ -368,6 +522,106 @@ extern "C" int dh_energy_fwd_bwd(const void* cur, const void* orig, int dtype, i
     case DH_DTYPE_BF16: launch_store<bf16>(w.acc, grad, C, h_in, w_in, grid, grad_scale, st); break;
     default: launch_store<float>(w.acc, grad, C, h_in, w_in, grid, grad_scale, st); break;
   }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_energy_plan_bytes(int grid, int n_pairs, size_t* bytes) {
+  DH_REQUIRE(grid >= 1 && n_pairs >= 0 && bytes, "bad arguments");
+  Arena a(nullptr, (size_t)-1);
+  EnergyPlan p;
+  carve_plan(a, grid, n_pairs, p);
+  *bytes = a.off + 256;
+  return DH_OK;
+}
+
+extern "C" int dh_energy_plan_build(const int32_t* pairs, int n_pairs, const int32_t* bg_trans, int n_bg_trans, int grid,
+                                    void* plan, size_t plan_bytes, void* stream) {
+  DH_REQUIRE(plan && grid >= 1 && n_pairs >= 0 && n_bg_trans >= 0, "bad arguments");
+  DH_REQUIRE((n_pairs == 0 || pairs) && (n_bg_trans == 0 || bg_trans), "null list");
+  hipStream_t st = (hipStream_t)stream;
+  const int G2 = grid * grid;
+  Arena a(plan, plan_bytes);
+  EnergyPlan p;
+  DH_REQUIRE(carve_plan(a, grid, n_pairs, p), "plan buffer too small");
+  DH_CHECK_HIP(hipMemsetAsync(p.cnt, 0, (G2 + 1) * sizeof(int), st));
+  DH_CHECK_HIP(hipMemsetAsync(p.bgflag, 0, G2, st));
+  if (n_pairs > 0) hipLaunchKernelGGL(k_hist, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, p.cnt, p.w1, p.w2);
+  hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, p.cnt, G2, p.off, p.cursor);
+  if (n_pairs > 0) hipLaunchKernelGGL(k_fill, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, p.cursor, p.src);
+  if (n_bg_trans > 0) hipLaunchKernelGGL(k_flag_cells, dim3(cdiv(n_bg_trans, 256)), dim3(256), 0, st, bg_trans, n_bg_trans, p.bgflag);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_energy_planned_workspace_bytes(int C, int grid, size_t* bytes) {
+  DH_REQUIRE(C >= 1 && grid >= 1 && bytes, "bad arguments");
+  Arena a(nullptr, (size_t)-1);
+  PlannedWs w;
+  carve_planned(a, C, grid, w);
+  *bytes = a.off + 256;
+  return DH_OK;
+}
+
+template <class T, class TG>
+static void launch_energy_grad(const void* orig, const void* cur, const EnergyPlan& p, const PlannedWs& w, int C, int G2,
+                               float coef_fg, float coef_bg, int use_bg, float scale, void* grad, int nblocks,
+                               hipStream_t st) {
+  hipLaunchKernelGGL((k_energy_grad<T, TG>), dim3(nblocks), dim3(256), 0, st, (const T*)orig, (const T*)cur, p.off, p.src,
+                     p.bgflag, w.sgn, C, G2, coef_fg, coef_bg, use_bg, scale, (TG*)grad, w.fg_part);
+}
+
+extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int dtype, int C, int grid, const void* plan,
+                                         size_t plan_bytes, int n_pairs, const int32_t* bg_orig, int n_bg_orig,
+                                         const int32_t* bg_trans, int n_bg_trans, float fg_w, float bg_w, float grad_scale,
+                                         float* loss_out, void* grad, int grad_dtype, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  DH_REQUIRE(cur && orig && grad && plan && workspace, "null pointer");
+  DH_REQUIRE(dtype == DH_DTYPE_F16 || dtype == DH_DTYPE_BF16, "the planned path takes 16-bit activations");
+  DH_REQUIRE(grad_dtype >= 0 && grad_dtype <= 2, "bad dtype");
+  DH_REQUIRE(C >= 8 && C % 8 == 0 && C <= 2048 && grid >= 1 && n_pairs >= 0, "bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int G2 = grid * grid;
+  Arena ap(const_cast<void*>(plan), plan_bytes);
+  EnergyPlan p;
+  DH_REQUIRE(carve_plan(ap, grid, n_pairs, p), "plan buffer too small");
+  Arena aw(workspace, workspace_bytes);
+  PlannedWs w;
+  DH_REQUIRE(carve_planned(aw, C, grid, w), "workspace too small");
+
+  const float fg_norm = n_pairs > 0 ? 1.f / ((float)C * (float)n_pairs) : 0.f;
+  float bg_norm = 0.f, coef_bg = 0.f;
+  int use_bg = 0;
+  if (n_bg_orig > 0 && n_bg_trans > 0) {
+    DH_REQUIRE(bg_orig && bg_trans, "null bg list");
+    const int nthreads = (C / 8) * COLSUM_S;
+    if (dtype == DH_DTYPE_F16)
+      hipLaunchKernelGGL((k_colsum16<f16>), dim3(cdiv(nthreads, 256), 2), dim3(256), 0, st, (const f16*)orig, bg_orig, n_bg_orig,
+                         w.part1, (const f16*)cur, bg_trans, n_bg_trans, w.part2, C, COLSUM_S);
+    else
+      hipLaunchKernelGGL((k_colsum16<bf16>), dim3(cdiv(nthreads, 256), 2), dim3(256), 0, st, (const bf16*)orig, bg_orig,
+                         n_bg_orig, w.part1, (const bf16*)cur, bg_trans, n_bg_trans, w.part2, C, COLSUM_S);
+    hipLaunchKernelGGL(k_global_diff, dim3(cdiv(C, GD_BLOCK)), dim3(GD_BLOCK), 0, st, w.part1, w.part2, COLSUM_S, C, n_bg_orig,
+                       n_bg_trans, w.sgn, w.bg_part);
+    bg_norm = 1.f / (float)C;
+    coef_bg = bg_w * bg_norm / (float)n_bg_trans;
+    use_bg = 1;
+  }
+  const int cpb = 256 / (C / 8);
+  const int nblocks = cdiv(G2, cpb);
+  const float coef_fg = fg_w * fg_norm;
+#define DH_EG(T_)                                                                                                          \
+  do {                                                                                                                     \
+    if (grad_dtype == DH_DTYPE_F16) launch_energy_grad<T_, f16>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st);        \
+    else if (grad_dtype == DH_DTYPE_BF16) launch_energy_grad<T_, bf16>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st); \
+    else launch_energy_grad<T_, float>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st);    \
+  } while (0)
+  if (dtype == DH_DTYPE_F16) DH_EG(f16);
+  else DH_EG(bf16);
+#undef DH_EG
+  if (loss_out)
+    hipLaunchKernelGGL(k_final_loss, dim3(1), dim3(256), 0, st, w.fg_part, n_pairs > 0 ? nblocks : 0, fg_norm, w.bg_part,
+                       use_bg ? cdiv(C, GD_BLOCK) : 0, bg_norm, fg_w, bg_w, loss_out);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

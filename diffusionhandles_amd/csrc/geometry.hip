@@ -36,30 +36,42 @@ __global__ void k_unproject(const float* depth, int res, const float* gx, const 
 }
 
 // NumPy's mean over an [N,3] float32 array along axis 0: sequential float32 accumulation in
-// row order, then / float32(N).  One wave; lanes 0..2 own one coordinate each.
-__global__ void k_centroid(const float* depth, const int* fg_pix, int n, int res, const float* gx, const float* gy,
-                           float ifx, float ify, float* cen) {
-  int lane = threadIdx.x;
-  if (lane >= 3) return;
+// row order, then / float32(N).  The additions are inherently serial (bit-exact order); the unprojection is
+// not: the whole workgroup stages the next 1024 points into LDS while lanes 0..2 (one coordinate each)
+// fold the previous 1024 in order.
+constexpr int CEN_CHUNK = 1024;
+__global__ void __launch_bounds__(CEN_CHUNK) k_centroid(const float* depth, const int* fg_pix, int n, int res, const float* gx,
+                                                         const float* gy, float ifx, float ify, float* cen) {
+  __shared__ float sv[2][3][CEN_CHUNK];
+  const int t = threadIdx.x;
   float acc = 0.f;
-  int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float X, Y, Z;
-      unproject_px(depth, fg_pix[i + k], res, gx, gy, ifx, ify, X, Y, Z);
-      v[k] = lane == 0 ? X : (lane == 1 ? Y : Z);
+  const int nchunks = (n + CEN_CHUNK - 1) / CEN_CHUNK;
+  for (int c = 0; c <= nchunks; ++c) {
+    if (c < nchunks) {
+      const int i = c * CEN_CHUNK + t;
+      if (i < n) {
+        float X, Y, Z;
+        unproject_px(depth, fg_pix[i], res, gx, gy, ifx, ify, X, Y, Z);
+        sv[c & 1][0][t] = X; sv[c & 1][1][t] = Y; sv[c & 1][2][t] = Z;
+      }
     }
+    if (c > 0 && t < 3) {
+      const int base = (c - 1) * CEN_CHUNK;
+      const int m = n - base < CEN_CHUNK ? n - base : CEN_CHUNK;
+      const float* v = sv[(c - 1) & 1][t];
+      int k = 0;
+      for (; k + 8 <= m; k += 8) {
+        float u[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc = acc + v[k];
+        for (int j = 0; j < 8; ++j) u[j] = v[k + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = acc + u[j];
+      }
+      for (; k < m; ++k) acc = acc + v[k];
+    }
+    __syncthreads();
   }
-  for (; i < n; ++i) {
-    float X, Y, Z;
-    unproject_px(depth, fg_pix[i], res, gx, gy, ifx, ify, X, Y, Z);
-    acc = acc + (lane == 0 ? X : (lane == 1 ? Y : Z));
-  }
-  cen[lane] = (float)((double)acc / (double)(float)n);
+  if (t < 3) cen[t] = (float)((double)acc / (double)(float)n);
 }
 
 __device__ __forceinline__ unsigned long long sortable_f64(double z) {
@@ -464,7 +476,7 @@ extern "C" int dh_unproject(const float* depth, int res, const float* grid_x, co
 extern "C" int dh_masked_centroid(const float* depth, const int32_t* fg_pix, int n_fg, int res, const float* grid_x,
                                   const float* grid_y, float inv_fx, float inv_fy, float* centroid, void* stream) {
   DH_REQUIRE(depth && fg_pix && centroid && n_fg > 0, "bad arguments");
-  hipLaunchKernelGGL(k_centroid, dim3(1), dim3(64), 0, (hipStream_t)stream, depth, fg_pix, n_fg, res, grid_x, grid_y,
+  hipLaunchKernelGGL(k_centroid, dim3(1), dim3(CEN_CHUNK), 0, (hipStream_t)stream, depth, fg_pix, n_fg, res, grid_x, grid_y,
                      inv_fx, inv_fy, centroid);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -500,7 +512,7 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
   DH_CHECK_HIP(hipMemsetAsync(w.minmax, 0, (size_t)2 * K * sizeof(unsigned int), st));
   for (int e = 0; e < K; ++e) DH_CHECK_HIP(hipMemsetAsync(w.minmax + 2 * e, 0xff, sizeof(unsigned int), st));
 
-  hipLaunchKernelGGL(k_centroid, dim3(1), dim3(64), 0, st, depth, fg_pix, n_fg, res, grid_x, grid_y, inv_fx, inv_fy,
+  hipLaunchKernelGGL(k_centroid, dim3(1), dim3(CEN_CHUNK), 0, st, depth, fg_pix, n_fg, res, grid_x, grid_y, inv_fx, inv_fy,
                      w.cen);
   hipLaunchKernelGGL(k_points, dim3(cdiv(P, 256), K), dim3(256), 0, st, depth, bg_depth, fg_pix, n_fg, res, grid_x,
                      grid_y, inv_fx, inv_fy, fx, fy, w.xf, w.cen, w.zbuf, w.pix, w.key);

@@ -111,7 +111,8 @@ __device__ __forceinline__ float silu_grad(float z) {
 //   normalising; block x == 0 also publishes (mean, rstd) for backward.
 // partial layout: [b][g][3][S]  (n | mean | M2 planes)
 constexpr int GN_GB = 4;       // groups per partial workgroup
-__host__ __device__ inline int gn_slices(int HW) { int s = HW / 4; return s < 1 ? 1 : (s > 16 ? 16 : s); }
+static int gn_slice_cap() { static const int v = getenv("DH_GN_SLICES") ? atoi(getenv("DH_GN_SLICES")) : 16; return v; }
+inline int gn_slices(int HW) { const int cap = gn_slice_cap(); int s = HW / 4; return s < 1 ? 1 : (s > cap ? cap : s); }
 
 template <class T, bool BWD>
 __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, const float* gamma, const float* beta,

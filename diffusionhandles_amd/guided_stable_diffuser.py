@@ -21,7 +21,8 @@ import torch
 
 from . import _lib
 from .guided_diffuser import GuidedDiffuser
-from .losses import energy_and_grad, process_correspondences as _process_correspondences
+from .losses import (EnergyPlan, energy_and_grad, energy_and_grad_planned,
+                     process_correspondences as _process_correspondences)
 from .scheduler import DDIMScheduler
 from .unet import HipUNet, SD2_DEPTH
 
@@ -279,7 +280,19 @@ class GuidedStableDiffuser(GuidedDiffuser):
         st.orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
         st.size = (st.orig[2].shape[1], st.orig[2].shape[2])
         st.n_pairs = len(st.pc["original_x"])
+        # default configuration: the energy runs through a per-edit plan (CSR + background flags built once)
+        st.plan = None
+        if (self.conf.fg_patch_size == 1 and self.conf.bg_loss_type == "global_avg"
+                and all(o.shape[1] == st.size[0] and o.shape[2] == st.size[1] for o in st.orig[1:])):
+            st.plan = EnergyPlan(st.pc, st.size[0], self.device)
         return st
+
+    def _energy_grad(self, st, k, act, t_idx, fgw, bgw):
+        """d(energy of layer k)/d(act) * grad_scale, act [h,w,C] channels-last."""
+        if st.plan is not None and act.shape[0] == st.plan.grid and act.shape[1] == st.plan.grid:
+            return energy_and_grad_planned(act, st.orig[k][t_idx], st.plan, fgw, bgw, grad_scale=self.grad_scale)[1]
+        return energy_and_grad(act, st.orig[k][t_idx], st.pc, fgw, bgw, self.conf.fg_patch_size, self.conf.bg_patch_size,
+                               st.size, self.conf.bg_loss_type, grad_scale=self.grad_scale)[1]
 
     def guided_step(self, st, x, t_idx, t, uncond, record=None):
         """One guided-denoise step (guided_stable_diffuser.py:377-479): up to num_optsteps x
@@ -295,10 +308,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
                                             want_acts=active, want_eps=False)
                 d_acts = [None, None, None]
                 for k in active:
-                    _, g = energy_and_grad(acts[k][0], st.orig[k][t_idx], st.pc, fgw[k], bgw[k], self.conf.fg_patch_size,
-                                           self.conf.bg_patch_size, st.size, self.conf.bg_loss_type,
-                                           grad_scale=self.grad_scale)
-                    d_acts[k] = g[None]
+                    d_acts[k] = self._energy_grad(st, k, acts[k][0], t_idx, fgw[k], bgw[k])[None]
                 d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
                 g_lat = d_sample[..., : x.shape[-1]].contiguous()
                 x_new = torch.empty_like(x)
@@ -331,10 +341,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
                     g_all = torch.empty_like(acts[k])
                     for e, st in enumerate(sts):
                         fw = fgw[k] if st.n_pairs > 0 else 0.0
-                        _, g = energy_and_grad(acts[k][e], st.orig[k][t_idx], st.pc, fw, bgw[k], self.conf.fg_patch_size,
-                                               self.conf.bg_patch_size, st.size, self.conf.bg_loss_type,
-                                               grad_scale=self.grad_scale)
-                        g_all[e].copy_(g)
+                        g_all[e].copy_(self._energy_grad(st, k, acts[k][e], t_idx, fw, bgw[k]))
                     d_acts[k] = g_all
                 d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
                 g_lat = d_sample[..., : x.shape[-1]].contiguous()

@@ -73,6 +73,53 @@ def _device_lists(pc, dev, grid):
 _WS = {}
 
 
+class EnergyPlan:
+    """Per-edit constants of the guidance energy on one cell grid: device index lists, the
+    target-cell -> source-cells CSR and the transformed-background flags (dh_energy_plan_build)."""
+
+    def __init__(self, processed_correspondences, grid, device):
+        L = _lib.lib()
+        self.grid = int(grid)
+        self.dl = _device_lists(processed_correspondences, device, self.grid)
+        self.n_pairs = int(self.dl["pairs"].shape[0])
+        nb = ctypes.c_size_t()
+        _lib.check(L.dh_energy_plan_bytes(self.grid, self.n_pairs, ctypes.byref(nb)), "dh_energy_plan_bytes")
+        self.nbytes = nb.value
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        _lib.check(L.dh_energy_plan_build(_lib.ptr(self.dl["pairs"]), self.n_pairs, _lib.ptr(self.dl["bg_trans"]),
+                                          self.dl["bg_trans"].numel(), self.grid, _lib.ptr(self.buf), self.nbytes,
+                                          _lib.stream_ptr()), "dh_energy_plan_build")
+        self._ws = {}
+
+    def workspace(self, C):
+        if C not in self._ws:
+            nb = ctypes.c_size_t()
+            _lib.check(_lib.lib().dh_energy_planned_workspace_bytes(C, self.grid, ctypes.byref(nb)))
+            self._ws[C] = (torch.empty(nb.value, dtype=torch.uint8, device=self.buf.device), nb.value)
+        return self._ws[C]
+
+
+def energy_and_grad_planned(act, act_orig, plan, fg_weight, bg_weight, grad_scale=1.0, want_loss=False):
+    """Default-configuration evaluation through a prebuilt EnergyPlan: act / act_orig [grid,grid,C] channels-last,
+    16-bit, contiguous.  Returns (loss[3] or None, grad like act)."""
+    _lib.require_gpu(act)
+    h, w, C = act.shape
+    if h != plan.grid or w != plan.grid or act.dtype not in (torch.float16, torch.bfloat16) or act_orig.dtype != act.dtype:
+        raise ValueError("planned energy: maps must be 16-bit [grid, grid, C] of one dtype")
+    a = act.detach().contiguous()
+    o = act_orig.detach().contiguous()
+    grad = torch.empty_like(a)
+    loss = torch.zeros(3, dtype=torch.float32, device=a.device) if want_loss else None
+    ws, wsb = plan.workspace(C)
+    dl = plan.dl
+    _lib.check(_lib.lib().dh_energy_fwd_bwd_planned(
+        _lib.ptr(a), _lib.ptr(o), _lib.DTYPE_CODE[a.dtype], C, plan.grid, _lib.ptr(plan.buf), plan.nbytes, plan.n_pairs,
+        _lib.ptr(dl["bg_orig"]), dl["bg_orig"].numel(), _lib.ptr(dl["bg_trans"]), dl["bg_trans"].numel(),
+        float(fg_weight), float(bg_weight), float(grad_scale), _lib.ptr(loss), _lib.ptr(grad),
+        _lib.DTYPE_CODE[a.dtype], _lib.ptr(ws), wsb, _lib.stream_ptr()), "dh_energy_fwd_bwd_planned")
+    return loss, grad
+
+
 def energy_and_grad(act, act_orig, processed_correspondences, fg_weight, bg_weight, fg_patch_size=1,
                     bg_patch_size=1, activations_size=(GRID, GRID), bg_loss_type="global_avg", grad_scale=1.0,
                     grad_dtype=None, channels_last=True):

@@ -127,6 +127,22 @@ int dh_energy_fwd_bwd(const void* cur, const void* orig, int dtype, int C, int h
                       float grad_scale, float* loss_out, void* grad, int grad_dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Planned form of the same evaluation for the default configuration (maps already at the cell grid,
+ * fg_patch 1, bg 'global_avg' -- config/default.yaml:5-9), 16-bit activations.  The correspondences of an
+ * edit are fixed over its 38 x 3 evaluations, so the target-cell -> source-cells CSR and the
+ * transformed-background flags are built ONCE (dh_energy_plan_build) and every evaluation is three kernels
+ * that read the activations once in their own dtype.  Same arithmetic per element as dh_energy_fwd_bwd:
+ * the gradient is bit-identical.  loss_out may be NULL (the guided loop only needs the gradient). */
+int dh_energy_plan_bytes(int grid, int n_pairs, size_t* bytes);
+int dh_energy_plan_build(const int32_t* pairs, int n_pairs, const int32_t* bg_trans, int n_bg_trans, int grid,
+                         void* plan, size_t plan_bytes, void* stream);
+int dh_energy_planned_workspace_bytes(int C, int grid, size_t* bytes);
+int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int dtype, int C, int grid,
+                              const void* plan, size_t plan_bytes, int n_pairs,
+                              const int32_t* bg_orig, int n_bg_orig, const int32_t* bg_trans, int n_bg_trans,
+                              float fg_w, float bg_w, float grad_scale, float* loss_out, void* grad,
+                              int grad_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* --------------------------------------------------------------------------------------
  * SD-2-depth U-Net engine (model/unet_2d_condition.py:809-1198 and the block files it
  * calls): forward with the three decoder activation captures, and the backward pass to the

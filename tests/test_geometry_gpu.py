@@ -174,6 +174,31 @@ def test_energy_fp16_and_scaling():
     assert torch.equal(grad, grad2)
 
 
+def test_energy_planned_path_is_bit_identical_to_general_path():
+    """dh_energy_fwd_bwd_planned (CSR built once per edit, 16-bit reads, 3 kernels) vs dh_energy_fwd_bwd:
+    identical gradient bits, loss within f32 rounding; also empty-pair and empty-background edge cases."""
+    from diffusionhandles_amd import losses as LS
+    dev = _dev()
+    gen = torch.Generator().manual_seed(9)
+    for dtype in (torch.float16, torch.bfloat16):
+        for C in (320, 640, 1280):
+            for n in (7000, 0):
+                corr = torch.stack([torch.randint(40, 470, (n,), generator=gen) for _ in range(4)], dim=-1)
+                pc = LS.process_correspondences(corr, 512, 0)
+                cur = torch.randn(64, 64, C, generator=gen).to(dtype).to(dev)
+                org = torch.randn(64, 64, C, generator=gen).to(dtype).to(dev)
+                plan = LS.EnergyPlan(pc, 64, dev)
+                for fw, bw in ((3.0, 2.0), (0.0, 1.5), (2.5, 0.0)):
+                    if n == 0 and fw != 0.0:
+                        continue
+                    l0, g0 = LS.energy_and_grad(cur, org, pc, fw, bw, grad_scale=256.0)
+                    l1, g1 = LS.energy_and_grad_planned(cur, org, plan, fw, bw, grad_scale=256.0, want_loss=True)
+                    assert torch.equal(g0, g1), (dtype, C, n, fw, bw)
+                    assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+                    _, g2 = LS.energy_and_grad_planned(cur, org, plan, fw, bw, grad_scale=256.0)
+                    assert torch.equal(g1, g2)
+
+
 def test_set_foreground_laplacian_blend_vs_oracle():
     """set_foreground: f64 CG on the GPU vs the oracle's sparse direct solve; depth values O(1..6) -> 1e-4."""
     from oracle import depth_ref as D
