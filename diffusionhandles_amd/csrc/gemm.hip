@@ -121,24 +121,37 @@ enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
 // issues half of the DMA pieces, and the groups' accumulators are added through LDS before the epilogue.  Same
 // LDS and DMA traffic as WG = 1 but two waves per SIMD, so one wave's ds_read / barrier waits sit under the
 // other's MFMAs (a single image fills the chip with at most one 4-wave block per CU).
-template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
-__global__ void __launch_bounds__(256 * WG) k_gemm_dma(const GemmK p) {
+// KG > 1: KG groups of four waves with a ring each work on DISJOINT K ranges of the block's tile (split-K inside
+// the workgroup): a GEMM with few output tiles and a long K loop is bounded by the serial depth of that loop
+// (~0.6 us per K tile), and this divides the depth by KG without partial slabs in HBM or a reduce launch.
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
+__global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
+  static_assert(WG == 1 || KG == 1, "one kind of wave grouping per instantiation");
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int NPA = BM / 32 / WG, NPB = BN / 32 / WG;     // 1-KiB pieces per wave per stage
   constexpr int NP = NPA + NPB;
   constexpr int STAGE = (BM + BN) * 128;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_all[KG * ST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   const int grp = WG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;     // wave-uniform (feeds m0 through dma16)
+  const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
+  unsigned char* smem = smem_all + kg * (ST * STAGE);
   const int wm = wave >> 1, wn = wave & 1, ln = lane & 31, hi = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * p.k_per_split;
+  int kbeg = blockIdx.z * p.k_per_split;
   int kend = kbeg + p.k_per_split;
   if (kend > p.K) kend = p.K;
-  const int ntiles = (kend - kbeg) / BK;
+  int ntiles = (kend - kbeg) / BK;
+  int loop_tiles = ntiles;                          // trip count of the K loop (uniform over the block: barriers)
+  if (KG > 1) {
+    loop_tiles = (ntiles + KG - 1) / KG;
+    kbeg += kg * loop_tiles * BK;
+    ntiles -= kg * loop_tiles;
+    ntiles = ntiles < 0 ? 0 : (ntiles > loop_tiles ? loop_tiles : ntiles);
+  }
   const T* Ag = reinterpret_cast<const T*>(p.A);
-  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all) + kg * (ST * STAGE);
   const int prow = lane >> 3;                       // row of this lane inside a piece
   // logical chunk this lane fetches (swizzle on the source): piece rows are 8 (wave + 4 j) + prow, so ((row >> 1) & 7)
   const int lchunk = (lane & 7) ^ (4 * (wave & 1) + (prow >> 1));
@@ -238,10 +251,11 @@ __global__ void __launch_bounds__(256 * WG) k_gemm_dma(const GemmK p) {
 
   constexpr int KK = BK / 16 / WG;                // k-steps of a tile multiplied by this wave group
   const int kk0 = grp * KK;
-  for (int kt = 0; kt < ntiles; ++kt) {
+  for (int kt = 0; kt < loop_tiles; ++kt) {
     // tile kt has landed once at most (ST-2) later tiles' loads are still outstanding
     if (ntiles - 1 - kt >= ST - 2) wait_vmcnt<NP * (ST - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (KG > 1 && kt >= ntiles) continue;           // a group with a shorter K range only keeps the barrier count
     const bool more = ABL != 2 && kt + ST - 1 < ntiles;
     const int nkt = kt + ST - 1, nstage = nkt % ST;
     if (ABL == 1) { if (more) issue(nkt, nstage); continue; }
@@ -274,27 +288,35 @@ __global__ void __launch_bounds__(256 * WG) k_gemm_dma(const GemmK p) {
     if (more) next_tile();
   }
 
-  if (WG > 1) {
-    // add the second group's partial sums: f32 through the (now idle) stage ring, [value][lane] per wave
-    static_assert(WG <= 2 && TM * TN * 16 * 64 * 4 * 4 <= ST * STAGE, "merge buffer does not fit the stage ring");
-    float* cb = reinterpret_cast<float*>(smem) + wave * (TM * TN * 16 * 64) + lane;
+  if (WG > 1 || KG > 1) {
+    // add the other groups' partial sums in group order: f32 through the (now idle) rings, [value][lane] per wave
+    constexpr int NG = WG * KG;
+    constexpr int SLOT = TM * TN * 16 * 64;
+    static_assert((NG - 1) * 4 * SLOT * 4 <= KG * ST * STAGE, "merge buffer does not fit the stage rings");
+    const int g = WG > 1 ? grp : kg;
+    float* cb = reinterpret_cast<float*>(smem_all);
     __syncthreads();
-    if (grp == 1) {
+    if (g > 0) {
+      float* slot = cb + ((g - 1) * 4 + wave) * SLOT + lane;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) cb[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r) slot[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
     }
     __syncthreads();
-    if (grp == 1) return;
+    if (g > 0) return;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int og = 1; og < NG; ++og) {
+      const float* slot = cb + ((og - 1) * 4 + wave) * SLOT + lane;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += cb[((i * TN + j) * 16 + r) * 64];
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((i * TN + j) * 16 + r) * 64];
+    }
   }
 
 #pragma unroll
@@ -351,11 +373,13 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
   static const int kSplitTiles = getenv("DH_SPLITK_TILES") ? atoi(getenv("DH_SPLITK_TILES")) : 200;
   static const int kSplitMinK = getenv("DH_SPLITK_MINKT") ? atoi(getenv("DH_SPLITK_MINKT")) : 24;
   static const int kSplitTarget = getenv("DH_SPLITK_TARGET") ? atoi(getenv("DH_SPLITK_TARGET")) : 256;
-  static const int kBigTiles = getenv("DH_BIG_TILES") ? atoi(getenv("DH_BIG_TILES")) : 0;
+  static const int kBigTiles = getenv("DH_BIG_TILES") ? atoi(getenv("DH_BIG_TILES")) : 48;
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
-  if (k.M <= 64 || cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles) { BM = 64; BN = 64; }
-  const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   const int ktiles = k.K / BK;
+  // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles, K split over four
+  // wave groups inside the workgroup (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
+  if (k.M <= 64 || (cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles && ktiles < kSplitMinK)) { BM = 64; BN = 64; }
+  const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
   if (k.partial && tiles < kSplitTiles && ktiles >= kSplitMinK) {
     splits = kSplitTarget / tiles;
@@ -398,18 +422,29 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
   } while (0)
   // two wave groups per block: measured ahead only on the 128x64 tile with a long K loop (conv 4096x320x2880:
   // 28.5 -> 24.9 us, x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge)
+#define DH_LAUNCH_GEMM_KG(BM_, BN_, ST_, KG_)                                                                               \
+  do {                                                                                                                      \
+    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_DENSE, 0, 1, KG_>), grid, dim3(256 * KG_), 0, st, k);        \
+    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1, 0, 1, KG_>), grid, dim3(256 * KG_), 0, st, k); \
+    else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC, 0, 1, KG_>), grid, dim3(256 * KG_), 0, st, k);                    \
+  } while (0)
+  static const int kKg = getenv("DH_GEMM_KG") ? atoi(getenv("DH_GEMM_KG")) : 0;
   static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 0;
-  const int wg = kWg ? kWg : (BM == 128 && BN == 64 && tiles_per_split >= 16 ? 2 : 1);
+  const int wg = kWg ? kWg : 1;
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
   if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 3 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 1>), grid, dim3(256), 0, st, k); }
+  else if (kKg != 1 && BM == 64 && tiles_per_split >= 8) DH_LAUNCH_GEMM_KG(64, 64, 2, 4);
+  else if (kKg != 1 && BM == 128 && BN == 64 && tiles_per_split >= 16) DH_LAUNCH_GEMM_KG(128, 64, 3, 2);
+  else if (kKg == 2 && BM == 128 && BN == 128) DH_LAUNCH_GEMM_KG(128, 128, 2, 2);
   else
   if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
   else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
   else DH_LAUNCH_GEMM(128, 64, 5);
 #undef DH_LAUNCH_GEMM
 #undef DH_LAUNCH_GEMM_WG
+#undef DH_LAUNCH_GEMM_KG
   if (e1) (void)hipEventRecord(e1, st);
   if (splits > 1) {
     const size_t groups = (size_t)k.M * k.N / 4;
