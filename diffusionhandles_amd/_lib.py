@@ -44,6 +44,9 @@ SIGNATURES = {
     "dh_energy_workspace_bytes": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_sz)]),
     "dh_energy_fwd_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i,
                                 c_f, c_f, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_sz, c_p]),
+    "dh_mesh_workspace_bytes": (c_i, [c_i, ctypes.POINTER(c_sz)]),
+    "dh_mesh_reproject": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p,
+                                c_sz, c_p]),
     "dh_energy_plan_bytes": (c_i, [c_i, c_i, ctypes.POINTER(c_sz)]),
     "dh_energy_plan_build": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_sz, c_p]),
     "dh_energy_planned_workspace_bytes": (c_i, [c_i, c_i, ctypes.POINTER(c_sz)]),

@@ -175,6 +175,86 @@ def transform_depth_pc(depth, bg_depth, fg_mask, intrinsics, rot_angle=None, rot
     return disp, corr
 
 
+MESH_BLUR_RADIUS = 1e-5      # depth_transform.py:152
+
+
+def mesh_xform(depth, fg_mask, intrinsics, rot_angle, rot_axis, translation):
+    """The 11 float32 numbers dh_mesh_reproject takes: unit axis, cos, sin, translation, centroid of the masked
+    points (transform_points, depth_transform.py:438-458; the centroid is the sequential float32 mean the point
+    path uses -- torch's own reduction order is not specified)."""
+    dev = _compute_device(depth)
+    res = depth.shape[-1]
+    d = depth.detach().to(dev, torch.float32).contiguous()
+    fg_pix = torch.nonzero((fg_mask.detach().to(dev)[0, 0] > 0.5).reshape(-1)).to(torch.int32).reshape(-1).contiguous()
+    gx, gy = _grids(res, res, dev)
+    ifx, ify = _inv_focal(intrinsics)
+    cen = torch.empty(3, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().dh_masked_centroid(_lib.ptr(d), _lib.ptr(fg_pix), fg_pix.numel(), res, _lib.ptr(gx), _lib.ptr(gy),
+                                             ifx, ify, _lib.ptr(cen), _lib.stream_ptr()), "dh_masked_centroid")
+    ax = np.asarray(rot_axis.detach().cpu().numpy() if isinstance(rot_axis, torch.Tensor) else rot_axis, dtype=np.float32)
+    ax = (ax / np.float32(np.linalg.norm(ax))).astype(np.float32)
+    ang = np.float32(rot_angle.item() if isinstance(rot_angle, torch.Tensor) else rot_angle)
+    theta = np.float32(ang * np.float32(np.pi / 180.0))
+    tr = translation.detach().cpu().numpy() if isinstance(translation, torch.Tensor) else np.asarray(translation)
+    c = cen.cpu().numpy()
+    return np.array([ax[0], ax[1], ax[2], np.cos(theta), np.sin(theta), tr[0], tr[1], tr[2], c[0], c[1], c[2]],
+                    dtype=np.float32)
+
+
+def transform_depth_mesh(depth, bg_depth, fg_mask, intrinsics, rot_angle=None, rot_axis=None, translation=None,
+                         use_input_depth_normalization=False, return_debug=False):
+    """depth_transform.py:91-195 with our own HIP triangle rasteriser in place of pytorch3d (parity unpinned)."""
+    if depth.dim() != 4 or depth.shape[0] != 1:
+        raise ValueError("Only batch size 1 is supported")
+    res = depth.shape[-1]
+    if depth.shape[-2] != res:
+        raise RuntimeError("square depth maps only")
+    out_dev = depth.device
+    dev = _compute_device(depth)
+    d = depth.detach().to(dev, torch.float32).contiguous()
+    bounds = None
+    if use_input_depth_normalization:
+        disp_in = 1.0 / d
+        bounds = torch.stack([disp_in.min(), disp_in.max()]).to(torch.float32).contiguous()
+    mask = (fg_mask.detach().to(dev)[0, 0] > 0.5)
+    if not bool(mask.any()):
+        lo_hi = None if bounds is None else (bounds[0], bounds[1])
+        return normalize_depth(1.0 / d, bounds=lo_hi).to(out_dev), torch.zeros((0, 4), dtype=torch.int64)
+    if rot_angle is None:
+        rot_angle = 0.0
+    if rot_axis is None:
+        rot_axis = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float32)
+    if translation is None:
+        translation = torch.tensor([0.0, 0.0, 0.0], dtype=torch.float32)
+    xf = mesh_xform(depth, fg_mask, intrinsics, rot_angle, rot_axis, translation)
+    L = _lib.lib()
+    bg = bg_depth.detach().to(dev, torch.float32).contiguous()
+    m8 = mask.to(torch.uint8).contiguous()
+    gx, _ = _grids(res, res, dev)
+    lin01 = torch.linspace(0, 1, res, dtype=torch.float32).to(dev)
+    ifx, _ = _inv_focal(intrinsics)
+    f = float(intrinsics.detach().to("cpu", torch.float32)[0, 0])
+    R2 = res * res
+    zmap = torch.empty(R2, dtype=torch.float32, device=dev)
+    disp = torch.empty(R2, dtype=torch.float32, device=dev)
+    flag = torch.empty(R2, dtype=torch.uint8, device=dev)
+    corr = torch.empty((R2, 4), dtype=torch.int64, device=dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    nb = ctypes.c_size_t()
+    _lib.check(L.dh_mesh_workspace_bytes(res, ctypes.byref(nb)))
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    xf_c = (ctypes.c_float * 11)(*[float(v) for v in xf])
+    _lib.check(L.dh_mesh_reproject(_lib.ptr(d), _lib.ptr(bg), _lib.ptr(m8), res, _lib.ptr(gx), _lib.ptr(lin01), ifx, f,
+                                   ctypes.cast(xf_c, ctypes.c_void_p), _lib.ptr(bounds), float(MESH_BLUR_RADIUS),
+                                   _lib.ptr(zmap), _lib.ptr(disp), _lib.ptr(flag), _lib.ptr(corr), _lib.ptr(counts),
+                                   _lib.ptr(ws), nb.value, _lib.stream_ptr()), "dh_mesh_reproject")
+    n = int(counts[0].item())
+    out = disp.view(1, 1, res, res).to(out_dev), corr[:n].cpu()
+    if return_debug:
+        return out + (dict(zmap=zmap.view(res, res), fg_flag=flag.view(res, res), xform=xf),)
+    return out
+
+
 def transform_depth(depth, bg_depth, fg_mask, intrinsics, rot_angle=None, rot_axis=None, translation=None,
                     use_input_depth_normalization=False, depth_transform_mode="pc"):
     """Same signature and return value as the reference's transform_depth (depth_transform.py:73-89)."""
@@ -182,8 +262,8 @@ def transform_depth(depth, bg_depth, fg_mask, intrinsics, rot_angle=None, rot_ax
         return transform_depth_pc(depth, bg_depth, fg_mask, intrinsics, rot_angle, rot_axis, translation,
                                   use_input_depth_normalization)
     if depth_transform_mode == "mesh":
-        raise NotImplementedError("depth_transform_mode='mesh' (pytorch3d rasteriser) is not built yet; "
-                                  "the z-buffered point path ('pc') replaces it")
+        return transform_depth_mesh(depth, bg_depth, fg_mask, intrinsics, rot_angle, rot_axis, translation,
+                                    use_input_depth_normalization)
     raise ValueError(f"Unknown depth transform mode '{depth_transform_mode}'.")
 
 

@@ -107,6 +107,27 @@ int dh_cells_from_correspondences(const int64_t* corr, int n, int img_res, int g
                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* --------------------------------------------------------------------------------------
+ * depth_transform_mode = 'mesh' (depth_transform.py:91-195 + depth_to_mesh :30-71 + the pytorch3d
+ * renderer outputs 'world_position' / 'flat_vertex_color'): per-pixel-quad triangulation of the
+ * background depth and of the rigidly moved foreground depth (transform_points :438-458, float32),
+ * nearest-z rasterisation with back-face culling, blur_radius coverage, perspective-correct clipped
+ * barycentrics.  pytorch3d is not in the reference tree: parity unpinned (oracle/mesh_ref.py restates
+ * the published rule; validated against the point z-buffer on smooth depth).
+ *   grid   [res] f32 = linspace(-1,1,res), lin01 [res] f32 = linspace(0,1,res) (host torch values)
+ *   xform  [11] f32 host: unit axis x3, cos, sin, translation x3, centroid of the masked points x3
+ *   bounds NULL or device {lo, hi} of the input disparity (use_input_depth_normalization)
+ * Outputs: zmap [res^2] f32 rendered depth, disparity [res^2] f32 in [0,255], fg_flag [res^2] u8,
+ *          corr [<= res^2][4] i64 (src_x, src_y, tgt_x, tgt_y) in row-major target order,
+ *          counts[0] = number of correspondences.
+ * ------------------------------------------------------------------------------------ */
+int dh_mesh_workspace_bytes(int res, size_t* bytes);
+int dh_mesh_reproject(const float* depth, const float* bg_depth, const uint8_t* fg_mask, int res,
+                      const float* grid, const float* lin01, float inv_f, float f, const float* xform,
+                      const float* bounds, float blur_radius, float* zmap, float* disparity,
+                      uint8_t* fg_flag, int64_t* corr, int32_t* counts, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------------------
  * Guidance energy (losses.py:4-84) on channels-last maps [h][w][C].
  * One call evaluates, for ONE activation layer,
  *     loss = fg_w * fg_term + bg_w * bg_term

@@ -152,3 +152,28 @@ def test_laplacian_blend_matches_reference(golden):
     g9 = golden("g9_misc.npz")
     out = D.laplacian_blend(g9["poisson_img"].copy(), g9["laplacian_bg"], g9["poisson_mask"].astype(bool))
     assert np.allclose(out, g9["laplacian_out"], atol=1e-9)
+
+
+def test_mesh_oracle_identity_transform_is_a_near_identity_map():
+    """oracle/mesh_ref.py (parity unpinned, see its header): with no motion every foreground pixel must map to
+    itself up to the half-pixel difference between the unprojection grid (edge-aligned linspace) and the
+    rasteriser's pixel centres, the foreground flag must reproduce the mask interior, and depth must be kept."""
+    import torch
+    from oracle import mesh_ref as M
+    from diffusionhandles_amd.synthetic import make_scene
+    res = 48
+    depth, bg_depth, mask = make_scene(res)
+    f = 1.0 / np.tan(np.radians(27.5))
+    gx = torch.linspace(-1, 1, res, dtype=torch.float32).numpy()
+    lin01 = torch.linspace(0, 1, res, dtype=torch.float32).numpy()
+    m = mask[0, 0].numpy() > 0.5
+    xf = np.array([0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 2.5], dtype=np.float32)
+    out = M.mesh_reproject(depth[0, 0].numpy(), bg_depth[0, 0].numpy(), m, gx, lin01, np.float32(1.0 / f), np.float32(f), xf)
+    c = out["corr"]
+    assert len(c) > 0.8 * m.sum()
+    assert np.abs(c[:, 0] - c[:, 2]).max() <= 1 and np.abs(c[:, 1] - c[:, 3]).max() <= 1
+    inner = m & np.roll(m, 1, 0) & np.roll(m, -1, 0) & np.roll(m, 1, 1) & np.roll(m, -1, 1)
+    assert out["fg_flag"][inner].all()
+    far = ~(m | np.roll(m, 2, 0) | np.roll(m, -2, 0) | np.roll(m, 2, 1) | np.roll(m, -2, 1))
+    assert not out["fg_flag"][far].any()
+    assert np.abs(out["zmap"][inner] - depth[0, 0].numpy()[inner]).max() < 0.05
