@@ -326,7 +326,7 @@ void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float*
 constexpr int LN_MAXCH = 8;
 
 template <class T>
-__global__ void k_ln_fwd(const T* x, const float* gamma, const float* beta, T* y, float* stats, int rows, int C,
+__global__ void __launch_bounds__(256) k_ln_fwd(const T* x, const float* gamma, const float* beta, T* y, float* stats, int rows, int C,
                          float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -374,21 +374,28 @@ __global__ void k_ln_fwd(const T* x, const float* gamma, const float* beta, T* y
 }
 
 template <class T>
-__global__ void k_ln_bwd(const T* x, const T* dy, const float* gamma, const float* stats, const T* add, T* dx,
+__global__ void __launch_bounds__(256) k_ln_bwd(const T* x, const T* dy, const float* gamma, const float* stats, const T* add, T* dx,
                          int rows, int C) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = C / 8;
   const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
-  uint4 rx[LN_MAXCH], rd[LN_MAXCH];
+  uint4 rx[LN_MAXCH], rd[LN_MAXCH], ra[LN_MAXCH];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
+  for (int k = 0; k < LN_MAXCH; ++k) {       // every load of the row is issued before the first reduction
     const int ch = lane + 64 * k;
     if (ch < nch) {
       rx[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * C + ch * 8);
       rd[k] = *reinterpret_cast<const uint4*>(dy + (size_t)row * C + ch * 8);
+      ra[k] = add ? *reinterpret_cast<const uint4*>(add + (size_t)row * C + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
       const T* xv = reinterpret_cast<const T*>(&rx[k]);
       const T* dv = reinterpret_cast<const T*>(&rd[k]);
 #pragma unroll
@@ -408,9 +415,7 @@ __global__ void k_ln_bwd(const T* x, const T* dy, const float* gamma, const floa
     if (ch < nch) {
       const T* xv = reinterpret_cast<const T*>(&rx[k]);
       const T* dv = reinterpret_cast<const T*>(&rd[k]);
-      uint4 ra = make_uint4(0, 0, 0, 0);
-      if (add) ra = *reinterpret_cast<const uint4*>(add + (size_t)row * C + ch * 8);
-      const T* av = reinterpret_cast<const T*>(&ra);
+      const T* av = reinterpret_cast<const T*>(&ra[k]);
       T o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
