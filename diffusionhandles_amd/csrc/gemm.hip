@@ -60,6 +60,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   int act_silu;
   float* partial;
   int splits, k_per_split;
+  float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
 };
 
 constexpr int BK = 64;
@@ -90,6 +91,16 @@ __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, flo
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(v[i]);
   *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = *reinterpret_cast<uint2*>(o);
+}
+
+// the same epilogue for one element (used for the GroupNorm pivots of k_splitk_reduce_gn)
+template <class T>
+__device__ __forceinline__ float epilogue_scalar(const GemmK& p, int m, int n, float v) {
+  if (p.bias) v += p.bias[n];
+  if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.rowvec_ld + n];
+  if (p.act_silu) v = v / (1.f + __expf(-v));
+  if (p.R) v += to_f32<T>(reinterpret_cast<const T*>(p.R)[(size_t)m * p.ldr + n]);
+  return to_f32<T>(from_f32<T>(v));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,8 +378,121 @@ __global__ void k_splitk_reduce(const GemmK p) {
   epilogue_store<T>(p, m, n, s.x, s.y, s.z, s.w);
 }
 
+// split-K reduce fused with the GroupNorm slice statistics of its output (the next op of a resnet's conv is a
+// GroupNorm): workgroup = (row slice, 4 groups, image) like k_gn_partial; a thread sums the slabs of 8 channels of a
+// row, applies the epilogue, stores the 16-bit result and accumulates the pivot-shifted sums of the ROUNDED values.
 template <class T>
-static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
+__global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
+  __shared__ float sm_piv[GN_GB];
+  __shared__ float sm_red[4][2 * GN_GB];
+  const int HW = p.gn_HW, G = p.gn_G, S = p.gn_S;
+  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = p.N / G;
+  const int W = GN_GB * cpg, nch = W / 8;
+  const int RP = (int)blockDim.x / nch;
+  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
+  const size_t slab = (size_t)p.M * p.N;
+  // sums are NOT pivot-shifted here (a pivot would cost a dependent pass over the slabs before the main one): conv /
+  // linear outputs are zero-centred to within a few standard deviations, where E[x^2] - E[x]^2 over the <= 10^4
+  // elements of a slice is accurate to ~1e-6 relative in f32; slices are merged with Chan's formula in the apply kernel
+  if ((int)threadIdx.x < GN_GB) sm_piv[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int rr = threadIdx.x / nch, ch = threadIdx.x - rr * nch;
+  float ga[GN_GB], gq[GN_GB];
+#pragma unroll
+  for (int gl = 0; gl < GN_GB; ++gl) { ga[gl] = 0.f; gq[gl] = 0.f; }
+  const int n = g0 * cpg + ch * 8;
+  if (rr < RP && n < p.N) {
+    int gi[8];
+    float av[8], qv[8], pv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      gi[i] = (ch * 8 + i) / cpg;
+      av[i] = 0.f; qv[i] = 0.f; pv[i] = 0.f;
+#pragma unroll
+      for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? sm_piv[gl] : pv[i];
+    }
+    float bias8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias8[i] = p.bias ? p.bias[n + i] : 0.f;
+    for (int r = r0 + rr; r < r1; r += RP) {
+      const int m = b * HW + r;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+      const float* pp = p.partial + (size_t)m * p.N + n;
+      int z = 0;
+      for (; z + 4 <= p.splits; z += 4) {             // four slabs in flight; added in slab order
+        float4 x0[4], x1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x0[j] = *reinterpret_cast<const float4*>(pp + (size_t)(z + j) * slab);
+          x1[j] = *reinterpret_cast<const float4*>(pp + (size_t)(z + j) * slab + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[0] += x0[j].x; v[1] += x0[j].y; v[2] += x0[j].z; v[3] += x0[j].w;
+          v[4] += x1[j].x; v[5] += x1[j].y; v[6] += x1[j].z; v[7] += x1[j].w;
+        }
+      }
+      for (; z < p.splits; ++z) {
+        const float4 x0 = *reinterpret_cast<const float4*>(pp + (size_t)z * slab);
+        const float4 x1 = *reinterpret_cast<const float4*>(pp + (size_t)z * slab + 4);
+        v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w;
+        v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += bias8[i];
+      if (p.rowvec) {
+        const float* rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += rv[i];
+      }
+      if (p.act_silu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
+      }
+      if (p.R) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n);
+        const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += to_f32<T>(rv[i]);
+      }
+      T o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        o[i] = from_f32<T>(v[i]);
+        const float d = to_f32<T>(o[i]) - pv[i];
+        av[i] += d; qv[i] += d * d;
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = *reinterpret_cast<uint4*>(o);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int gl = 0; gl < GN_GB; ++gl) {
+        ga[gl] += gi[i] == gl ? av[i] : 0.f;
+        gq[gl] += gi[i] == gl ? qv[i] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int gl = 0; gl < GN_GB; ++gl) { ga[gl] = wave_sum(ga[gl]); gq[gl] = wave_sum(gq[gl]); }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int gl = 0; gl < GN_GB; ++gl) { sm_red[threadIdx.x >> 6][2 * gl] = ga[gl]; sm_red[threadIdx.x >> 6][2 * gl + 1] = gq[gl]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < GN_GB && g0 + (int)threadIdx.x < G) {
+    const int gl = threadIdx.x, g = g0 + gl;
+    float sa = 0.f, sq = 0.f;
+    for (int w = 0; w < 4; ++w) { sa += sm_red[w][2 * gl]; sq += sm_red[w][2 * gl + 1]; }
+    const float cnt = (float)(r1 - r0) * (float)cpg;
+    float* o = p.gn_part + ((size_t)(b * G + g) * 3) * S + s;
+    o[0] = cnt; o[S] = sm_piv[gl] + sa / cnt; o[2 * S] = sq - sa * sa / cnt;
+  }
+}
+
+template <class T>
+static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn_done) {
   // tile / split-K policy (environment overrides are for tuning runs only)
   static const int kSplitTiles = getenv("DH_SPLITK_TILES") ? atoi(getenv("DH_SPLITK_TILES")) : 200;
   static const int kSplitMinK = getenv("DH_SPLITK_MINKT") ? atoi(getenv("DH_SPLITK_MINKT")) : 24;
@@ -447,8 +571,15 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st) {
 #undef DH_LAUNCH_GEMM_KG
   if (e1) (void)hipEventRecord(e1, st);
   if (splits > 1) {
-    const size_t groups = (size_t)k.M * k.N / 4;
-    hipLaunchKernelGGL((k_splitk_reduce<T>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, k);
+    if (k.gn_part && k.gn_G > 0 && k.gn_HW > 0 && k.N % k.gn_G == 0 && (GN_GB * (k.N / k.gn_G)) % 8 == 0 &&
+        GN_GB * (k.N / k.gn_G) <= 2048 && k.M % k.gn_HW == 0) {
+      k.gn_S = gn_slices(k.gn_HW);
+      hipLaunchKernelGGL((k_splitk_reduce_gn<T>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
+      if (gn_done) *gn_done = 1;
+    } else {
+      const size_t groups = (size_t)k.M * k.N / 4;
+      hipLaunchKernelGGL((k_splitk_reduce<T>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, k);
+    }
   }
 }
 
@@ -461,8 +592,10 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   k.rows_per_batch = a.rows_per_batch > 0 ? a.rows_per_batch : 1;
   k.R = a.R; k.ldr = a.ldr; k.C = a.C; k.ldc = a.ldc; k.act_silu = a.act_silu;
   k.partial = a.partial; k.splits = 1; k.k_per_split = a.K;
-  if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st);
-  else gemm_dispatch<bf16>(k, a.partial_elems, st);
+  k.gn_part = a.gn_part; k.gn_HW = a.gn_HW; k.gn_G = a.gn_G; k.gn_S = 0;
+  if (a.gn_done) *a.gn_done = 0;
+  if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st, a.gn_done);
+  else gemm_dispatch<bf16>(k, a.partial_elems, st, a.gn_done);
   return 2.0 * (double)a.M * (double)a.N * (double)a.K;
 }
 

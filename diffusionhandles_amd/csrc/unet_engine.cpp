@@ -64,6 +64,7 @@ struct Op {
   // attention
   int heads = 0, Nq = 0, Nk = 0, cross = 0, kv_col = 0; size_t lse_off = 0;
   // concat: in0 | in1
+  int gn_next = -1;         // index of the GroupNorm op that consumes `out` right after this op (statistics fused here)
 };
 
 }  // namespace dh
@@ -404,6 +405,13 @@ int build(dh_unet& u) {
     set_error("internal: fused projection sizes do not match");
     return DH_ERR_STATE;
   }
+  // a GroupNorm directly after the producer of its input takes its slice statistics from that producer
+  // (split-K reduce epilogue / concat copy) instead of a statistics pass of its own
+  for (size_t i = 0; i + 1 < u.ops.size(); ++i) {
+    Op& o = u.ops[i];
+    const Op& nx = u.ops[i + 1];
+    if (nx.type == OP_GN && nx.in0 == o.out && (o.type == OP_GEMM || o.type == OP_CONCAT)) o.gn_next = (int)(i + 1);
+  }
   // scratch: split-K partial slabs, upsample-backward temporary, small f32 vectors
   size_t biggest = 0;
   for (const Ten& t : u.tens) biggest = std::max(biggest, (size_t)t.rows * t.C * c.max_batch);
@@ -573,6 +581,7 @@ static void forward_ops(dh_unet* u, int B, int n_ops, hipStream_t st) {
   const int dt = u->dtype;
   const dh_unet_config& c = u->cfg;
   u->flops_fwd = 0;
+  int gn_have = 0;       // the op just executed left the GroupNorm slice statistics of its output in u->small
   launch_f32_to_t(dt, u->in_text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
   for (int oi = 0; oi < n_ops; ++oi) {
     const Op& o = u->ops[oi];
@@ -600,13 +609,20 @@ static void forward_ops(dh_unet* u, int B, int n_ops, hipStream_t st) {
       case OP_GEMM: {
         GemmArgs g;
         fill_gemm(u, o, B, g);
+        gn_have = 0;
+        if (o.gn_next >= 0 && oi + 1 < n_ops) {        // the next op normalises this output: statistics ride along
+          const Ten& to = u->tens[o.out];
+          g.gn_part = u->small; g.gn_HW = to.rows; g.gn_G = u->ops[o.gn_next].groups; g.gn_done = &gn_have;
+        }
         u->flops_fwd += launch_gemm(dt, g, st);
         break;
       }
       case OP_GN: {
         const Ten& t = u->tens[o.in0];
+        const int have = (oi > 0 && u->ops[oi - 1].gn_next == oi) ? gn_have : 0;
         launch_groupnorm_fwd(dt, u->aptr(o.in0), u->pf + o.gamma_off, u->pf + o.beta_off, u->aptr(o.out),
-                             u->f32a + o.stats_off, u->small, B, t.rows, t.C, o.groups, o.eps, o.silu, st);
+                             u->f32a + o.stats_off, u->small, B, t.rows, t.C, o.groups, o.eps, o.silu, st, have);
+        gn_have = 0;
         break;
       }
       case OP_LN: {
@@ -638,8 +654,16 @@ static void forward_ops(dh_unet* u, int B, int n_ops, hipStream_t st) {
       }
       case OP_CONCAT: {
         const Ten &a = u->tens[o.in0], &b2 = u->tens[o.in1], &t = u->tens[o.out];
-        launch_copy_cols(dt, u->aptr(o.in0), a.C, u->aptr(o.out), t.C, B * t.rows, a.C, 0, st);
-        launch_copy_cols(dt, u->aptr(o.in1), b2.C, u->aptr(o.out) + a.C, t.C, B * t.rows, b2.C, 0, st);
+        gn_have = 0;
+        const int G = o.gn_next >= 0 ? u->ops[o.gn_next].groups : 0;
+        if (o.gn_next >= 0 && oi + 1 < n_ops && a.C % 8 == 0 && b2.C % 8 == 0 && t.C % G == 0 &&
+            (GN_GB * (t.C / G)) % 8 == 0 && GN_GB * (t.C / G) <= 2048) {
+          launch_concat_gn(dt, u->aptr(o.in0), a.C, u->aptr(o.in1), b2.C, u->aptr(o.out), u->small, B, t.rows, G, st);
+          gn_have = 1;
+        } else {
+          launch_copy_cols(dt, u->aptr(o.in0), a.C, u->aptr(o.out), t.C, B * t.rows, a.C, 0, st);
+          launch_copy_cols(dt, u->aptr(o.in1), b2.C, u->aptr(o.out) + a.C, t.C, B * t.rows, b2.C, 0, st);
+        }
         break;
       }
     }

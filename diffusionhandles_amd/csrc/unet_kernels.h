@@ -21,6 +21,9 @@ struct GemmArgs {
   void* C = nullptr; long ldc = 0;
   int act_silu = 0;
   float* partial = nullptr; size_t partial_elems = 0;   // split-K scratch (f32)
+  // optional: the output feeds a GroupNorm next.  When the launch goes through the split-K reduce, that kernel
+  // also leaves the GroupNorm slice statistics (gn_partial layout) and *gn_done is set to 1.
+  float* gn_part = nullptr; int gn_HW = 0, gn_G = 0; int* gn_done = nullptr;
 };
 // D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
@@ -40,9 +43,17 @@ void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* 
 void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float* w, void* dx, int dx_is_f32,
                            int accumulate, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 
-// GroupNorm (+SiLU): y = act(gn(x));  stats = [B*G][2] (mean, rstd) saved for backward
+// GroupNorm (+SiLU): y = act(gn(x));  stats = [B*G][2] (mean, rstd) saved for backward.
+// have_partials != 0: the slice statistics in `scratch` were already left by the producer of x
+// (split-K reduce / concat), only the apply kernel runs.
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
-                          float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st);
+                          float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
+                          int have_partials = 0);
+int gn_slices(int HW);          // number of row slices of the GroupNorm statistics for HW rows per image
+constexpr int GN_GB = 4;        // groups per statistics workgroup
+// out[m][0..Ca) = a[m], out[m][Ca..Ca+Cb) = b[m], plus the GroupNorm slice statistics of out (G groups)
+void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, void* out, float* gn_part, int B, int HW,
+                      int G, hipStream_t st);
 // dx (=|+=) d gn-act / d x
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,

@@ -110,9 +110,8 @@ __device__ __forceinline__ float silu_grad(float z) {
 //   the apply kernel combines the S <= 16 slices (8 lanes per group, butterfly, Chan's formula) before
 //   normalising; block x == 0 also publishes (mean, rstd) for backward.
 // partial layout: [b][g][3][S]  (n | mean | M2 planes)
-constexpr int GN_GB = 4;       // groups per partial workgroup
 static int gn_slice_cap() { static const int v = getenv("DH_GN_SLICES") ? atoi(getenv("DH_GN_SLICES")) : 16; return v; }
-inline int gn_slices(int HW) { const int cap = gn_slice_cap(); int s = HW / 4; return s < 1 ? 1 : (s > cap ? cap : s); }
+int gn_slices(int HW) { const int cap = gn_slice_cap(); int s = HW / 4; return s < 1 ? 1 : (s > cap ? cap : s); }
 
 template <class T, bool BWD>
 __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, const float* gamma, const float* beta,
@@ -252,14 +251,15 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
 }
 
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
-                          float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st) {
+                          float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
+                          int have_partials) {
   const int S = gn_slices(HW);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_partial<f16, false>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
+    if (!have_partials) hipLaunchKernelGGL((k_gn_partial<f16, false>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu);
   } else {
-    hipLaunchKernelGGL((k_gn_partial<bf16, false>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
+    if (!have_partials) hipLaunchKernelGGL((k_gn_partial<bf16, false>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu);
   }
 }
@@ -319,6 +319,88 @@ void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float*
     hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate);
   }
+}
+
+// concat(a, b) along channels fused with the GroupNorm slice statistics of the result (the up-path resnets
+// normalise the concatenation right away): same workgroup shape and arithmetic as k_gn_partial<fwd>.
+template <class T>
+__global__ void __launch_bounds__(256) k_concat_gn(const T* a, int Ca, const T* bsrc, int Cb, T* out, float* part, int HW, int G,
+                                                   int S) {
+  __shared__ float sm_red[4][2 * GN_GB];
+  const int C = Ca + Cb;
+  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = C / G;
+  const int W = GN_GB * cpg, nch = W / 8;
+  const int RP = (int)blockDim.x / nch;
+  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
+  const int rr = threadIdx.x / nch, ch = threadIdx.x - rr * nch;
+  auto load8 = [&](size_t m, int n) {          // n: channel of the result, multiple of 8; a chunk never straddles a | b
+    return n < Ca ? *reinterpret_cast<const uint4*>(a + m * Ca + n) : *reinterpret_cast<const uint4*>(bsrc + m * Cb + (n - Ca));
+  };
+  float ga[GN_GB], gq[GN_GB], pg[GN_GB];
+#pragma unroll
+  for (int gl = 0; gl < GN_GB; ++gl) {
+    ga[gl] = 0.f; gq[gl] = 0.f; pg[gl] = 0.f;
+    if (g0 + gl < G) {
+      const int n = (g0 + gl) * cpg;
+      const size_t m = (size_t)b * HW + r0;
+      pg[gl] = to_f32<T>(n < Ca ? a[m * Ca + n] : bsrc[m * Cb + (n - Ca)]);
+    }
+  }
+  if (rr < RP && g0 * cpg + ch * 8 < C) {
+    const int n = g0 * cpg + ch * 8;
+    int gi[8];
+    float av[8], qv[8], pv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      gi[i] = (ch * 8 + i) / cpg;
+      av[i] = 0.f; qv[i] = 0.f; pv[i] = 0.f;
+#pragma unroll
+      for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
+    }
+    for (int r = r0 + rr; r < r1; r += RP) {
+      const size_t m = (size_t)b * HW + r;
+      const uint4 raw = load8(m, n);
+      *reinterpret_cast<uint4*>(out + m * C + n) = raw;
+      const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = to_f32<T>(v[i]) - pv[i]; av[i] += d; qv[i] += d * d; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int gl = 0; gl < GN_GB; ++gl) {
+        ga[gl] += gi[i] == gl ? av[i] : 0.f;
+        gq[gl] += gi[i] == gl ? qv[i] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int gl = 0; gl < GN_GB; ++gl) { ga[gl] = wave_sum(ga[gl]); gq[gl] = wave_sum(gq[gl]); }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int gl = 0; gl < GN_GB; ++gl) { sm_red[threadIdx.x >> 6][2 * gl] = ga[gl]; sm_red[threadIdx.x >> 6][2 * gl + 1] = gq[gl]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < GN_GB && g0 + (int)threadIdx.x < G) {
+    const int gl = threadIdx.x, g = g0 + gl;
+    float sa = 0.f, sq = 0.f;
+    for (int w = 0; w < 4; ++w) { sa += sm_red[w][2 * gl]; sq += sm_red[w][2 * gl + 1]; }
+    const float n = (float)(r1 - r0) * (float)cpg;
+    float piv = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN_GB; ++k) piv = gl == k ? pg[k] : piv;
+    float* o = part + ((size_t)(b * G + g) * 3) * S + s;
+    o[0] = n; o[S] = piv + sa / n; o[2 * S] = sq - sa * sa / n;
+  }
+}
+
+void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, void* out, float* gn_part, int B, int HW,
+                      int G, hipStream_t st) {
+  const int S = gn_slices(HW);
+  dim3 grid(S, cdiv(G, GN_GB), B);
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_concat_gn<f16>), grid, dim3(256), 0, st, (const f16*)a, Ca, (const f16*)b, Cb, (f16*)out, gn_part, HW, G, S);
+  else
+    hipLaunchKernelGGL((k_concat_gn<bf16>), grid, dim3(256), 0, st, (const bf16*)a, Ca, (const bf16*)b, Cb, (bf16*)out, gn_part, HW, G, S);
 }
 
 // ----------------------------------------------------------------------------- LayerNorm

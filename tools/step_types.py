@@ -7,7 +7,8 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 marks = [i for i, r in enumerate(rows) if "k_ddim_cfg" in r[2]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-seg = rows[marks[-k - 1] + 1: marks[-1] + 1]
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # the last steps are the eager event-bracket pass
+seg = rows[marks[-k - 1 - skip] + 1: marks[-1 - skip] + 1]
 busy = sum(e - s for s, e, _ in seg) / 1e3 / k
 agg = collections.defaultdict(lambda: [0, 0.0])
 for s, e, n in seg:
