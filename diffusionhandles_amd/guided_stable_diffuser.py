@@ -122,6 +122,20 @@ class GuidedStableDiffuser(GuidedDiffuser):
                 else:
                     self.unet.init_synthetic(self._synthetic_seed)     # no checkpoint offline: seeded weights
             from .synthetic import SyntheticTextEncoder, SyntheticTokenizer, SyntheticVAE
+            from .vae import AutoencoderKL, build_text_encoder
+            # real modules when checkpoints are given (PyTorch-ROCm; once per image / edit), "sd" / "sd2" = the real
+            # architectures with random weights, otherwise the cheap deterministic stand-ins (no checkpoints offline)
+            if self.tokenizer is None and os.environ.get("DIFFHANDLES_TOKENIZER_DIR"):
+                from transformers import CLIPTokenizer
+                self.tokenizer = CLIPTokenizer.from_pretrained(os.environ["DIFFHANDLES_TOKENIZER_DIR"])
+            if self.text_encoder is None and os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR"):
+                self.text_encoder = build_text_encoder(os.environ["DIFFHANDLES_TEXT_ENCODER_DIR"])
+            if self.vae is None and os.environ.get("DIFFHANDLES_VAE_SAFETENSORS"):
+                self.vae = AutoencoderKL.from_safetensors(os.environ["DIFFHANDLES_VAE_SAFETENSORS"])
+            if isinstance(self.text_encoder, str):
+                self.text_encoder = build_text_encoder()
+            if isinstance(self.vae, str):
+                self.vae = AutoencoderKL()
             if self.tokenizer is None:
                 self.tokenizer = SyntheticTokenizer()
             if self.text_encoder is None:

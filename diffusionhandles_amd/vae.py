@@ -1,0 +1,192 @@
+"""SD-2 AutoencoderKL and CLIP text tower in plain PyTorch-ROCm (once per image / edit,
+"keep in PyTorch-ROCm first").
+
+The reference takes both from third-party packages that are not in its tree: `diffusers.AutoencoderKL`
+(`guided_stable_diffuser.py:9,29`, used at `:93-108, 481-483` and `stable_null_inverter.py:72-110`) and
+`transformers.CLIPTextModel` (`:8,34-35`).  diffusers is not installed here, so the VAE is restated from its
+published structure with **diffusers' state-dict key names** (a real `vae/diffusion_pytorch_model.safetensors`
+loads with `load_state_dict`); parity is unpinned (no weights, no diffusers).  The text tower is
+transformers' own `CLIPTextModel` built from the SD-2 configuration (random init offline, `from_pretrained`
+when a checkpoint directory is given).
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SD_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
+              layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215)
+SD2_TEXT = dict(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=23,
+                num_attention_heads=16, max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5,
+                projection_dim=512, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+
+
+class _Resnet(nn.Module):
+    def __init__(self, cin, cout, groups):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=1e-6)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h)))
+        return h + (x if self.conv_shortcut is None else self.conv_shortcut(x))
+
+
+class _Attention(nn.Module):
+    """Single-head spatial self-attention of the VAE mid block (diffusers Attention, residual connection)."""
+
+    def __init__(self, ch, groups):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(groups, ch, eps=1e-6)
+        self.to_q, self.to_k, self.to_v = nn.Linear(ch, ch), nn.Linear(ch, ch), nn.Linear(ch, ch)
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Identity()])
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        t = self.group_norm(x).view(b, c, h * w).transpose(1, 2)
+        o = F.scaled_dot_product_attention(self.to_q(t)[:, None], self.to_k(t)[:, None], self.to_v(t)[:, None])[:, 0]
+        return x + self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
+
+
+class _Mid(nn.Module):
+    def __init__(self, ch, groups):
+        super().__init__()
+        self.attentions = nn.ModuleList([_Attention(ch, groups)])
+        self.resnets = nn.ModuleList([_Resnet(ch, ch, groups), _Resnet(ch, ch, groups)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, n, groups, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        self.downsamplers = nn.ModuleList([nn.ModuleDict(dict(conv=nn.Conv2d(cout, cout, 3, stride=2)))]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0]["conv"](F.pad(x, (0, 1, 0, 1)))      # diffusers pads right/bottom, padding=0
+        return x
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, n, groups, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        self.upsamplers = nn.ModuleList([nn.ModuleDict(dict(conv=nn.Conv2d(cout, cout, 3, padding=1)))]) if up else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0]["conv"](F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return x
+
+
+class _Encoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        ch, g = c["block_out_channels"], c["norm_num_groups"]
+        self.conv_in = nn.Conv2d(c["in_channels"], ch[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList([_Down(ch[max(i - 1, 0)], ch[i], c["layers_per_block"], g, i < len(ch) - 1)
+                                          for i in range(len(ch))])
+        self.mid_block = _Mid(ch[-1], g)
+        self.conv_norm_out = nn.GroupNorm(g, ch[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(ch[-1], 2 * c["latent_channels"], 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class _Decoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        ch, g = list(reversed(c["block_out_channels"])), c["norm_num_groups"]
+        self.conv_in = nn.Conv2d(c["latent_channels"], ch[0], 3, padding=1)
+        self.mid_block = _Mid(ch[0], g)
+        self.up_blocks = nn.ModuleList([_Up(ch[max(i - 1, 0)], ch[i], c["layers_per_block"] + 1, g, i < len(ch) - 1)
+                                        for i in range(len(ch))])
+        self.conv_norm_out = nn.GroupNorm(g, ch[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(ch[-1], c["out_channels"], 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for b in self.up_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class _Gaussian:
+    """diffusers DiagonalGaussianDistribution: `.mean`, `.sample(generator)`, `.mode()`."""
+
+    def __init__(self, moments):
+        self.mean, self.logvar = moments.chunk(2, dim=1)
+        self.logvar = self.logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None):
+        return self.mean + self.std * torch.randn(self.mean.shape, generator=generator, device=self.mean.device,
+                                                   dtype=self.mean.dtype)
+
+    def mode(self):
+        return self.mean
+
+
+class _Out(dict):
+    """dict with attribute access, like diffusers' BaseOutput (`out['sample']`, `out.sample`, `out[0]`)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __getitem__(self, k):
+        return list(self.values())[k] if isinstance(k, int) else dict.__getitem__(self, k)
+
+
+class AutoencoderKL(nn.Module):
+    """`vae.encode(img)['latent_dist'].mean`, `vae.decode(z)['sample']`, `vae.config.scaling_factor` as the loops use
+    them (guided_stable_diffuser.py:93-108, 481-483; stable_null_inverter.py:72-110)."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        c = dict(SD_VAE, **(config or {}))
+        self.config = SimpleNamespace(**c)
+        self.encoder, self.decoder = _Encoder(c), _Decoder(c)
+        self.quant_conv = nn.Conv2d(2 * c["latent_channels"], 2 * c["latent_channels"], 1)
+        self.post_quant_conv = nn.Conv2d(c["latent_channels"], c["latent_channels"], 1)
+
+    def encode(self, x, return_dict=True):
+        dist = _Gaussian(self.quant_conv(self.encoder(x)))
+        return _Out(latent_dist=dist) if return_dict else (dist,)
+
+    def decode(self, z, return_dict=True):
+        img = self.decoder(self.post_quant_conv(z))
+        return _Out(sample=img) if return_dict else (img,)
+
+    @classmethod
+    def from_safetensors(cls, path, config=None):
+        from safetensors.torch import load_file
+        m = cls(config)
+        m.load_state_dict(load_file(path))
+        return m
+
+
+def build_text_encoder(pretrained_dir=None, config=None):
+    """transformers.CLIPTextModel with the SD-2 text configuration (`text_encoder(ids)[0]` -> [B,77,1024])."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    if pretrained_dir is not None:
+        return CLIPTextModel.from_pretrained(pretrained_dir)
+    return CLIPTextModel(CLIPTextConfig(**dict(SD2_TEXT, **(config or {})))).eval()
