@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""End-to-end edit harness: the build's counterpart of the reference's test/test_diffusion_handles.py
+(invert -> reconstruct -> set_foreground -> transform_foreground per transform), on the synthetic scene or on a
+scene directory, writing PNGs and the .npz identity cache with the reference's keys
+(null_text_emb, init_noise, activations1..3, latent_image; test_diffusion_handles.py:106-113).
+
+  python tools/run_edit.py --out /tmp/edit                       # synthetic sphere-on-plane scene
+  python tools/run_edit.py --scene DIR --out /tmp/edit           # DIR: input.npy [3,H,W] in [0,1], depth.npy, bg_depth.npy,
+                                                                 #      mask.npy, prompt.txt, transforms.json
+Real weights: DIFFHANDLES_UNET_SAFETENSORS / DIFFHANDLES_VAE_SAFETENSORS / DIFFHANDLES_TEXT_ENCODER_DIR /
+DIFFHANDLES_TOKENIZER_DIR (otherwise seeded random U-Net weights and the synthetic side modules).
+"""
+import argparse
+import json
+import os
+import struct
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def write_png(path, img):
+    """img: [H,W] or [H,W,3] float in [0,1] (or uint8).  Minimal zlib PNG writer (no imaging library offline)."""
+    a = np.asarray(img)
+    if a.dtype != np.uint8:
+        a = (np.clip(a, 0, 1) * 255 + 0.5).astype(np.uint8)
+    if a.ndim == 2:
+        a = a[..., None]
+    h, w, c = a.shape
+    raw = b"".join(b"\x00" + a[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    hdr = struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2}[c], 0, 0, 0)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", hdr) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--out", default="edit_out")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--mode", default="pc", choices=["pc", "mesh"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--skip-inversion", action="store_true", help="generate the image from noise instead of inverting an input")
+    args = ap.parse_args()
+    from diffusionhandles_amd import DiffusionHandles
+    from diffusionhandles_amd import conf as C
+    from diffusionhandles_amd.synthetic import TRANSFORMS, make_image, make_scene
+    from diffusionhandles_amd.unet import SD2_DEPTH
+    os.makedirs(args.out, exist_ok=True)
+    dev = torch.device("cuda:0")
+    conf = C.load_default()
+    conf.depth_transform_mode = args.mode
+    if args.scene:
+        ld = lambda n: torch.from_numpy(np.load(os.path.join(args.scene, n))).float()
+        img, depth, bg_depth, mask = ld("input.npy")[None], ld("depth.npy")[None, None], ld("bg_depth.npy")[None, None], ld("mask.npy")[None, None]
+        prompt = open(os.path.join(args.scene, "prompt.txt")).read().strip()
+        transforms = json.load(open(os.path.join(args.scene, "transforms.json")))
+        res = depth.shape[-1]
+    else:
+        res = args.res
+        depth, bg_depth, mask = make_scene(res)
+        img = make_image(res)
+        prompt = "a sphere on a plane"
+        transforms = [dict(name=f"edit{i}", rotation=TRANSFORMS[i][0], axis=[0, 1, 0], translation=list(TRANSFORMS[i][1]))
+                      for i in (2, 4)]
+    dh = DiffusionHandles(conf, dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16,
+                          unet_config=dict(SD2_DEPTH, sample_size=res // 8)).to(dev)
+    depth, bg_depth, mask, img = depth.to(dev), bg_depth.to(dev), mask.to(dev), img.to(dev)
+    t0 = time.time()
+    bg_depth = dh.set_foreground(depth, mask, bg_depth)
+    null_text, noise = (None, None)
+    if not args.skip_inversion:
+        null_text, noise = dh.invert_input_image(img, depth, prompt)
+    null_text, noise, acts, latent = dh.generate_input_image(depth, prompt, null_text, noise)
+    torch.cuda.synchronize()
+    t_identity = time.time() - t0
+    np.savez(os.path.join(args.out, "identity.npz"), null_text_emb=null_text.float().cpu().numpy(),
+             init_noise=noise.float().cpu().numpy(), activations1=acts[0].float().cpu().numpy(),
+             activations2=acts[1].float().cpu().numpy(), activations3=acts[2].float().cpu().numpy(),
+             latent_image=latent.float().cpu().numpy())
+    recon = dh.diffuser.decode_latent_image(latent)
+    write_png(os.path.join(args.out, "recon.png"), recon[0].permute(1, 2, 0).float().cpu().numpy())
+    report = dict(resolution=res, mode=args.mode, identity_s=round(t_identity, 2), edits=[])
+    for tf in transforms:
+        t0 = time.time()
+        out = dh.transform_foreground(depth, prompt, mask, bg_depth, null_text, noise, acts, rot_angle=float(tf["rotation"]),
+                                      rot_axis=torch.tensor(tf.get("axis", [0, 1, 0]), dtype=torch.float32),
+                                      translation=torch.tensor(tf["translation"], dtype=torch.float32))
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        edited, disparity = out[0], out[1]
+        name = tf.get("name", f"edit{len(report['edits'])}")
+        write_png(os.path.join(args.out, f"{name}.png"), edited[0].permute(1, 2, 0).float().cpu().numpy())
+        write_png(os.path.join(args.out, f"{name}_disparity.png"), (disparity[0, 0] / 255.0).float().cpu().numpy())
+        report["edits"].append(dict(name=name, seconds=round(dt, 3)))
+    json.dump(report, open(os.path.join(args.out, "report.json"), "w"), indent=1)
+    print(json.dumps(report))
+
+
+if __name__ == "__main__":
+    main()
