@@ -278,10 +278,11 @@ __global__ void k_normalize(int R2, float* disp, const unsigned int* minmax, con
 __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const uint8_t* inpaint, const int* unk,
                                                   const int* counts, int count_stride, int slot_n, int slot_it,
                                                   double* vx, double* vr, double* vp, double* vq, int max_iter,
-                                                  double tol2, int* counts_out, const float* rhs_extra) {
+                                                  double tol2, int* counts_out, const float* rhs_extra, int min_n) {
   __shared__ double sm[16];
   const int e = blockIdx.x, R2 = res * res;
   const int n = counts[e * count_stride + slot_n];
+  if (n <= min_n) return;                                // solved on chip by k_cg_fill_lds
   float* d = disp + (size_t)e * R2;
   const uint8_t* mk = inpaint + (size_t)e * R2;
   const int* U = unk + (size_t)e * R2;
@@ -346,6 +347,103 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int pix = U[i];
     d[pix] = (float)x[pix];
+  }
+  if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = it;
+}
+
+// The same iteration with the vectors on chip: thread t owns unknowns t, t + 1024, ... (the order the kernel above
+// visits them in, so every partial sum and therefore every iterate is bit-identical), x / r / q live in registers,
+// p in LDS where the four neighbours are read through a pixel -> unknown index map.  One iteration is three
+// workgroup barriers and two LDS reductions instead of five passes over global memory.
+constexpr int CG_SLOTS = 8;      // unknowns per thread: n <= 8192 takes this path
+__global__ void __launch_bounds__(1024) k_cg_fill_lds(int res, float* disp, const uint8_t* inpaint, const int* unk,
+                                                      const int* counts, int count_stride, int slot_n, int slot_it,
+                                                      int* pixmap, int max_iter, double tol2, int* counts_out,
+                                                      const float* rhs_extra, double* vx, double* vr, double* vp,
+                                                      double* vq) {
+  __shared__ double sm[16];
+  __shared__ double sp[CG_SLOTS * 1024];
+  const int e = blockIdx.x, R2 = res * res;
+  const int n = counts[e * count_stride + slot_n];
+  if (n > CG_SLOTS * 1024) return;                       // handled by k_cg_fill (launched right after)
+  float* d = disp + (size_t)e * R2;
+  const uint8_t* mk = inpaint + (size_t)e * R2;
+  const int* U = unk + (size_t)e * R2;
+  int* map = pixmap + (size_t)e * R2;
+  if (n == 0) {
+    if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = 0;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) map[U[i]] = i;
+  __syncthreads();
+  int nb[CG_SLOTS][4];
+  double x[CG_SLOTS], r[CG_SLOTS], q[CG_SLOTS];
+  double part = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < CG_SLOTS; ++sl) {
+    const int i = threadIdx.x + sl * 1024;
+    x[sl] = 0.0; r[sl] = 0.0; q[sl] = 0.0;
+    nb[sl][0] = nb[sl][1] = nb[sl][2] = nb[sl][3] = -1;
+    if (i < n) {
+      const int pix = U[i], y = pix / res, xx = pix - y * res;
+      double b = 0.0;
+      if (y > 0) { if (!mk[pix - res]) b += (double)d[pix - res]; else nb[sl][0] = map[pix - res]; }
+      if (y < res - 1) { if (!mk[pix + res]) b += (double)d[pix + res]; else nb[sl][1] = map[pix + res]; }
+      if (xx > 0) { if (!mk[pix - 1]) b += (double)d[pix - 1]; else nb[sl][2] = map[pix - 1]; }
+      if (xx < res - 1) { if (!mk[pix + 1]) b += (double)d[pix + 1]; else nb[sl][3] = map[pix + 1]; }
+      if (rhs_extra) b -= (double)rhs_extra[(size_t)e * R2 + pix];
+      r[sl] = b;
+      sp[i] = b;
+      part += b * b;
+    }
+  }
+  double rs = block_sum(part, sm);
+  const double bnorm = rs;
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    if (!(rs > tol2 * bnorm)) break;
+    __syncthreads();
+    part = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < CG_SLOTS; ++sl) {
+      const int i = threadIdx.x + sl * 1024;
+      if (i < n) {
+        const double pi = sp[i];
+        double a = 4.0 * pi;
+        if (nb[sl][0] >= 0) a -= sp[nb[sl][0]];
+        if (nb[sl][1] >= 0) a -= sp[nb[sl][1]];
+        if (nb[sl][2] >= 0) a -= sp[nb[sl][2]];
+        if (nb[sl][3] >= 0) a -= sp[nb[sl][3]];
+        q[sl] = a;
+        part += pi * a;
+      }
+    }
+    const double pq = block_sum(part, sm);
+    const double alpha = rs / pq;
+    part = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < CG_SLOTS; ++sl) {
+      const int i = threadIdx.x + sl * 1024;
+      if (i < n) {
+        x[sl] += alpha * sp[i];
+        const double rr = r[sl] - alpha * q[sl];
+        r[sl] = rr;
+        part += rr * rr;
+      }
+    }
+    const double rsn = block_sum(part, sm);       // its barriers also order the reads of p above before the update below
+    const double beta = rsn / rs;
+#pragma unroll
+    for (int sl = 0; sl < CG_SLOTS; ++sl) {
+      const int i = threadIdx.x + sl * 1024;
+      if (i < n) sp[i] = r[sl] + beta * sp[i];
+    }
+    rs = rsn;
+  }
+#pragma unroll
+  for (int sl = 0; sl < CG_SLOTS; ++sl) {
+    const int i = threadIdx.x + sl * 1024;
+    if (i < n) d[U[i]] = (float)x[sl];
   }
   if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = it;
 }
@@ -535,8 +633,12 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
   hipLaunchKernelGGL(k_normalize, dim3(cdiv(R2, 256), K), dim3(256), 0, st, R2, disparity, w.minmax, bounds, raw_mask,
                      clean_mask, w.inpaint);
   compact(w.inpaint, R2, K, R2, w.unk, R2, counts + 2, 4, w.block_counts, st);
+  static const bool cg_lds = !(getenv("DH_CG_LDS") && atoi(getenv("DH_CG_LDS")) == 0);
+  if (cg_lds)
+    hipLaunchKernelGGL(k_cg_fill_lds, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3,
+                       reinterpret_cast<int*>(w.vq), 20000, 1e-24, counts, (const float*)nullptr, w.vx, w.vr, w.vp, w.vq);
   hipLaunchKernelGGL(k_cg_fill, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3, w.vx,
-                     w.vr, w.vp, w.vq, 20000, 1e-24, counts, (const float*)nullptr);
+                     w.vr, w.vp, w.vq, 20000, 1e-24, counts, (const float*)nullptr, cg_lds ? CG_SLOTS * 1024 : 0);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
@@ -577,8 +679,10 @@ extern "C" int dh_laplacian_blend(const float* depth, const float* bg_depth, con
   DH_CHECK_HIP(hipMemcpyAsync(out, depth, (size_t)R2 * 4, hipMemcpyDeviceToDevice, st));
   DH_CHECK_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int), st));
   compact(src, R2, 1, 0, unk, 0, counts + 2, 1, bc, st);
+  hipLaunchKernelGGL(k_cg_fill_lds, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3,
+                     reinterpret_cast<int*>(vq), 50000, 1e-24, counts, (const float*)lap, vx, vr, vp, vq);
   hipLaunchKernelGGL(k_cg_fill, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, vx, vr, vp, vq, 50000,
-                     1e-24, counts, (const float*)lap);
+                     1e-24, counts, (const float*)lap, CG_SLOTS * 1024);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
