@@ -8,9 +8,12 @@ for r in csv.DictReader(open(sys.argv[1])):
                  int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"])))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if "k_ddim_cfg" in r[2]]
+# one guided step of the TIMED region (full launch count, no device-side spin of the event-bracket pass)
+segs = [rows[a + 1: b + 1] for a, b in zip(marks[:-1], marks[1:])]
+first_spin = next((i for i, x in enumerate(segs) if any("spin_kernel" in r[2] for r in x)), len(segs))
+segs = [x for x in segs[:first_spin] if len(x) > 2500]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-a, b = marks[-k - 1] + 1, marks[-k] + 1
-seg = rows[a:b]
+seg = segs[-k]
 span = (seg[-1][1] - seg[0][0]) / 1e3
 busy = sum(e - s for s, e, *_ in seg) / 1e3
 print(f"kernels {len(seg)} span {span:.1f} us busy {busy:.1f} us")
