@@ -59,22 +59,26 @@ __device__ __forceinline__ void load_row_frags(const T* base, long ld, long row,
     f[kk] = ok ? *reinterpret_cast<const uint4*>(base + row * ld + col0 + 16 * kk + 8 * hi) : make_uint4(0, 0, 0, 0);
 }
 
-// a 64 x 64 tile travels global -> 2 registers per thread (fetch, issued one tile ahead of its use) -> LDS (commit)
-struct TileRegs { uint4 v[2]; };
-template <class T>
-__device__ __forceinline__ void fetch_tile(const T* tile_ptr /* base + col0 + chunk*8, per thread */, long ld, long row0,
-                                           long rows_total, TileRegs& t, int tid = threadIdx.x) {
-  const int r0 = tid >> 3;
+// a 64 x 64 tile travels global -> registers (fetch, issued one tile ahead of its use) -> LDS (commit); the GT threads
+// of a wave group share the 512 sixteen-byte chunks of the tile
+template <int GT> struct TileRegs { uint4 v[(512 + GT - 1) / GT]; };
+template <class T, int GT>
+__device__ __forceinline__ void fetch_tile(const T* base /* + head column */, long ld, long row0, long rows_total,
+                                           TileRegs<GT>& t, int tid) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long r = row0 + r0 + 32 * j;
-    t.v[j] = (r < rows_total) ? *reinterpret_cast<const uint4*>(tile_ptr + r * ld) : make_uint4(0, 0, 0, 0);
+  for (int j = 0; j < (512 + GT - 1) / GT; ++j) {
+    const int idx = tid + j * GT;
+    const long r = row0 + (idx >> 3);
+    t.v[j] = (idx < 512 && r < rows_total) ? *reinterpret_cast<const uint4*>(base + r * ld + (idx & 7) * 8) : make_uint4(0, 0, 0, 0);
   }
 }
-__device__ __forceinline__ void commit_tile(const TileRegs& t, unsigned short* rm, int tid = threadIdx.x) {
-  const int r0 = tid >> 3, chunk = tid & 7;
+template <int GT>
+__device__ __forceinline__ void commit_tile(const TileRegs<GT>& t, unsigned short* rm, int tid) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(&rm[(r0 + 32 * j) * TLD + chunk * 8]) = t.v[j];
+  for (int j = 0; j < (512 + GT - 1) / GT; ++j) {
+    const int idx = tid + j * GT;
+    if (512 % GT == 0 || idx < 512) *reinterpret_cast<uint4*>(&rm[(idx >> 3) * TLD + (idx & 7) * 8]) = t.v[j];
+  }
 }
 
 // acc = sum_kk mfma(A = rows (rowbase + lane&31) of an LDS row-major tile, B = register fragments)
@@ -142,44 +146,45 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // keys [ks, ks+1) * ceil(tiles / KS) and the groups' (m, l, O) are merged through LDS at the end.  A single
 // image has only Nq/128 * H query tiles (160 at 64x64 latents, 5 heads): splitting the keys inside the block
 // puts KS waves on every SIMD instead of one, so one wave's softmax VALU work hides under another's MFMAs.
-template <class T, int KS>
-__global__ void __launch_bounds__(256 * KS) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
+template <class T, int KS, int QW>
+__global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
                                                        float* lse, int H, int Nq, int Nk) {
   __shared__ __attribute__((aligned(16))) unsigned short smem[KS * 2 * TILE];
-  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
+  const int ks = threadIdx.x / GT, tid = threadIdx.x - ks * GT;
   const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   unsigned short* sK = smem + ks * 2 * TILE;
   unsigned short* sV = sK + TILE;
-  const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
+  const long qrow = (long)blockIdx.x * (32 * QW) + wave * 32 + ln;
   const bool qok = qrow < Nq;
   uint4 qf[4];
   load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
   v16f oacc[2] = {zero16(), zero16()};
   float m_run = -INFINITY, l_run = 0.f;
-  const T* kp = k + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
-  const T* vp = v + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
+  const T* kp = k + (long)b * Nk * ldk + h * HD;
+  const T* vp = v + (long)b * Nk * ldk + h * HD;
   const unsigned short* vt = sV + (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const int tiles = (Nk + 63) >> 6, tps = (tiles + KS - 1) / KS;
   const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
-  TileRegs rk, rv;
+  TileRegs<GT> rk, rv;
   if (t_begin < t_end) {
-    fetch_tile<T>(kp, ldk, t_begin * 64, Nk, rk, tid);
-    fetch_tile<T>(vp, ldk, t_begin * 64, Nk, rv, tid);
+    fetch_tile<T, GT>(kp, ldk, t_begin * 64, Nk, rk, tid);
+    fetch_tile<T, GT>(vp, ldk, t_begin * 64, Nk, rv, tid);
   }
   for (int it = 0; it < tps; ++it) {
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;        // uniform per wave group; barriers are block-wide
     __syncthreads();
     if (act) {
-      commit_tile(rk, sK, tid);
-      commit_tile(rv, sV, tid);
+      commit_tile<GT>(rk, sK, tid);
+      commit_tile<GT>(rv, sV, tid);
     }
     __syncthreads();
     if (!act) continue;
     if (t_begin + it + 1 < t_end) {            // next tile's loads fly under this tile's MFMAs
-      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk, tid);
-      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv, tid);
+      fetch_tile<T, GT>(kp, ldk, k0 + 64, Nk, rk, tid);
+      fetch_tile<T, GT>(vp, ldk, k0 + 64, Nk, rv, tid);
     }
     v16f s[2];
     s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(256 * KS) k_attn_fwd(const T* q, long ldq, con
     for (int step = KS / 2; step >= 1; step >>= 1) {
       __syncthreads();
       if (ks >= step && ks < 2 * step) {
-        float* slot = cb + ((ks - step) * 4 + wave) * (34 * 64) + lane;
+        float* slot = cb + ((ks - step) * QW + wave) * (34 * 64) + lane;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(256 * KS) k_attn_fwd(const T* q, long ldq, con
       }
       __syncthreads();
       if (ks < step) {
-        const float* slot = cb + (ks * 4 + wave) * (34 * 64) + lane;
+        const float* slot = cb + (ks * QW + wave) * (34 * 64) + lane;
         const float m2 = slot[32 * 64], l2 = slot[33 * 64];
         const float m_new = fmaxf(m_run, m2);
         const float a1 = fast_exp2((m_run - m_new) * CEXP), a2 = fast_exp2((m2 - m_new) * CEXP);
@@ -288,17 +293,18 @@ __global__ void k_attn_delta(const T* o, long ldo, const T* d_o, long lddo, floa
 // ---------------------------------------------------------------------------- backward dQ
 // Same block shape as the forward (128 queries x KS key ranges, dQ partial sums merged through LDS).
 // delta = rowsum(dO * O) is computed here from the row fragments and written for the dK/dV kernel.
-template <class T, int KS>
-__global__ void __launch_bounds__(256 * KS) k_attn_bwd_dq(const T* q, long ldq, const T* k, const T* v, long ldk, const T* o,
+template <class T, int KS, int QW>
+__global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long ldq, const T* k, const T* v, long ldk, const T* o,
                                                           long ldo, const T* d_o, long lddo, const float* lse, float* delta,
                                                           T* dq, long lddq, int H, int Nq, int Nk) {
   __shared__ __attribute__((aligned(16))) unsigned short smem[KS * 2 * TILE];
-  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
+  const int ks = threadIdx.x / GT, tid = threadIdx.x - ks * GT;
   const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   unsigned short* sK = smem + ks * 2 * TILE;
   unsigned short* sV = sK + TILE;
-  const long qrow = (long)blockIdx.x * 128 + wave * 32 + ln;
+  const long qrow = (long)blockIdx.x * (32 * QW) + wave * 32 + ln;
   const bool qok = qrow < Nq;
   uint4 qf[4], dof[4];
   load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
@@ -319,29 +325,29 @@ __global__ void __launch_bounds__(256 * KS) k_attn_bwd_dq(const T* q, long ldq, 
   }
   const float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;
   v16f dqacc[2] = {zero16(), zero16()};
-  const T* kp = k + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
-  const T* vp = v + (long)b * Nk * ldk + h * HD + (tid & 7) * 8;
+  const T* kp = k + (long)b * Nk * ldk + h * HD;
+  const T* vp = v + (long)b * Nk * ldk + h * HD;
   const unsigned short* kt = sK + (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const int tiles = (Nk + 63) >> 6, tps = (tiles + KS - 1) / KS;
   const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
-  TileRegs rk, rv;
+  TileRegs<GT> rk, rv;
   if (t_begin < t_end) {
-    fetch_tile<T>(kp, ldk, t_begin * 64, Nk, rk, tid);
-    fetch_tile<T>(vp, ldk, t_begin * 64, Nk, rv, tid);
+    fetch_tile<T, GT>(kp, ldk, t_begin * 64, Nk, rk, tid);
+    fetch_tile<T, GT>(vp, ldk, t_begin * 64, Nk, rv, tid);
   }
   for (int it = 0; it < tps; ++it) {
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;
     __syncthreads();
     if (act) {
-      commit_tile(rk, sK, tid);
-      commit_tile(rv, sV, tid);
+      commit_tile<GT>(rk, sK, tid);
+      commit_tile<GT>(rv, sV, tid);
     }
     __syncthreads();
     if (!act) continue;
     if (t_begin + it + 1 < t_end) {
-      fetch_tile<T>(kp, ldk, k0 + 64, Nk, rk, tid);
-      fetch_tile<T>(vp, ldk, k0 + 64, Nk, rv, tid);
+      fetch_tile<T, GT>(kp, ldk, k0 + 64, Nk, rk, tid);
+      fetch_tile<T, GT>(vp, ldk, k0 + 64, Nk, rv, tid);
     }
     const bool ragged = k0 + 64 > Nk;
 #pragma unroll
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(256 * KS) k_attn_bwd_dq(const T* q, long ldq, 
     for (int step = KS / 2; step >= 1; step >>= 1) {
       __syncthreads();
       if (ks >= step && ks < 2 * step) {
-        float* slot = cb + ((ks - step) * 4 + wave) * (32 * 64) + lane;
+        float* slot = cb + ((ks - step) * QW + wave) * (32 * 64) + lane;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -377,7 +383,7 @@ __global__ void __launch_bounds__(256 * KS) k_attn_bwd_dq(const T* q, long ldq, 
       }
       __syncthreads();
       if (ks < step) {
-        const float* slot = cb + (ks * 4 + wave) * (32 * 64) + lane;
+        const float* slot = cb + (ks * QW + wave) * (32 * 64) + lane;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -391,47 +397,48 @@ __global__ void __launch_bounds__(256 * KS) k_attn_bwd_dq(const T* q, long ldq, 
 
 // ------------------------------------------------------------------------- backward dK, dV
 // 128 keys x KS query ranges per block; the groups' dK / dV partial sums are merged through LDS.
-template <class T, int KS>
-__global__ void __launch_bounds__(256 * KS) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
+template <class T, int KS, int QW>
+__global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
                                                            long lddo, const float* lse, const float* delta, T* dk, T* dv,
                                                            long lddk, int H, int Nq, int Nk) {
   constexpr int GRP = 2 * TILE + 256;     // shorts per group: Q tile, dO tile, 64 lse + 64 delta (f32)
   __shared__ __attribute__((aligned(16))) unsigned short smem[KS * GRP];
-  const int tid = threadIdx.x & 255, ks = threadIdx.x >> 8;
+  constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
+  const int ks = threadIdx.x / GT, tid = threadIdx.x - ks * GT;
   const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   unsigned short* sQ = smem + ks * GRP;
   unsigned short* sdO = sQ + TILE;
   float* sLse = reinterpret_cast<float*>(sdO + TILE);
   float* sDel = sLse + 64;
-  const long krow = (long)blockIdx.x * 128 + wave * 32 + ln;
+  const long krow = (long)blockIdx.x * (32 * QW) + wave * 32 + ln;
   const bool kok = krow < Nk;
   uint4 kf[4], vf[4];
   load_row_frags<T>(k + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, kf);
   load_row_frags<T>(v + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, vf);
   v16f dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
-  const T* qp = q + (long)b * Nq * ldq + h * HD + (tid & 7) * 8;
-  const T* dop = d_o + (long)b * Nq * lddo + h * HD + (tid & 7) * 8;
+  const T* qp = q + (long)b * Nq * ldq + h * HD;
+  const T* dop = d_o + (long)b * Nq * lddo + h * HD;
   const int toff = (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const unsigned short* qt = sQ + toff;
   const unsigned short* dot = sdO + toff;
   const int tiles = (Nq + 63) >> 6, tps = (tiles + KS - 1) / KS;
   const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
-  TileRegs rq, rdo;
+  TileRegs<GT> rq, rdo;
   if (t_begin < t_end) {
-    fetch_tile<T>(qp, ldq, t_begin * 64, Nq, rq, tid);
-    fetch_tile<T>(dop, lddo, t_begin * 64, Nq, rdo, tid);
+    fetch_tile<T, GT>(qp, ldq, t_begin * 64, Nq, rq, tid);
+    fetch_tile<T, GT>(dop, lddo, t_begin * 64, Nq, rdo, tid);
   }
   for (int it = 0; it < tps; ++it) {
     const int q0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;
     __syncthreads();
     if (act) {
-      commit_tile(rq, sQ, tid);
-      commit_tile(rdo, sdO, tid);
+      commit_tile<GT>(rq, sQ, tid);
+      commit_tile<GT>(rdo, sdO, tid);
       if (t_begin + it + 1 < t_end) {
-        fetch_tile<T>(qp, ldq, q0 + 64, Nq, rq, tid);
-        fetch_tile<T>(dop, lddo, q0 + 64, Nq, rdo, tid);
+        fetch_tile<T, GT>(qp, ldq, q0 + 64, Nq, rq, tid);
+        fetch_tile<T, GT>(dop, lddo, q0 + 64, Nq, rdo, tid);
       }
       if (tid < 64) {
         const long qr = q0 + tid;
@@ -502,26 +509,73 @@ __global__ void __launch_bounds__(256 * KS) k_attn_bwd_dkv(const T* q, long ldq,
 }
 
 // ------------------------------------------------------------------------------ launchers
-template <class T, int KS>
-static void attn_fwd_launch(dim3 grid, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
-                            long ldo, float* lse, int H, int Nq, int Nk) {
-  hipLaunchKernelGGL((k_attn_fwd<T, KS>), grid, dim3(256 * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk, (T*)o, ldo,
-                     lse, H, Nq, Nk);
-}
-// key-range split per block (measured on MI355X, fp16, B=1 H=5 N=4096: fwd 97 -> 57 us at KS=4, dq+dkv 244 -> 160 us
-// at KS=2; still ahead at 9216 keys and B=2, so the choice depends on the loop length only)
+// ---- launch shapes ------------------------------------------------------------------------------------------
+// KS: key-range (query-range for dK/dV) split over wave groups inside a block (measured on MI355X, fp16, B=1 H=5
+//     N=4096: fwd 97 -> 57 us at KS=4, dq+dkv 244 -> 160 us at KS=2; still ahead at 9216 keys and B=2, so the choice
+//     depends on the loop length only)
+// QW: waves of 32 rows per wave group, i.e. the block owns 32*QW rows.  One image has only N/32 * H row-waves
+//     (640 at N=4096, H=5): the row tile is chosen so that the blocks cover the 256 CUs as evenly as possible
+//     (128-row tiles = 160 blocks leave 96 CUs idle, 96-row tiles = 215 blocks).
 static int attn_key_split(int tiles, int max_ks) {
   static const int force = getenv("DH_ATTN_KS") ? atoi(getenv("DH_ATTN_KS")) : 0;
   int ks = tiles >= 16 ? 4 : tiles >= 8 ? 2 : 1;
   if (force == 1 || force == 2 || force == 4) ks = force;
   return ks < max_ks ? ks : max_ks;
 }
+static int attn_row_waves(int rows, int hb, int loop_rows) {
+  static const int force = getenv("DH_ATTN_QW") ? atoi(getenv("DH_ATTN_QW")) : 0;
+  if (force >= 1 && force <= 4) return force;
+  const int min_qw = loop_rows > 1024 ? 2 : 1;        // a 32-row block would stream the whole K/V per 32 rows
+  int best = 4;
+  long best_cost = -1;
+  for (int qw = 4; qw >= min_qw; --qw) {
+    const long blocks = (long)cdiv(rows, 32 * qw) * hb;
+    const long cost = ((blocks + 255) / 256) * qw;    // rounds over the CUs x work per block
+    if (best_cost < 0 || cost < best_cost) { best = qw; best_cost = cost; }
+  }
+  return best;
+}
+
+template <class T, int KS, int QW>
+static void attn_fwd_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
+                            long ldo, float* lse, int H, int Nq, int Nk) {
+  hipLaunchKernelGGL((k_attn_fwd<T, KS, QW>), dim3(cdiv(Nq, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
+                     (const T*)k, (const T*)v, ldk, (T*)o, ldo, lse, H, Nq, Nk);
+}
+template <class T, int KS, int QW>
+static void attn_dq_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
+                           const void* o, long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq,
+                           long lddq, int H, int Nq, int Nk) {
+  hipLaunchKernelGGL((k_attn_bwd_dq<T, KS, QW>), dim3(cdiv(Nq, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
+                     (const T*)k, (const T*)v, ldk, (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
+}
+template <class T, int KS, int QW>
+static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
+                            const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk,
+                            int H, int Nq, int Nk) {
+  hipLaunchKernelGGL((k_attn_bwd_dkv<T, KS, QW>), dim3(cdiv(Nk, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
+                     (const T*)k, (const T*)v, ldk, (const T*)d_o, lddo, lse, delta, (T*)dk, (T*)dv, lddk, H, Nq, Nk);
+}
+
+// (ks, qw) -> instantiation
+#define DH_ATTN_QW(FN, T_, KS_, ...)                                   \
+  do {                                                                  \
+    if (qw == 4) FN<T_, KS_, 4>(__VA_ARGS__);                           \
+    else if (qw == 3) FN<T_, KS_, 3>(__VA_ARGS__);                      \
+    else if (qw == 2) FN<T_, KS_, 2>(__VA_ARGS__);                      \
+    else FN<T_, KS_, 1>(__VA_ARGS__);                                   \
+  } while (0)
+
 void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o, long ldo,
                           float* lse, int B, int H, int Nq, int Nk, hipStream_t st) {
-  dim3 grid(cdiv(Nq, 128), H, B);
   const int ks = attn_key_split((Nk + 63) / 64, 4);
-#define DH_ATTN_FWD(T_) \
-  (ks == 4 ? attn_fwd_launch<T_, 4> : ks == 2 ? attn_fwd_launch<T_, 2> : attn_fwd_launch<T_, 1>)(grid, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk)
+  const int qw = attn_row_waves(Nq, H * B, Nk);
+#define DH_ATTN_FWD(T_)                                                                         \
+  do {                                                                                          \
+    if (ks == 4) DH_ATTN_QW(attn_fwd_launch, T_, 4, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk);       \
+    else if (ks == 2) DH_ATTN_QW(attn_fwd_launch, T_, 2, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk);  \
+    else DH_ATTN_QW(attn_fwd_launch, T_, 1, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk);               \
+  } while (0)
   if (dtype == DH_DTYPE_F16) DH_ATTN_FWD(f16);
   else DH_ATTN_FWD(bf16);
 #undef DH_ATTN_FWD
@@ -537,42 +591,35 @@ void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o,
     hipLaunchKernelGGL((k_attn_delta<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)o, ldo, (const bf16*)d_o, lddo, delta, H, Nq, total);
 }
 
-template <class T, int KS>
-static void attn_dq_launch(dim3 grid, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
-                           const void* o, long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq,
-                           long lddq, int H, int Nq, int Nk) {
-  hipLaunchKernelGGL((k_attn_bwd_dq<T, KS>), grid, dim3(256 * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk,
-                     (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
-}
 void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* o,
                              long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq, long lddq,
                              int B, int H, int Nq, int Nk, hipStream_t st) {
-  dim3 grid(cdiv(Nq, 128), H, B);
   const int ks = attn_key_split((Nk + 63) / 64, 2);
-#define DH_ATTN_DQ(T_) \
-  (ks == 2 ? attn_dq_launch<T_, 2> : attn_dq_launch<T_, 1>)(grid, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk)
+  const int qw = attn_row_waves(Nq, H * B, Nk);
+#define DH_ATTN_DQ(T_)                                                                                                          \
+  do {                                                                                                                           \
+    if (ks == 2) DH_ATTN_QW(attn_dq_launch, T_, 2, B, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk); \
+    else DH_ATTN_QW(attn_dq_launch, T_, 1, B, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk);          \
+  } while (0)
   if (dtype == DH_DTYPE_F16) DH_ATTN_DQ(f16);
   else DH_ATTN_DQ(bf16);
 #undef DH_ATTN_DQ
 }
 
-template <class T, int KS>
-static void attn_dkv_launch(dim3 grid, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
-                            const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk,
-                            int H, int Nq, int Nk) {
-  hipLaunchKernelGGL((k_attn_bwd_dkv<T, KS>), grid, dim3(256 * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk,
-                     (const T*)d_o, lddo, lse, delta, (T*)dk, (T*)dv, lddk, H, Nq, Nk);
-}
 void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* d_o,
                               long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk, int B,
                               int H, int Nq, int Nk, hipStream_t st) {
-  dim3 grid(cdiv(Nk, 128), H, B);
   const int ks = attn_key_split((Nq + 63) / 64, 2);
-#define DH_ATTN_DKV(T_) \
-  (ks == 2 ? attn_dkv_launch<T_, 2> : attn_dkv_launch<T_, 1>)(grid, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk)
+  const int qw = attn_row_waves(Nk, H * B, Nq);
+#define DH_ATTN_DKV(T_)                                                                                                         \
+  do {                                                                                                                           \
+    if (ks == 2) DH_ATTN_QW(attn_dkv_launch, T_, 2, B, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk);    \
+    else DH_ATTN_QW(attn_dkv_launch, T_, 1, B, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk);             \
+  } while (0)
   if (dtype == DH_DTYPE_F16) DH_ATTN_DKV(f16);
   else DH_ATTN_DKV(bf16);
 #undef DH_ATTN_DKV
 }
+#undef DH_ATTN_QW
 
 }  // namespace dh
