@@ -554,6 +554,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   } while (0)
   static const int kKg = getenv("DH_GEMM_KG") ? atoi(getenv("DH_GEMM_KG")) : 0;
   static const int kKg64 = getenv("DH_GEMM_KG64") ? atoi(getenv("DH_GEMM_KG64")) : 11;     // 64x64 tile: (groups, stages) as two digits; in situ no K grouping wins (27.9 vs 27.4 steps/s for 4 groups x 2 stages)
+  static const int kKg2MinKt = getenv("DH_KG2_MINKT") ? atoi(getenv("DH_KG2_MINKT")) : 16;
   static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 0;
   const int wg = kWg ? kWg : 1;
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
@@ -563,7 +564,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 42) DH_LAUNCH_GEMM_KG(64, 64, 2, 4);
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 24) DH_LAUNCH_GEMM_KG(64, 64, 4, 2);
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 23) DH_LAUNCH_GEMM_KG(64, 64, 3, 2);
-  else if (kKg != 1 && BM == 128 && BN == 64 && tiles_per_split >= 16) DH_LAUNCH_GEMM_KG(128, 64, 3, 2);
+  else if (kKg != 1 && BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) DH_LAUNCH_GEMM_KG(128, 64, 3, 2);
   else if (kKg == 2 && BM == 128 && BN == 128) DH_LAUNCH_GEMM_KG(128, 128, 2, 2);
   else
   if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
