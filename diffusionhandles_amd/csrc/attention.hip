@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
       for (int i = 0; i < 8; ++i) del_q += to_f32<T>(ov[i]) * to_f32<T>(dv[i]);
     }
     del_q += __shfl_xor(del_q, 32, 64);
-    if (qok && ks == 0 && hi == 0) delta[((long)b * H + h) * Nq + qrow] = del_q;
+    if (delta && qok && ks == 0 && hi == 0) delta[((long)b * H + h) * Nq + qrow] = del_q;      // NULL: already there
   }
   const float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;
   v16f dqacc[2] = {zero16(), zero16()};

@@ -84,7 +84,8 @@ void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, con
 // delta[b][h][q] = sum_d dO*O
 void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o, long lddo, float* delta, int B,
                             int H, int Nq, hipStream_t st);
-// dq also WRITES delta[b][h][q] = sum_d dO*O (read by the dkv kernel launched after it)
+// dq also WRITES delta[b][h][q] = sum_d dO*O (read by the dkv kernel launched after it) unless delta is NULL
+// (then launch_attention_delta has produced it and dq / dkv may run concurrently)
 void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* o,
                              long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq, long lddq,
                              int B, int H, int Nq, int Nk, hipStream_t st);
