@@ -98,6 +98,45 @@ def test_edge_cases_empty_mask_and_input_normalisation():
         DT.transform_depth(depth.to(dev), bg.to(dev), mask.to(dev), K, depth_transform_mode="nope")
 
 
+@pytest.mark.parametrize("res", [512, 768])
+def test_full_size_properties_identity_round_trip_and_monotone_translation(res):
+    """Size-independent properties at the BASELINE resolutions (the oracle's Python z-buffer takes ~1 s per edit
+    there, so full sizes are checked through invariants): (1) the identity transform maps every foreground pixel to
+    itself, leaves no hole, and returns the normalised input disparity; (2) a pure translation towards the camera
+    keeps every correspondence's source inside the mask, targets unique, and never shrinks the silhouette;
+    (3) the K-batched call equals K single calls bit for bit."""
+    from diffusionhandles_amd import depth_transform as DT
+    from oracle import depth_ref as D
+    depth, bg, mask = make_scene(res)
+    K = D.intrinsics_f32()
+    dev = _dev()
+    d, b, m = depth.to(dev), bg.to(dev), mask.to(dev)
+    axis = torch.tensor([0.0, 1.0, 0.0])
+    zero = torch.tensor([0.0, 0.0, 0.0])
+    (disp, corr), = DT.reproject_edits(d, b, m, K, [(0.0, axis, zero)])
+    c = corr.numpy()
+    # (the reference's OPEN(2x2 ellipse) clean-up of the re-projected mask trims ~1 % of silhouette pixels even here)
+    assert int(0.98 * mask.sum()) <= len(c) <= int(mask.sum())
+    assert np.array_equal(c[:, 0], c[:, 2]) and np.array_equal(c[:, 1], c[:, 3])
+    key = c[:, 1] * res + c[:, 0]
+    assert (np.diff(key) > 0).all() and (mask[0, 0].numpy()[c[:, 1], c[:, 0]] > 0.5).all()   # row-major source order
+    diff = (disp.cpu() - D.normalize_depth(1.0 / depth)[0]).abs().flatten()
+    assert float((diff <= 2e-3).float().mean()) > 0.995       # all but the trimmed / in-filled silhouette pixels
+    tfs = [(0.0, axis, torch.tensor([0.0, 0.0, -0.4])), (20.0, axis, torch.tensor([0.2, 0.0, 0.0])),
+           (-35.0, axis, torch.tensor([-0.3, 0.05, 0.3]))]
+    batched = DT.reproject_edits(d, b, m, K, tfs)
+    mk = mask[0, 0].numpy() > 0.5
+    for i, tf in enumerate(tfs):
+        (ds, cs), = DT.reproject_edits(d, b, m, K, [tf])
+        assert torch.equal(cs, batched[i][1]) and torch.equal(ds, batched[i][0])
+        c = cs.numpy()
+        assert mk[c[:, 1], c[:, 0]].all()
+        assert len({(int(x), int(y)) for x, y in c[:, 2:4]}) == len(c)                  # one source per target pixel
+        assert (c[:, 2:4] >= 0).all() and (c[:, 2:4] < res).all()
+        assert torch.isfinite(ds).all() and float(ds.min()) >= -1e-3 and float(ds.max()) <= 255.001
+    assert len(batched[0][1]) >= int(0.95 * mask.sum())        # moving closer never shrinks the visible silhouette much
+
+
 def test_zbuffer_determinism():
     a = _edits(512, [3])[3 + 1]
     b = _edits(512, [3])[3 + 1]
