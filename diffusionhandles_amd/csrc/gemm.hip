@@ -61,7 +61,6 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   float* partial;
   int splits, k_per_split;
   float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
-  const void* geglu_pre; long geglu_ld;        // GEGLU backward fused into the epilogue (see GemmArgs)
 };
 
 constexpr int BK = 64;
@@ -89,23 +88,6 @@ __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, flo
     for (int i = 0; i < 4; ++i) v[i] += to_f32<T>(rv[i]);
   }
   T o[4];
-  if (p.geglu_pre) {      // v = dA of y = h * gelu(g): write d(pre) = [v * gelu(g) | v * h * gelu'(g)]
-    const T* pre = reinterpret_cast<const T*>(p.geglu_pre) + (size_t)m * p.geglu_ld + n;
-    const uint2 rh = *reinterpret_cast<const uint2*>(pre), rg = *reinterpret_cast<const uint2*>(pre + p.N);
-    const T* hv = reinterpret_cast<const T*>(&rh);
-    const T* gv = reinterpret_cast<const T*>(&rg);
-    T og[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float g = to_f32<T>(gv[i]);
-      o[i] = from_f32<T>(v[i] * gelu_f(g));
-      og[i] = from_f32<T>(v[i] * to_f32<T>(hv[i]) * gelu_grad(g));
-    }
-    T* out = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n;
-    *reinterpret_cast<uint2*>(out) = *reinterpret_cast<uint2*>(o);
-    *reinterpret_cast<uint2*>(out + p.N) = *reinterpret_cast<uint2*>(og);
-    return;
-  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(v[i]);
   *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = *reinterpret_cast<uint2*>(o);
@@ -615,7 +597,6 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   k.R = a.R; k.ldr = a.ldr; k.C = a.C; k.ldc = a.ldc; k.act_silu = a.act_silu;
   k.partial = a.partial; k.splits = 1; k.k_per_split = a.K;
   k.gn_part = a.gn_part; k.gn_HW = a.gn_HW; k.gn_G = a.gn_G; k.gn_S = 0;
-  k.geglu_pre = a.geglu_pre; k.geglu_ld = a.geglu_ld;
   if (a.gn_done) *a.gn_done = 0;
   if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st, a.gn_done);
   else gemm_dispatch<bf16>(k, a.partial_elems, st, a.gn_done);

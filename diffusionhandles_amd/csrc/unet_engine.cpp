@@ -796,17 +796,6 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
         if (o.mode == A_DENSE) {
           g.mode = A_DENSE;
           g.M = B * to.rows; g.N = w.K; g.K = w.N;
-          const Op* prod = oi > 0 ? &u->ops[oi - 1] : nullptr;
-          if (prod && prod->type == OP_GEGLU && prod->out == o.in0 && !u->gready[o.in0] && o.in_col == 0 &&
-              u->tens[prod->in0].req_grad) {
-            // the input is a GEGLU output used only here: the epilogue turns dA into d(pre-activation) directly
-            // (the GEGLU op's own backward finds no gradient on its output and does nothing)
-            g.geglu_pre = u->aptr(prod->in0); g.geglu_ld = 2 * ti.C;
-            g.C = u->gptr(prod->in0); g.ldc = 2 * ti.C;
-            u->flops_bwd += launch_gemm(dt, g, st);
-            u->gready[prod->in0] = 1;
-            break;
-          }
           g.C = u->gptr(o.in0) + o.in_col; g.ldc = ti.C;
           if (u->gready[o.in0]) { g.R = g.C; g.ldr = ti.C; }
           u->flops_bwd += launch_gemm(dt, g, st);

@@ -5,11 +5,6 @@
 
 namespace dh {
 
-__host__ __device__ inline float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
-__device__ inline float gelu_grad(float g) {
-  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
-}
-
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONVT2 = 2 };
 
 struct GemmArgs {
@@ -29,9 +24,6 @@ struct GemmArgs {
   // optional: the output feeds a GroupNorm next.  When the launch goes through the split-K reduce, that kernel
   // also leaves the GroupNorm slice statistics (gn_partial layout) and *gn_done is set to 1.
   float* gn_part = nullptr; int gn_HW = 0, gn_G = 0; int* gn_done = nullptr;
-  // optional: the product D [M][N] is dA of a GEGLU (y = h * gelu(g), pre = [h | g], N = F).  The epilogue then
-  // writes d(pre) = [D * gelu(g) | D * h * gelu'(g)] into C [M][2F] (ldc = 2F) instead of D.
-  const void* geglu_pre = nullptr; long geglu_ld = 0;
 };
 // D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);

@@ -528,7 +528,10 @@ void launch_layernorm_bwd(int dtype, const void* x, const void* dy, const float*
 }
 
 // --------------------------------------------------------------------------------- GEGLU
-// gelu_f / gelu_grad: unet_kernels.h (shared with the GEMM epilogue)
+__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float g) {
+  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
 
 template <class T>
 __global__ void k_geglu_fwd(const T* x, T* y, size_t rows, int F) {
