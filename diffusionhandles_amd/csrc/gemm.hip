@@ -68,10 +68,11 @@ constexpr int BK = 64;
 
 template <class T>
 __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, float v0, float v1, float v2, float v3,
-                                               bool have_r = false, uint2 rpre = make_uint2(0, 0)) {
+                                               bool have_r = false, uint2 rpre = make_uint2(0, 0), bool have_b = false,
+                                               float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f)) {
   float v[4] = {v0, v1, v2, v3};
   if (p.bias) {
-    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    const float4 b = have_b ? bpre : *reinterpret_cast<const float4*>(p.bias + n);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   }
   if (p.rowvec) {
@@ -266,6 +267,17 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
   // sitting at the tail of the kernel (these loads are younger than the prologue DMAs and older than every later one,
   // so the counted vmcnt waits below can only become stricter)
   const bool pre_r = p.R != nullptr && p.pre_r && p.splits == 1 && (WG == 1 || grp == 0) && (KG == 1 || kg == 0);
+  const bool pre_b = p.bias != nullptr && p.pre_r && p.splits == 1;
+  float4 bpre[TN][4];
+  if (pre_b) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+        bpre[j][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
   uint2 rpre[TM][TN][4];
   if (pre_r) {
 #pragma unroll
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
           *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = o;
         } else {
           epilogue_store<T>(p, m, n, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], pre_r,
-                            rpre[i][j][g]);
+                            rpre[i][j][g], pre_b, bpre[j][g]);
         }
       }
   }
