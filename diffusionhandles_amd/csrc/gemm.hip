@@ -406,12 +406,25 @@ __global__ void k_splitk_reduce(const GemmK p) {
   if (q >= total) return;
   const size_t e = q * 4;
   const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
+  // every load of the element group is issued before the first add: bias / residual first, slabs four at a time
+  const bool have_r = p.R != nullptr, have_b = p.bias != nullptr;
+  const uint2 rpre = have_r ? *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n) : make_uint2(0, 0);
+  const float4 bpre = have_b ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t slab = (size_t)p.M * p.N;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int z = 0; z < p.splits; ++z) {
-    const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)z * p.M * p.N + e);
+  int z = 0;
+  for (; z + 4 <= p.splits; z += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(p.partial + (size_t)(z + j) * slab + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+  }
+  for (; z < p.splits; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)z * slab + e);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  epilogue_store<T>(p, m, n, s.x, s.y, s.z, s.w);
+  epilogue_store<T>(p, m, n, s.x, s.y, s.z, s.w, have_r, rpre, have_b, bpre);
 }
 
 // split-K reduce fused with the GroupNorm slice statistics of its output (the next op of a resnet's conv is a
