@@ -235,6 +235,11 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
   const size_t row = (size_t)b * HW + (live ? idx / cchunks : 0);
   const int c0 = (int)(idx % cchunks) * 8, cpg = C / G;
   uint4 raw = *reinterpret_cast<const uint4*>(x + row * C + c0);      // in flight under the slice combine
+  float gmv[8], btv[8];                                               // so are the affine parameters of the 8 channels
+  *reinterpret_cast<float4*>(gmv) = *reinterpret_cast<const float4*>(gamma + c0);
+  *reinterpret_cast<float4*>(gmv + 4) = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+  *reinterpret_cast<float4*>(btv) = *reinterpret_cast<const float4*>(beta + c0);
+  *reinterpret_cast<float4*>(btv + 4) = *reinterpret_cast<const float4*>(beta + c0 + 4);
   gn_combine(part, b, G, S, eps, sm_stats, blockIdx.x == 0 ? stats : nullptr);
   if (!live) return;
   const T* xv = reinterpret_cast<const T*>(&raw);
@@ -243,7 +248,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
   for (int i = 0; i < 8; ++i) {
     const int c = c0 + i;
     const float2 st = sm_stats[c / cpg];
-    float z = (to_f32<T>(xv[i]) - st.x) * st.y * gamma[c] + beta[c];
+    float z = (to_f32<T>(xv[i]) - st.x) * st.y * gmv[i] + btv[i];
     if (silu) z = silu_f(z);
     o[i] = from_f32<T>(z);
   }
@@ -279,6 +284,11 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
   uint4 rd = *reinterpret_cast<const uint4*>(dy + row * C + c0);
   uint4 ro = make_uint4(0, 0, 0, 0);
   if (accumulate) ro = *reinterpret_cast<const uint4*>(dx + row * C + c0);
+  float gmv[8], btv[8];
+  *reinterpret_cast<float4*>(gmv) = *reinterpret_cast<const float4*>(gamma + c0);
+  *reinterpret_cast<float4*>(gmv + 4) = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+  *reinterpret_cast<float4*>(btv) = *reinterpret_cast<const float4*>(beta + c0);
+  *reinterpret_cast<float4*>(btv + 4) = *reinterpret_cast<const float4*>(beta + c0 + 4);
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     const float* p = part + ((size_t)(b * G + g) * S) * 2;
     float a = 0.f, c = 0.f;
@@ -298,8 +308,8 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
     const float4 st = sm_st[c / cpg];
     const float xh = (to_f32<T>(xv[i]) - st.x) * st.y;
     float d = to_f32<T>(dv[i]);
-    if (silu) d *= silu_grad(xh * gamma[c] + beta[c]);
-    d *= gamma[c];
+    if (silu) d *= silu_grad(xh * gmv[i] + btv[i]);
+    d *= gmv[i];
     float r = st.y * (d - st.z - xh * st.w);
     if (accumulate) r += to_f32<T>(ov[i]);
     o[i] = from_f32<T>(r);
