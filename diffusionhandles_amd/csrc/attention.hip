@@ -400,7 +400,9 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
 template <class T, int KS, int QW>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
                                                            long lddo, const float* lse, const float* delta, T* dk, T* dv,
-                                                           long lddk, int H, int Nq, int Nk) {
+                                                           long lddk, int H, int Nq, int Nk, float* qpart, int qchunks) {
+  // qchunks > 1 (cross-attention: one key block per head, thousands of queries): blockIdx.x is a QUERY chunk and the
+  // block leaves f32 partial dK / dV in qpart [chunk][b][h][dK|dV][32*QW keys][64]; k_attn_dkv_reduce sums the chunks
   constexpr int GRP = 2 * TILE + 256;     // shorts per group: Q tile, dO tile, 64 lse + 64 delta (f32)
   __shared__ __attribute__((aligned(16))) unsigned short smem[KS * GRP];
   constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
@@ -411,7 +413,8 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
   unsigned short* sdO = sQ + TILE;
   float* sLse = reinterpret_cast<float*>(sdO + TILE);
   float* sDel = sLse + 64;
-  const long krow = (long)blockIdx.x * (32 * QW) + wave * 32 + ln;
+  const int chunk = qchunks > 1 ? blockIdx.x : 0;
+  const long krow = (long)(qchunks > 1 ? 0 : blockIdx.x) * (32 * QW) + wave * 32 + ln;
   const bool kok = krow < Nk;
   uint4 kf[4], vf[4];
   load_row_frags<T>(k + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, kf);
@@ -422,8 +425,11 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
   const int toff = (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const unsigned short* qt = sQ + toff;
   const unsigned short* dot = sdO + toff;
-  const int tiles = (Nq + 63) >> 6, tps = (tiles + KS - 1) / KS;
-  const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
+  const int tiles_all = (Nq + 63) >> 6;
+  const int tpc = (tiles_all + qchunks - 1) / qchunks;                 // q tiles of this block's chunk
+  const int c_end = min((chunk + 1) * tpc, tiles_all);
+  const int tps = (tpc + KS - 1) / KS;
+  const int t_begin = chunk * tpc + ks * tps, t_end = min(t_begin + tps, c_end);
   TileRegs<GT> rq, rdo;
   if (t_begin < t_end) {
     fetch_tile<T, GT>(qp, ldq, t_begin * 64, Nq, rq, tid);
@@ -502,6 +508,20 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
     }
     if (ks != 0) return;
   }
+  if (qchunks > 1) {
+    float* base = qpart + ((((size_t)chunk * gridDim.z + b) * H + h) * 2) * (32 * QW * 64) + (size_t)(wave * 32 + ln) * 64;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const v16f (&acc)[2] = which == 0 ? dkacc : dvacc;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(base + which * (32 * QW * 64) + dt * 32 + 8 * g + 4 * hi) =
+              make_float4(acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+    }
+    return;
+  }
   if (kok) {
     store_rows_t<T>(dk + (long)b * Nk * lddk, lddk, krow, h * HD, hi, dkacc, 1.f);
     store_rows_t<T>(dv + (long)b * Nk * lddk, lddk, krow, h * HD, hi, dvacc, 1.f);
@@ -509,6 +529,29 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
 }
 
 // ------------------------------------------------------------------------------ launchers
+// dk / dv [b][key][h*64 + d] = sum over the query chunks of the f32 partials (chunk order: deterministic)
+template <class T>
+__global__ void k_attn_dkv_reduce(const float* qpart, int qchunks, int rows_pad, T* dk, T* dv, long lddk, int B, int H, int Nk) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;        // over B*H*2*Nk*16 (4 d values each)
+  const long total = (long)B * H * 2 * Nk * 16;
+  if (idx >= total) return;
+  const int d4 = (int)(idx & 15);
+  long r = idx >> 4;
+  const int key = (int)(r % Nk); r /= Nk;
+  const int which = (int)(r & 1); r >>= 1;
+  const int h = (int)(r % H);
+  const int b = (int)(r / H);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < qchunks; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(
+        qpart + (((((size_t)c * B + b) * H + h) * 2 + which) * rows_pad + key) * 64 + d4 * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  T o[4] = {from_f32<T>(s.x), from_f32<T>(s.y), from_f32<T>(s.z), from_f32<T>(s.w)};
+  T* out = (which ? dv : dk) + ((long)b * Nk + key) * lddk + h * HD + d4 * 4;
+  *reinterpret_cast<uint2*>(out) = *reinterpret_cast<uint2*>(o);
+}
+
 // ---- launch shapes ------------------------------------------------------------------------------------------
 // KS: key-range (query-range for dK/dV) split over wave groups inside a block (measured on MI355X, fp16, B=1 H=5
 //     N=4096: fwd 97 -> 57 us at KS=4, dq+dkv 244 -> 160 us at KS=2; still ahead at 9216 keys and B=2, so the choice
@@ -552,9 +595,15 @@ static void attn_dq_launch(int B, hipStream_t st, const void* q, long ldq, const
 template <class T, int KS, int QW>
 static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
                             const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk,
-                            int H, int Nq, int Nk) {
-  hipLaunchKernelGGL((k_attn_bwd_dkv<T, KS, QW>), dim3(cdiv(Nk, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
-                     (const T*)k, (const T*)v, ldk, (const T*)d_o, lddo, lse, delta, (T*)dk, (T*)dv, lddk, H, Nq, Nk);
+                            int H, int Nq, int Nk, float* qpart, int qchunks) {
+  hipLaunchKernelGGL((k_attn_bwd_dkv<T, KS, QW>), dim3(qchunks > 1 ? qchunks : cdiv(Nk, 32 * QW), H, B), dim3(64 * QW * KS), 0,
+                     st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk, (const T*)d_o, lddo, lse, delta, (T*)dk, (T*)dv, lddk,
+                     H, Nq, Nk, qpart, qchunks);
+  if (qchunks > 1) {
+    const long total = (long)B * H * 2 * Nk * 16;
+    hipLaunchKernelGGL((k_attn_dkv_reduce<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, qpart, qchunks, 32 * QW,
+                       (T*)dk, (T*)dv, lddk, B, H, Nk);
+  }
 }
 
 // (ks, qw) -> instantiation
@@ -608,13 +657,24 @@ void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, 
 
 void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* d_o,
                               long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk, int B,
-                              int H, int Nq, int Nk, hipStream_t st) {
-  const int ks = attn_key_split((Nq + 63) / 64, 2);
+                              int H, int Nq, int Nk, hipStream_t st, float* scratch, size_t scratch_elems) {
+  int ks = attn_key_split((Nq + 63) / 64, 2);
   const int qw = attn_row_waves(Nk, H * B, Nq);
+  // cross-attention shape (77 keys, thousands of queries): the key blocks alone are H*B workgroups; split the queries
+  // over workgroups too and sum f32 partials
+  int qchunks = 1;
+  float* qpart = nullptr;
+  if (scratch && Nk <= 32 * qw && Nq >= 512) {
+    const int tiles_all = (Nq + 63) / 64;
+    qchunks = 256 / (H * B);
+    if (qchunks > tiles_all / 2) qchunks = tiles_all / 2;
+    while (qchunks > 1 && (size_t)qchunks * B * H * 2 * 32 * qw * 64 > scratch_elems) --qchunks;
+    if (qchunks > 1) { qpart = scratch; ks = attn_key_split(cdiv(tiles_all, qchunks), 2); } else qchunks = 1;
+  }
 #define DH_ATTN_DKV(T_)                                                                                                         \
   do {                                                                                                                           \
-    if (ks == 2) DH_ATTN_QW(attn_dkv_launch, T_, 2, B, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk);    \
-    else DH_ATTN_QW(attn_dkv_launch, T_, 1, B, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk);             \
+    if (ks == 2) DH_ATTN_QW(attn_dkv_launch, T_, 2, B, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk, qpart, qchunks);    \
+    else DH_ATTN_QW(attn_dkv_launch, T_, 1, B, st, q, ldq, k, v, ldk, d_o, lddo, lse, delta, dk, dv, lddk, H, Nq, Nk, qpart, qchunks);             \
   } while (0)
   if (dtype == DH_DTYPE_F16) DH_ATTN_DKV(f16);
   else DH_ATTN_DKV(bf16);

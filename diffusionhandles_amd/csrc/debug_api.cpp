@@ -61,7 +61,13 @@ extern "C" int dh_dbg_attention(int dtype, const void* q, long ldq, const void* 
   if (d_o) {
     if (dq) launch_attention_bwd_dq(dtype, q, ldq, k, v, ldk, o, ldo, d_o, ldo, lse, delta, dq, ldq, B, H, Nq, Nk, st);
     else launch_attention_delta(dtype, o, ldo, d_o, ldo, delta, B, H, Nq, st);
-    if (dk && dv) launch_attention_bwd_dkv(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dk, dv, ldk, B, H, Nq, Nk, st);
+    if (dk && dv) {
+      static float* scratch = nullptr;                 // test hook only: lets the query-chunk path of the few-key case run
+      constexpr size_t kScratch = (size_t)16 << 20;
+      if (!scratch && hipMalloc((void**)&scratch, kScratch * sizeof(float)) != hipSuccess) scratch = nullptr;
+      launch_attention_bwd_dkv(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dk, dv, ldk, B, H, Nq, Nk, st, scratch,
+                               scratch ? kScratch : 0);
+    }
   }
   DH_LAUNCH_CHECK();
   return DH_OK;

@@ -869,7 +869,8 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
           if (bw.need_text) {
             unsigned short* dkv = u->gptr(o.in1) + o.kv_col;
             launch_attention_bwd_dkv(dt, u->aptr(o.in0), tq.C, kv, kv + C, tkv.C, u->gptr(o.out), C,
-                                     u->f32a + o.lse_off, delta, dkv, dkv + C, tkv.C, B, o.heads, o.Nq, o.Nk, st);
+                                     u->f32a + o.lse_off, delta, dkv, dkv + C, tkv.C, B, o.heads, o.Nq, o.Nk, st, u->partial,
+                                     u->partial_elems);
             u->gready[o.in1] = 1;
             u->flops_bwd += 8.0 * B * o.heads * (double)o.Nq * o.Nk * 64;
           }

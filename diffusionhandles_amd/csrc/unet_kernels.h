@@ -91,6 +91,7 @@ void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, 
                              int B, int H, int Nq, int Nk, hipStream_t st);
 void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk,
                               const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv,
-                              long lddk, int B, int H, int Nq, int Nk, hipStream_t st);
+                              long lddk, int B, int H, int Nq, int Nk, hipStream_t st, float* scratch = nullptr,
+                              size_t scratch_elems = 0);   // scratch (f32): lets the few-key case split the queries over workgroups
 
 }  // namespace dh
