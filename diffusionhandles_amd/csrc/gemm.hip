@@ -8,12 +8,12 @@
 //   W:      [N][K] with K contiguous (torch Linear layout; conv weights are re-laid to
 //           [Cout][ky][kx][Cin] at load time).
 //
-// 256 threads = 4 waves (2 x 2).  Per K tile of 64: global -> registers (issued one tile
-// ahead, T14 split) -> LDS rows padded to 72 halves (conflict-free ds_read_b128) ->
+// 256 threads = 4 waves (2 x 2) per wave group.  Per K tile of 64: LDS-DMA (global_load_lds_dwordx4) into a ring of
+// unpadded, source-swizzled stages (see k_gemm_dma below) -> ds_read_b128 fragments ->
 // v_mfma_f32_32x32x16 with the operands SWAPPED (W is the A operand), so a lane owns one
 // output row m and 4 consecutive n per accumulator group: 8-byte stores, per-lane row
 // scalars.  f32 accumulate; optional split-K through f32 partial slabs + a reduce kernel
-// that applies the same epilogue.
+// that applies the same epilogue (and, when a GroupNorm follows, leaves its slice statistics).
 #include <stdlib.h>
 
 #include <vector>
@@ -549,6 +549,9 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   static const int kBigTiles = getenv("DH_BIG_TILES") ? atoi(getenv("DH_BIG_TILES")) : 48;
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
   const int ktiles = k.K / BK;
+  // tuning knob: long-K GEMMs whose 128x128 tiling has at most this many tiles use the 128x64 tile (two wave groups)
+  static const int kNarrowTiles = getenv("DH_NARROW_TILES") ? atoi(getenv("DH_NARROW_TILES")) : 0;
+  if (BN == 128 && ktiles >= 16 && cdiv(k.M, 128) * cdiv(k.N, 128) <= kNarrowTiles) BN = 64;
   // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles, K split over four
   // wave groups inside the workgroup (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
   if (k.M <= 64 || (cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles && ktiles < kSplitMinK)) { BM = 64; BN = 64; }
