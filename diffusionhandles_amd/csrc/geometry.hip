@@ -154,13 +154,17 @@ __device__ __forceinline__ float unsort_f32(unsigned int k) {
 }
 
 // per pixel: depth map, raw fg mask, raw disparity 1/z and its min/max keys
+constexpr int PIX_PER_THREAD = 16;
 __global__ void k_pixels(int R2, const unsigned long long* zbuf, const int* owner, float* zmap, uint8_t* raw_mask,
                          float* disp, unsigned int* minmax) {
   __shared__ unsigned int smin[4], smax[4];
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
   int e = blockIdx.y;
   unsigned int kmin = 0xffffffffu, kmax = 0u;
-  if (p < R2) {
+  // PIX_PER_THREAD pixels per thread: 16x fewer workgroups contend on the two min / max words of the edit
+#pragma unroll 4
+  for (int it = 0; it < PIX_PER_THREAD; ++it) {
+    int p = (blockIdx.x * PIX_PER_THREAD + it) * blockDim.x + threadIdx.x;
+    if (p >= R2) break;
     size_t o = (size_t)e * R2 + p;
     unsigned long long k = zbuf[o];
     float z = (k == ~0ull) ? __uint_as_float(0x7f800000u) : (float)unsort_f64(k);
@@ -169,7 +173,9 @@ __global__ void k_pixels(int R2, const unsigned long long* zbuf, const int* owne
     raw_mask[o] = (k != ~0ull && w >= R2) ? 1 : 0;
     float d = (float)(1.0 / (double)z);
     disp[o] = d;
-    kmin = kmax = sortable_f32(d);
+    const unsigned int kd = sortable_f32(d);
+    kmin = kd < kmin ? kd : kmin;
+    kmax = kd > kmax ? kd : kmax;
   }
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) {
@@ -274,11 +280,16 @@ __global__ void k_normalize(int R2, float* disp, const unsigned int* minmax, con
 }
 
 // Harmonic in-fill: A x = b with A = 4 I - adjacency(masked), solved by CG in float64 by ONE
-// workgroup per edit (deterministic fixed-tree reductions).
+// workgroup per edit (deterministic fixed-tree reductions).  The vectors are indexed by UNKNOWN (compact, coalesced);
+// the four neighbour unknowns of every unknown are resolved once through a pixel -> unknown map, so an iteration is
+// three streaming passes plus four gathers per unknown.  (Used for holes of more than CG_SLOTS * 1024 pixels; smaller
+// ones stay on chip in k_cg_fill_lds, which visits the unknowns in the same order: identical iterates.)
 __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const uint8_t* inpaint, const int* unk,
                                                   const int* counts, int count_stride, int slot_n, int slot_it,
                                                   double* vx, double* vr, double* vp, double* vq, int max_iter,
-                                                  double tol2, int* counts_out, const float* rhs_extra, int min_n) {
+                                                  double tol2, int* counts_out, const float* rhs_extra, int min_n,
+                                                  int* pixmap, int2* nb_ud, size_t nb_ud_stride, int2* nb_lr,
+                                                  size_t nb_lr_stride) {
   __shared__ double sm[16];
   const int e = blockIdx.x, R2 = res * res;
   const int n = counts[e * count_stride + slot_n];
@@ -290,22 +301,25 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
   double* r = vr + (size_t)e * R2;
   double* p = vp + (size_t)e * R2;
   double* q = vq + (size_t)e * R2;
-  if (n == 0) {
-    if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = 0;
-    return;
-  }
+  int* map = pixmap + (size_t)e * R2;
+  int2* nud = nb_ud + (size_t)e * nb_ud_stride;
+  int2* nlr = nb_lr + (size_t)e * nb_lr_stride;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) map[U[i]] = i;
+  __syncthreads();
   double part = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int pix = U[i], y = pix / res, xx = pix - y * res;
     double b = 0.0;
-    if (y > 0 && !mk[pix - res]) b += (double)d[pix - res];
-    if (y < res - 1 && !mk[pix + res]) b += (double)d[pix + res];
-    if (xx > 0 && !mk[pix - 1]) b += (double)d[pix - 1];
-    if (xx < res - 1 && !mk[pix + 1]) b += (double)d[pix + 1];
+    int2 ud = make_int2(-1, -1), lr = make_int2(-1, -1);
+    if (y > 0) { if (!mk[pix - res]) b += (double)d[pix - res]; else ud.x = map[pix - res]; }
+    if (y < res - 1) { if (!mk[pix + res]) b += (double)d[pix + res]; else ud.y = map[pix + res]; }
+    if (xx > 0) { if (!mk[pix - 1]) b += (double)d[pix - 1]; else lr.x = map[pix - 1]; }
+    if (xx < res - 1) { if (!mk[pix + 1]) b += (double)d[pix + 1]; else lr.y = map[pix + 1]; }
     if (rhs_extra) b -= (double)rhs_extra[(size_t)e * R2 + pix];
-    x[pix] = 0.0;
-    r[pix] = b;
-    p[pix] = b;
+    nud[i] = ud; nlr[i] = lr;
+    x[i] = 0.0;
+    r[i] = b;
+    p[i] = b;
     part += b * b;
   }
   double rs = block_sum(part, sm);
@@ -315,39 +329,36 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
     if (!(rs > tol2 * bnorm)) break;
     __syncthreads();
     part = 0.0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      int pix = U[i], y = pix / res, xx = pix - y * res;
-      double a = 4.0 * p[pix];
-      if (y > 0 && mk[pix - res]) a -= p[pix - res];
-      if (y < res - 1 && mk[pix + res]) a -= p[pix + res];
-      if (xx > 0 && mk[pix - 1]) a -= p[pix - 1];
-      if (xx < res - 1 && mk[pix + 1]) a -= p[pix + 1];
-      q[pix] = a;
-      part += p[pix] * a;
+      const int2 ud = nud[i], lr = nlr[i];
+      const double pi = p[i];
+      double a = 4.0 * pi;
+      if (ud.x >= 0) a -= p[ud.x];
+      if (ud.y >= 0) a -= p[ud.y];
+      if (lr.x >= 0) a -= p[lr.x];
+      if (lr.y >= 0) a -= p[lr.y];
+      q[i] = a;
+      part += pi * a;
     }
     const double pq = block_sum(part, sm);
     const double alpha = rs / pq;
     part = 0.0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      int pix = U[i];
-      x[pix] += alpha * p[pix];
-      double rr = r[pix] - alpha * q[pix];
-      r[pix] = rr;
+      x[i] += alpha * p[i];
+      double rr = r[i] - alpha * q[i];
+      r[i] = rr;
       part += rr * rr;
     }
     const double rsn = block_sum(part, sm);
     const double beta = rsn / rs;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      int pix = U[i];
-      p[pix] = r[pix] + beta * p[pix];
-    }
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = r[i] + beta * p[i];
     rs = rsn;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    int pix = U[i];
-    d[pix] = (float)x[pix];
-  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) d[U[i]] = (float)x[i];
   if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = it;
 }
 
@@ -615,7 +626,7 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
   hipLaunchKernelGGL(k_points, dim3(cdiv(P, 256), K), dim3(256), 0, st, depth, bg_depth, fg_pix, n_fg, res, grid_x,
                      grid_y, inv_fx, inv_fy, fx, fy, w.xf, w.cen, w.zbuf, w.pix, w.key);
   hipLaunchKernelGGL(k_resolve, dim3(cdiv(P, 256), K), dim3(256), 0, st, P, R2, w.zbuf, w.pix, w.key, w.owner);
-  hipLaunchKernelGGL(k_pixels, dim3(cdiv(R2, 256), K), dim3(256), 0, st, R2, w.zbuf, w.owner, zmap, raw_mask,
+  hipLaunchKernelGGL(k_pixels, dim3(cdiv(R2, 256 * PIX_PER_THREAD), K), dim3(256), 0, st, R2, w.zbuf, w.owner, zmap, raw_mask,
                      disparity, w.minmax);
   hipLaunchKernelGGL(k_fg_vis, dim3(cdiv(n_fg, 256), K), dim3(256), 0, st, n_fg, R2, P, res, w.pix, w.owner, vis,
                      target_xy);
@@ -636,9 +647,11 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
   static const bool cg_lds = !(getenv("DH_CG_LDS") && atoi(getenv("DH_CG_LDS")) == 0);
   if (cg_lds)
     hipLaunchKernelGGL(k_cg_fill_lds, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3,
-                       reinterpret_cast<int*>(w.vq), 20000, 1e-24, counts, (const float*)nullptr, w.vx, w.vr, w.vp, w.vq);
+                       w.owner, 20000, 1e-24, counts, (const float*)nullptr, w.vx, w.vr, w.vp, w.vq);
+  // scratch of the solve: the z-buffer, owner map and key list are dead by now (last read by k_pixels / k_write_corr)
   hipLaunchKernelGGL(k_cg_fill, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3, w.vx,
-                     w.vr, w.vp, w.vq, 20000, 1e-24, counts, (const float*)nullptr, cg_lds ? CG_SLOTS * 1024 : 0);
+                     w.vr, w.vp, w.vq, 20000, 1e-24, counts, (const float*)nullptr, cg_lds ? CG_SLOTS * 1024 : 0, w.owner,
+                     reinterpret_cast<int2*>(w.zbuf), (size_t)R2, reinterpret_cast<int2*>(w.key), (size_t)P);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
@@ -646,7 +659,7 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
 extern "C" int dh_laplacian_blend_workspace_bytes(int res, size_t* bytes) {
   DH_REQUIRE(res >= 2 && bytes, "bad arguments");
   const size_t R2 = (size_t)res * res;
-  *bytes = 4 * align_up(R2 * 8, 256) + 3 * align_up(R2, 256) + 2 * align_up(R2 * 4, 256) +
+  *bytes = 4 * align_up(R2 * 8, 256) + 3 * align_up(R2, 256) + 3 * align_up(R2 * 4, 256) + 2 * align_up(R2 * 8, 256) +
            (size_t)(cdiv((int)R2, CP_TILE) + 2) * 4 + 4096;
   return DH_OK;
 }
@@ -668,6 +681,9 @@ extern "C" int dh_laplacian_blend(const float* depth, const float* bg_depth, con
   uint8_t* m0 = a.take<uint8_t>(R2); uint8_t* m1 = a.take<uint8_t>(R2);
   float* lap = a.take<float>(R2);
   int* unk = a.take<int>(R2);
+  int* pixmap = a.take<int>(R2);
+  int2* nb_ud = a.take<int2>(R2);
+  int2* nb_lr = a.take<int2>(R2);
   int* bc = a.take<int>(cdiv(R2, CP_TILE) + 2);
   DH_CHECK_HIP(hipMemcpyAsync(m0, fg_mask, R2, hipMemcpyDeviceToDevice, st));
   uint8_t *src = m0, *dst = m1;
@@ -679,10 +695,10 @@ extern "C" int dh_laplacian_blend(const float* depth, const float* bg_depth, con
   DH_CHECK_HIP(hipMemcpyAsync(out, depth, (size_t)R2 * 4, hipMemcpyDeviceToDevice, st));
   DH_CHECK_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int), st));
   compact(src, R2, 1, 0, unk, 0, counts + 2, 1, bc, st);
-  hipLaunchKernelGGL(k_cg_fill_lds, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3,
-                     reinterpret_cast<int*>(vq), 50000, 1e-24, counts, (const float*)lap, vx, vr, vp, vq);
+  hipLaunchKernelGGL(k_cg_fill_lds, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, pixmap, 50000, 1e-24,
+                     counts, (const float*)lap, vx, vr, vp, vq);
   hipLaunchKernelGGL(k_cg_fill, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, vx, vr, vp, vq, 50000,
-                     1e-24, counts, (const float*)lap, CG_SLOTS * 1024);
+                     1e-24, counts, (const float*)lap, CG_SLOTS * 1024, pixmap, nb_ud, (size_t)R2, nb_lr, (size_t)R2);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
