@@ -607,6 +607,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   static const int kKg = getenv("DH_GEMM_KG") ? atoi(getenv("DH_GEMM_KG")) : 0;
   static const int kKg64 = getenv("DH_GEMM_KG64") ? atoi(getenv("DH_GEMM_KG64")) : 11;     // 64x64 tile: (groups, stages) as two digits; in situ no K grouping wins (27.9 vs 27.4 steps/s for 4 groups x 2 stages)
   static const int kKg2MinKt = getenv("DH_KG2_MINKT") ? atoi(getenv("DH_KG2_MINKT")) : 16;
+  static const int kManyBlocks = getenv("DH_GEMM_MANY") ? atoi(getenv("DH_GEMM_MANY")) : 512;
   static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 0;
   const int wg = kWg ? kWg : 1;
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
@@ -620,6 +621,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (kKg == 2 && BM == 128 && BN == 128) DH_LAUNCH_GEMM_KG(128, 128, 2, 2);
   else
   if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
+  else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) DH_LAUNCH_GEMM(128, 128, 2);   // 64 KiB: two workgroups per CU
   else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
   else DH_LAUNCH_GEMM(128, 64, 5);
 #undef DH_LAUNCH_GEMM
