@@ -59,6 +59,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   void* C; long ldc;
   int act_silu;
   int pre_r;        // fetch the residual tile before the K loop
+  int wide_store;   // 16-byte epilogue stores (N % 32 == 0, C and ldc 16-byte aligned)
   float* partial;
   int splits, k_per_split;
   float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
@@ -66,10 +67,10 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
 
 constexpr int BK = 64;
 
+// bias / per-image vector / SiLU / residual of four consecutive outputs of row m, rounded to the storage type
 template <class T>
-__device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, float v0, float v1, float v2, float v3,
-                                               bool have_r = false, uint2 rpre = make_uint2(0, 0), bool have_b = false,
-                                               float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f)) {
+__device__ __forceinline__ uint2 epilogue_pack(const GemmK& p, int m, int n, float v0, float v1, float v2, float v3,
+                                               bool have_r, uint2 rpre, bool have_b, float4 bpre) {
   float v[4] = {v0, v1, v2, v3};
   if (p.bias) {
     const float4 b = have_b ? bpre : *reinterpret_cast<const float4*>(p.bias + n);
@@ -93,7 +94,14 @@ __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, flo
   T o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(v[i]);
-  *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = *reinterpret_cast<uint2*>(o);
+  return *reinterpret_cast<uint2*>(o);
+}
+template <class T>
+__device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, float v0, float v1, float v2, float v3,
+                                               bool have_r = false, uint2 rpre = make_uint2(0, 0), bool have_b = false,
+                                               float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f)) {
+  *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) =
+      epilogue_pack<T>(p, m, n, v0, v1, v2, v3, have_r, rpre, have_b, bpre);
 }
 
 // the same epilogue for one element (used for the GroupNorm pivots of k_splitk_reduce_gn)
@@ -363,6 +371,37 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((i * TN + j) * 16 + r) * 64];
     }
+  }
+
+  // 16-bit results: the two lanes of a row (lane, lane ^ 32) own alternating 4-column groups; they swap two groups so
+  // that each stores two 16-byte chunks instead of four 8-byte ones (half the write transactions, whole 32-byte sectors
+  // per lane pair)
+  if (p.splits == 1 && p.wide_store) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (BM / 2) + i * 32 + ln;
+      if (m >= p.M) continue;                       // both lanes of a pair share m
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * (BN / 2) + j * 32;
+        if (nb >= p.N) continue;                    // N is a multiple of 32 on this path
+        uint2 w[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          w[g] = epilogue_pack<T>(p, m, nb + 8 * g + 4 * hi, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
+                                  acc[i][j][4 * g + 3], pre_r, rpre[i][j][g], pre_b, bpre[j][g]);
+        const uint2 sa = hi ? w[0] : w[1], sb = hi ? w[2] : w[3];
+        uint2 ra, rb;
+        ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
+        rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
+        const uint4 ca = hi ? make_uint4(ra.x, ra.y, w[1].x, w[1].y) : make_uint4(w[0].x, w[0].y, ra.x, ra.y);
+        const uint4 cb = hi ? make_uint4(rb.x, rb.y, w[3].x, w[3].y) : make_uint4(w[2].x, w[2].y, rb.x, rb.y);
+        T* out = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 8 * hi;
+        *reinterpret_cast<uint4*>(out) = ca;
+        *reinterpret_cast<uint4*>(out + 16) = cb;
+      }
+    }
+    return;
   }
 
 #pragma unroll
@@ -652,6 +691,8 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   k.partial = a.partial; k.splits = 1; k.k_per_split = a.K;
   static const int kPreR = getenv("DH_GEMM_PRE_R") ? atoi(getenv("DH_GEMM_PRE_R")) : 1;
   k.pre_r = kPreR;
+  static const int kWide = getenv("DH_GEMM_WIDE_STORE") ? atoi(getenv("DH_GEMM_WIDE_STORE")) : 1;
+  k.wide_store = kWide && a.N % 32 == 0 && a.ldc % 8 == 0 && ((size_t)a.C & 15) == 0;
   k.gn_part = a.gn_part; k.gn_HW = a.gn_HW; k.gn_G = a.gn_G; k.gn_S = 0;
   if (a.gn_done) *a.gn_done = 0;
   if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st, a.gn_done);
