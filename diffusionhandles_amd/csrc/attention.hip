@@ -125,18 +125,31 @@ __device__ __forceinline__ uint4 pack8<bf16>(const v16f& p, int s) {
   return *reinterpret_cast<uint4*>(o);
 }
 
-// store a transposed accumulator pair (rows = d, col = lane's row) as row `row` of a [rows][ld] matrix
+// store a transposed accumulator pair (rows = d, col = lane's row) as row `row` of a [rows][ld] matrix.  The two lanes
+// of a row (lane, lane ^ 32) own alternating 4-column groups: they swap two groups and write 16-byte chunks.
+// Must be called by both lanes of a pair (the guard `row valid` is the same for both).
 template <class T>
 __device__ __forceinline__ void store_rows_t(T* base, long ld, long row, int col0, int hi, const v16f (&acc)[2], float mul) {
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < 2; ++dt) {
+    uint2 w[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       T o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(acc[dt][4 * g + i] * mul);
-      *reinterpret_cast<uint2*>(base + row * ld + col0 + dt * 32 + 8 * g + 4 * hi) = *reinterpret_cast<uint2*>(o);
+      w[g] = *reinterpret_cast<uint2*>(o);
     }
+    const uint2 sa = hi ? w[0] : w[1], sb = hi ? w[2] : w[3];
+    uint2 ra, rb;
+    ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
+    rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
+    const uint4 ca = hi ? make_uint4(ra.x, ra.y, w[1].x, w[1].y) : make_uint4(w[0].x, w[0].y, ra.x, ra.y);
+    const uint4 cb = hi ? make_uint4(rb.x, rb.y, w[3].x, w[3].y) : make_uint4(w[2].x, w[2].y, rb.x, rb.y);
+    T* out = base + row * ld + col0 + dt * 32 + 8 * hi;
+    *reinterpret_cast<uint4*>(out) = ca;
+    *reinterpret_cast<uint4*>(out + 16) = cb;
+  }
 }
 
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
