@@ -140,11 +140,20 @@ __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, con
       for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
     }
     if (BWD) {
+      // vector loads: the affine parameters of the 8 channels and the (mean, rstd) pairs of the 4 groups
+      *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(gamma + g0 * cpg + ch * 8);
+      *reinterpret_cast<float4*>(gm + 4) = *reinterpret_cast<const float4*>(gamma + g0 * cpg + ch * 8 + 4);
+      *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(beta + g0 * cpg + ch * 8);
+      *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(beta + g0 * cpg + ch * 8 + 4);
+      float2 st4[GN_GB];
+#pragma unroll
+      for (int gl = 0; gl < GN_GB; ++gl)
+        st4[gl] = g0 + gl < G ? *reinterpret_cast<const float2*>(stats + 2 * (b * G + g0 + gl)) : make_float2(0.f, 0.f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int sg = b * G + g0 + gi[i];
-        gm[i] = gamma[g0 * cpg + ch * 8 + i]; bt[i] = beta[g0 * cpg + ch * 8 + i];
-        mu[i] = stats[2 * sg]; rs[i] = stats[2 * sg + 1];
+        mu[i] = 0.f; rs[i] = 0.f;
+#pragma unroll
+        for (int gl = 0; gl < GN_GB; ++gl) { mu[i] = gi[i] == gl ? st4[gl].x : mu[i]; rs[i] = gi[i] == gl ? st4[gl].y : rs[i]; }
       }
     }
     for (int r = r0 + rr; r < r1; r += RP) {
