@@ -880,10 +880,10 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
       }
       case OP_CONCAT: {
         if (!u->gready[o.out]) break;
-        const Ten &a = u->tens[o.in0], &t = u->tens[o.out];
-        bw.add_into(o.in0, u->gptr(o.out), t.C, a.C);
+        const Ten &a = u->tens[o.in0], &b2 = u->tens[o.in1], &t = u->tens[o.out];
+        launch_split_cols(dt, u->gptr(o.out), t.C, u->gptr(o.in0), a.C, a.C, u->gready[o.in0] ? 1 : 0, u->gptr(o.in1), b2.C,
+                          b2.C, u->gready[o.in1] ? 1 : 0, B * t.rows, st);
         u->gready[o.in0] = 1;
-        bw.add_into(o.in1, u->gptr(o.out) + a.C, t.C, u->tens[o.in1].C);
         u->gready[o.in1] = 1;
         break;
       }

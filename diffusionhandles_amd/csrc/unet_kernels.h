@@ -70,6 +70,9 @@ void launch_geglu_bwd(int dtype, const void* x, const void* dy, void* dx, int ro
 // misc
 void launch_copy_cols(int dtype, const void* src, long lds, void* dst, long ldd, int rows, int cols, int accumulate,
                       hipStream_t st);                       // dst[r][0..cols) (=|+=) src[r][0..cols)
+// src [rows][colsA + colsB] split into dstA (=|+=) and dstB (=|+=) in one launch (concat backward)
+void launch_split_cols(int dtype, const void* src, long lds, void* dstA, long ldA, int colsA, int accA, void* dstB, long ldB,
+                       int colsB, int accB, int rows, hipStream_t st);
 void launch_pool2x2_sum(int dtype, const void* src, void* dst, int B, int h, int w, int C, int accumulate,
                         hipStream_t st);                     // dst[b][y][x] (=|+=) sum of the 2x2 block of src
 void launch_f32_to_t(int dtype, const float* src, void* dst, size_t n, hipStream_t st);

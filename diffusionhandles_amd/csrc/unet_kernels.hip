@@ -631,6 +631,38 @@ void launch_copy_cols(int dtype, const void* src, long lds_, void* dst, long ldd
   else hipLaunchKernelGGL((k_copy_cols<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)src, lds_, (bf16*)dst, ldd, (size_t)rows, cols, accumulate);
 }
 
+// backward of a channel concat in ONE launch: src [rows][colsA + colsB] -> dstA (=|+=) left part, dstB (=|+=) right part
+template <class T>
+__global__ void k_split_cols(const T* src, long lds_, T* dstA, long ldA, int colsA, int accA, T* dstB, long ldB, int colsB,
+                             int accB, size_t rows) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cch = (colsA + colsB) / 8;
+  if (idx >= rows * cch) return;
+  const size_t row = idx / cch;
+  const int c0 = (int)(idx - row * cch) * 8;
+  uint4 v = *reinterpret_cast<const uint4*>(src + row * lds_ + c0);
+  const bool left = c0 < colsA;
+  T* dst = left ? dstA + row * ldA + c0 : dstB + row * ldB + (c0 - colsA);
+  if (left ? accA : accB) {
+    uint4 o = *reinterpret_cast<const uint4*>(dst);
+    const T* a = reinterpret_cast<const T*>(&v);
+    const T* b = reinterpret_cast<const T*>(&o);
+    T r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]));
+    v = *reinterpret_cast<uint4*>(r);
+  }
+  *reinterpret_cast<uint4*>(dst) = v;
+}
+void launch_split_cols(int dtype, const void* src, long lds_, void* dstA, long ldA, int colsA, int accA, void* dstB, long ldB,
+                       int colsB, int accB, int rows, hipStream_t st) {
+  const unsigned nb = (unsigned)(((size_t)rows * ((colsA + colsB) / 8) + 255) / 256);
+  if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_split_cols<f16>), dim3(nb), dim3(256), 0, st, (const f16*)src, lds_, (f16*)dstA, ldA, colsA, accA, (f16*)dstB, ldB, colsB, accB, (size_t)rows);
+  else
+    hipLaunchKernelGGL((k_split_cols<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)src, lds_, (bf16*)dstA, ldA, colsA, accA, (bf16*)dstB, ldB, colsB, accB, (size_t)rows);
+}
+
 template <class T>
 __global__ void k_pool2x2(const T* src, T* dst, int B, int h, int w, int C, int accumulate) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
