@@ -103,6 +103,12 @@ def test_engine_sd2_depth_full_size_fp16():
     run_case(U.SD2_DEPTH, torch.float16, 1, 500.0, 2e-2, 6e-2)
 
 
+def test_engine_sd2_depth_full_size_bf16_batch2():
+    """BASELINE config 5 computes the U-Net in bf16: full configuration, B=2 (the CFG pass shape), bf16 tolerance."""
+    from oracle import unet_torch as U
+    run_case(U.SD2_DEPTH, torch.bfloat16, 2, 261.0, 3e-2, 5e-2, check_text=False)   # measured 1.1e-2 / 1.5e-2
+
+
 def test_engine_truncated_forward_matches_full():
     """want_eps=False stops the tape after the last requested activation: that activation and the
     gradient from it must be bit-identical to the full pass (same kernels, same order)."""
