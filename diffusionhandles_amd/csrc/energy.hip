@@ -204,23 +204,34 @@ __global__ void k_colsum(const float* X, const int* list, int n, int C, int S, f
   part[(size_t)s * C + c] = acc;
 }
 
-// sgn[c] = sign(m1 - m2), loss_c = |m1 - m2|; one wave per 64 channels, slice partials added in slice order
+// sgn[c] = sign(m1 - m2), loss_c = |m1 - m2|.  Workgroup = 64 channels x 4 waves: wave q adds the slice partials of
+// quarter q in slice order, the four quarter sums are added in quarter order (fixed tree: deterministic)
 constexpr int GD_BLOCK = 64;
-__global__ void __launch_bounds__(GD_BLOCK) k_global_diff(const float* p1, const float* p2, int S, int C, int n1, int n2,
-                                                          float* sgn, double* loss_part) {
-  const int c = blockIdx.x * GD_BLOCK + threadIdx.x;
-  double l = 0.0;
+__global__ void __launch_bounds__(4 * GD_BLOCK) k_global_diff(const float* p1, const float* p2, int S, int C, int n1, int n2,
+                                                              float* sgn, double* loss_part) {
+  __shared__ float sq[2][4][GD_BLOCK];
+  const int cl = threadIdx.x & (GD_BLOCK - 1), q = threadIdx.x / GD_BLOCK;
+  const int c = blockIdx.x * GD_BLOCK + cl;
+  const int per = (S + 3) / 4, s0 = q * per, s1 = s0 + per < S ? s0 + per : S;
+  float a = 0.f, b = 0.f;
   if (c < C) {
-    float a = 0.f, b = 0.f;
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
       float va[8], vb[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { va[j] = p1[(size_t)(s + j) * C + c]; vb[j] = p2[(size_t)(s + j) * C + c]; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) { a += va[j]; b += vb[j]; }
     }
-    for (; s < S; ++s) { a += p1[(size_t)s * C + c]; b += p2[(size_t)s * C + c]; }
+    for (; s < s1; ++s) { a += p1[(size_t)s * C + c]; b += p2[(size_t)s * C + c]; }
+  }
+  sq[0][q][cl] = a; sq[1][q][cl] = b;
+  __syncthreads();
+  if (q != 0) return;
+  double l = 0.0;
+  if (c < C) {
+    a = ((sq[0][0][cl] + sq[0][1][cl]) + sq[0][2][cl]) + sq[0][3][cl];
+    b = ((sq[1][0][cl] + sq[1][1][cl]) + sq[1][2][cl]) + sq[1][3][cl];
     const float d = a / (float)n1 - b / (float)n2;
     sgn[c] = (float)((d > 0.f) - (d < 0.f));
     l = (double)fabsf(d);
@@ -256,7 +267,7 @@ struct EnergyWs {
   uint8_t *w1, *w2;
   double *fg_part, *bg_part;
 };
-constexpr int COLSUM_S = 32;
+constexpr int COLSUM_S = 128;     // slices of a background column sum (more slices = shorter serial gather chains)
 
 static bool carve_energy(Arena& a, int C, int grid, int n_pairs, EnergyWs& w) {
   const size_t G2 = (size_t)grid * grid, M = G2 * C;
@@ -312,13 +323,14 @@ static void pair_term(const EnergyWs& w, const int* pairs, int n, int C, int gri
 //                           k_final_loss  (only when the caller wants the loss values)
 // Same arithmetic, in the same order per element, as the general path above: the gradient is bit-identical.
 struct EnergyPlan {
-  int *off, *src, *cnt, *cursor;
-  uint8_t *bgflag, *w1, *w2;
+  int *off, *src, *cnt, *cursor, *mult;      // after the build: cnt[t] = number of DISTINCT sources of target t,
+  uint8_t *bgflag, *w1, *w2;                 // src / mult [off[t], off[t] + cnt[t]) = their cells (ascending) / multiplicities
 };
 static bool carve_plan(Arena& a, int grid, int n_pairs, EnergyPlan& p) {
   const size_t G2 = (size_t)grid * grid;
   p.off = a.take<int>(G2 + 1); p.cnt = a.take<int>(G2 + 1); p.cursor = a.take<int>(G2 + 1);
   p.src = a.take<int>(n_pairs > 0 ? n_pairs : 1);
+  p.mult = a.take<int>(n_pairs > 0 ? n_pairs : 1);
   p.bgflag = a.take<uint8_t>(G2); p.w1 = a.take<uint8_t>(G2); p.w2 = a.take<uint8_t>(G2);
   return a.ok();
 }
@@ -332,6 +344,34 @@ static bool carve_planned(Arena& a, int C, int grid, PlannedWs& w) {
   w.sgn = a.take<float>(C);
   w.fg_part = a.take<double>(G2); w.bg_part = a.take<double>(cdiv(C, GD_BLOCK));
   return a.ok();
+}
+
+// one workgroup per target cell: its source list (one entry per pixel pair: ~8x8 pixels share a cell pair) becomes
+// (distinct source cell, multiplicity) in ascending cell order, through an LDS histogram over the grid's cells
+__global__ void __launch_bounds__(256) k_dedupe_sources(const int* off, int* src, int* mult, int* ucnt, int G2) {
+  extern __shared__ int hist[];          // [G2] counts, then [256] scan scratch
+  int* scan = hist + G2;
+  const int t = blockIdx.x, b = off[t], e = off[t + 1];
+  if (b == e) { if (threadIdx.x == 0) ucnt[t] = 0; return; }
+  for (int c = threadIdx.x; c < G2; c += blockDim.x) hist[c] = 0;
+  __syncthreads();
+  for (int k = b + threadIdx.x; k < e; k += blockDim.x) atomicAdd(&hist[src[k]], 1);
+  __syncthreads();
+  const int per = (G2 + blockDim.x - 1) / blockDim.x, c0 = threadIdx.x * per, c1 = min(c0 + per, G2);
+  int mine = 0;
+  for (int c = c0; c < c1; ++c) mine += hist[c] != 0;
+  scan[threadIdx.x] = mine;
+  __syncthreads();
+  for (int o = 1; o < (int)blockDim.x; o <<= 1) {
+    const int v = (int)threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+    __syncthreads();
+    scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int pos = b + scan[threadIdx.x] - mine;
+  for (int c = c0; c < c1; ++c)
+    if (hist[c]) { src[pos] = c; mult[pos] = hist[c]; ++pos; }
+  if (threadIdx.x == blockDim.x - 1) ucnt[t] = scan[threadIdx.x];
 }
 
 __global__ void k_flag_cells(const int* list, int n, uint8_t* flag) {
@@ -382,8 +422,8 @@ __global__ void k_colsum16(const T* X1, const int* list1, int n1, float* part1, 
 
 // thread = (target cell, 8-channel chunk); block = 256 / (C/8) cells
 template <class T, class TG>
-__global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur, const int* off, const int* src,
-                                                     const uint8_t* bgflag, const float* sgn, int C, int G2, float coef_fg,
+__global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur, const int* off, const int* ucnt,
+                                                     const int* src, const int* mult, const uint8_t* bgflag, const float* sgn, int C, int G2, float coef_fg,
                                                      float coef_bg, int use_bg, float scale, TG* grad, double* loss_part) {
   __shared__ double sm[4];
   const int nch = C / 8, cpb = (int)blockDim.x / nch;
@@ -397,13 +437,13 @@ __global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur
     int sg[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[i] = to_f32<T>(av[i]); sg[i] = 0; }
-    const int b = off[cell], e = off[cell + 1];
+    const int b = off[cell], e = b + ucnt[cell];
     int k = b;
-    for (; k + 8 <= e; k += 8) {        // 8 source rows in flight
-      int id[8];
+    for (; k + 8 <= e; k += 8) {        // 8 distinct source rows in flight
+      int id[8], mu[8];
       uint4 ro[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) id[j] = src[k + j];
+      for (int j = 0; j < 8; ++j) { id[j] = src[k + j]; mu[j] = mult[k + j]; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) ro[j] = *reinterpret_cast<const uint4*>(orig + (size_t)id[j] * C + ch * 8);
 #pragma unroll
@@ -412,19 +452,20 @@ __global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float d = to_f32<T>(ov[i]) - a[i];
-          la += (double)fabsf(d);
-          sg[i] += (d > 0.f) - (d < 0.f);
+          la += (double)mu[j] * (double)fabsf(d);
+          sg[i] += mu[j] * ((d > 0.f) - (d < 0.f));
         }
       }
     }
     for (; k < e; ++k) {
       const uint4 ro = *reinterpret_cast<const uint4*>(orig + (size_t)src[k] * C + ch * 8);
+      const int mu = mult[k];
       const T* ov = reinterpret_cast<const T*>(&ro);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float d = to_f32<T>(ov[i]) - a[i];
-        la += (double)fabsf(d);
-        sg[i] += (d > 0.f) - (d < 0.f);
+        la += (double)mu * (double)fabsf(d);
+        sg[i] += mu * ((d > 0.f) - (d < 0.f));
       }
     }
     const bool bg = use_bg && bgflag[cell];
@@ -501,7 +542,7 @@ extern "C" int dh_energy_fwd_bwd(const void* cur, const void* orig, int dtype, i
                          COLSUM_S, w.part1);
       hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 256), COLSUM_S), dim3(256), 0, st, w.cur, bg_trans, n_bg_trans, C,
                          COLSUM_S, w.part2);
-      hipLaunchKernelGGL(k_global_diff, dim3(cdiv(C, GD_BLOCK)), dim3(GD_BLOCK), 0, st, w.part1, w.part2, COLSUM_S, C,
+      hipLaunchKernelGGL(k_global_diff, dim3(cdiv(C, GD_BLOCK)), dim3(4 * GD_BLOCK), 0, st, w.part1, w.part2, COLSUM_S, C,
                          n_bg_orig, n_bg_trans, w.sgn, w.bg_part);
       bg_norm = 1.f / (float)C;
       hipLaunchKernelGGL(k_global_apply, dim3(n_bg_trans), dim3(256), 0, st, bg_trans, n_bg_trans, w.sgn, C,
@@ -549,6 +590,10 @@ extern "C" int dh_energy_plan_build(const int32_t* pairs, int n_pairs, const int
   if (n_pairs > 0) hipLaunchKernelGGL(k_hist, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, p.cnt, p.w1, p.w2);
   hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, p.cnt, G2, p.off, p.cursor);
   if (n_pairs > 0) hipLaunchKernelGGL(k_fill, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, p.cursor, p.src);
+  if (n_pairs > 0)
+    hipLaunchKernelGGL(k_dedupe_sources, dim3(G2), dim3(256), (size_t)(G2 + 256) * sizeof(int), st, p.off, p.src, p.mult, p.cnt, G2);
+  else
+    DH_CHECK_HIP(hipMemsetAsync(p.cnt, 0, (G2 + 1) * sizeof(int), st));
   if (n_bg_trans > 0) hipLaunchKernelGGL(k_flag_cells, dim3(cdiv(n_bg_trans, 256)), dim3(256), 0, st, bg_trans, n_bg_trans, p.bgflag);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -567,8 +612,8 @@ template <class T, class TG>
 static void launch_energy_grad(const void* orig, const void* cur, const EnergyPlan& p, const PlannedWs& w, int C, int G2,
                                float coef_fg, float coef_bg, int use_bg, float scale, void* grad, int nblocks,
                                hipStream_t st) {
-  hipLaunchKernelGGL((k_energy_grad<T, TG>), dim3(nblocks), dim3(256), 0, st, (const T*)orig, (const T*)cur, p.off, p.src,
-                     p.bgflag, w.sgn, C, G2, coef_fg, coef_bg, use_bg, scale, (TG*)grad, w.fg_part);
+  hipLaunchKernelGGL((k_energy_grad<T, TG>), dim3(nblocks), dim3(256), 0, st, (const T*)orig, (const T*)cur, p.off, p.cnt,
+                     p.src, p.mult, p.bgflag, w.sgn, C, G2, coef_fg, coef_bg, use_bg, scale, (TG*)grad, w.fg_part);
 }
 
 extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int dtype, int C, int grid, const void* plan,
@@ -601,7 +646,7 @@ extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int 
     else
       hipLaunchKernelGGL((k_colsum16<bf16>), dim3(cdiv(nthreads, 256), 2), dim3(256), 0, st, (const bf16*)orig, bg_orig,
                          n_bg_orig, w.part1, (const bf16*)cur, bg_trans, n_bg_trans, w.part2, C, COLSUM_S);
-    hipLaunchKernelGGL(k_global_diff, dim3(cdiv(C, GD_BLOCK)), dim3(GD_BLOCK), 0, st, w.part1, w.part2, COLSUM_S, C, n_bg_orig,
+    hipLaunchKernelGGL(k_global_diff, dim3(cdiv(C, GD_BLOCK)), dim3(4 * GD_BLOCK), 0, st, w.part1, w.part2, COLSUM_S, C, n_bg_orig,
                        n_bg_trans, w.sgn, w.bg_part);
     bg_norm = 1.f / (float)C;
     coef_bg = bg_w * bg_norm / (float)n_bg_trans;

@@ -150,7 +150,7 @@ int dh_energy_fwd_bwd(const void* cur, const void* orig, int dtype, int C, int h
 
 /* Planned form of the same evaluation for the default configuration (maps already at the cell grid,
  * fg_patch 1, bg 'global_avg' -- config/default.yaml:5-9), 16-bit activations.  The correspondences of an
- * edit are fixed over its 38 x 3 evaluations, so the target-cell -> source-cells CSR and the
+ * edit are fixed over its 38 x 3 evaluations, so the target-cell -> (distinct source cell, multiplicity) CSR and the
  * transformed-background flags are built ONCE (dh_energy_plan_build) and every evaluation is three kernels
  * that read the activations once in their own dtype.  Same arithmetic per element as dh_energy_fwd_bwd:
  * the gradient is bit-identical.  loss_out may be NULL (the guided loop only needs the gradient). */
