@@ -63,6 +63,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   float* partial;
   int splits, k_per_split;
   float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
+  const void* gnb_x; long gnb_ldx; const float *gnb_gamma, *gnb_beta, *gnb_stats; int gnb_silu;   // backward statistics
 };
 
 constexpr int BK = 64;
@@ -469,7 +470,7 @@ __global__ void k_splitk_reduce(const GemmK p) {
 // split-K reduce fused with the GroupNorm slice statistics of its output (the next op of a resnet's conv is a
 // GroupNorm): workgroup = (row slice, 4 groups, image) like k_gn_partial; a thread sums the slabs of 8 channels of a
 // row, applies the epilogue, stores the 16-bit result and accumulates the pivot-shifted sums of the ROUNDED values.
-template <class T>
+template <class T, bool BWD>
 __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
   __shared__ float sm_piv[GN_GB];
   __shared__ float sm_red[4][2 * GN_GB];
@@ -502,6 +503,18 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
     float bias8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias8[i] = p.bias ? p.bias[n + i] : 0.f;
+    float gm[8], bt[8], mu[8], rs[8];
+    if (BWD) {           // output = dy of a GroupNorm: accumulate sum d and sum d * xhat (d = dy * gamma * act')
+      *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(p.gnb_gamma + n);
+      *reinterpret_cast<float4*>(gm + 4) = *reinterpret_cast<const float4*>(p.gnb_gamma + n + 4);
+      *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(p.gnb_beta + n);
+      *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(p.gnb_beta + n + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sg = b * G + g0 + gi[i];
+        mu[i] = p.gnb_stats[2 * sg]; rs[i] = p.gnb_stats[2 * sg + 1];
+      }
+    }
     for (int r = r0 + rr; r < r1; r += RP) {
       const int m = b * HW + r;
       float v[8];
@@ -546,11 +559,25 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
         for (int i = 0; i < 8; ++i) v[i] += to_f32<T>(rv[i]);
       }
       T o[8];
+      if (!BWD) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        o[i] = from_f32<T>(v[i]);
-        const float d = to_f32<T>(o[i]) - pv[i];
-        av[i] += d; qv[i] += d * d;
+        for (int i = 0; i < 8; ++i) {
+          o[i] = from_f32<T>(v[i]);
+          const float d = to_f32<T>(o[i]) - pv[i];
+          av[i] += d; qv[i] += d * d;
+        }
+      } else {
+        const uint4 rawx = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.gnb_x) + (size_t)m * p.gnb_ldx + n);
+        const T* xv = reinterpret_cast<const T*>(&rawx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          o[i] = from_f32<T>(v[i]);
+          const float xh = (to_f32<T>(xv[i]) - mu[i]) * rs[i];
+          float d = to_f32<T>(o[i]);
+          if (p.gnb_silu) d *= silu_grad(xh * gm[i] + bt[i]);
+          d *= gm[i];
+          av[i] += d; qv[i] += d * xh;
+        }
       }
       *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = *reinterpret_cast<uint4*>(o);
     }
@@ -573,9 +600,14 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
     const int gl = threadIdx.x, g = g0 + gl;
     float sa = 0.f, sq = 0.f;
     for (int w = 0; w < 4; ++w) { sa += sm_red[w][2 * gl]; sq += sm_red[w][2 * gl + 1]; }
-    const float cnt = (float)(r1 - r0) * (float)cpg;
-    float* o = p.gn_part + ((size_t)(b * G + g) * 3) * S + s;
-    o[0] = cnt; o[S] = sm_piv[gl] + sa / cnt; o[2 * S] = sq - sa * sa / cnt;
+    if (BWD) {
+      p.gn_part[((size_t)(b * G + g) * S + s) * 2] = sa;
+      p.gn_part[((size_t)(b * G + g) * S + s) * 2 + 1] = sq;
+    } else {
+      const float cnt = (float)(r1 - r0) * (float)cpg;
+      float* o = p.gn_part + ((size_t)(b * G + g) * 3) * S + s;
+      o[0] = cnt; o[S] = sm_piv[gl] + sa / cnt; o[2 * S] = sq - sa * sa / cnt;
+    }
   }
 }
 
@@ -671,7 +703,8 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
     if (k.gn_part && k.gn_G > 0 && k.gn_HW > 0 && k.N % k.gn_G == 0 && (GN_GB * (k.N / k.gn_G)) % 8 == 0 &&
         GN_GB * (k.N / k.gn_G) <= 2048 && k.M % k.gn_HW == 0) {
       k.gn_S = gn_slices(k.gn_HW);
-      hipLaunchKernelGGL((k_splitk_reduce_gn<T>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
+      if (k.gnb_x) hipLaunchKernelGGL((k_splitk_reduce_gn<T, true>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
+      else hipLaunchKernelGGL((k_splitk_reduce_gn<T, false>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
       if (gn_done) *gn_done = 1;
     } else {
       const size_t groups = (size_t)k.M * k.N / 4;
@@ -694,6 +727,8 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   static const int kWide = getenv("DH_GEMM_WIDE_STORE") ? atoi(getenv("DH_GEMM_WIDE_STORE")) : 1;
   k.wide_store = kWide && a.N % 32 == 0 && a.ldc % 8 == 0 && ((size_t)a.C & 15) == 0;
   k.gn_part = a.gn_part; k.gn_HW = a.gn_HW; k.gn_G = a.gn_G; k.gn_S = 0;
+  k.gnb_x = a.gnb_x; k.gnb_ldx = a.gnb_ldx; k.gnb_gamma = a.gnb_gamma; k.gnb_beta = a.gnb_beta; k.gnb_stats = a.gnb_stats;
+  k.gnb_silu = a.gnb_silu;
   if (a.gn_done) *a.gn_done = 0;
   if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st, a.gn_done);
   else gemm_dispatch<bf16>(k, a.partial_elems, st, a.gn_done);

@@ -758,6 +758,7 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
     if (act_mask & (1u << i)) u->gready[u->act_ids[i]] = 1;     // seeded by the caller's copy
   Bwd bw{u, B, dt, st, d_text != nullptr};
   bool text_grad_written = false;
+  int gnb_have = 0, gnb_for = -1;       // the split-K reduce just run left the backward statistics of GroupNorm op gnb_for
   for (int oi = (int)u->ops.size() - 1; oi >= 0; --oi) {
     const Op& o = u->ops[oi];
     switch (o.type) {
@@ -817,6 +818,18 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
           g.M = B * o.Hin * o.Win; g.N = o.Cin; g.K = 9 * w.N;
           g.C = u->gptr(o.in0); g.ldc = ti.C;
           if (u->gready[o.in0]) { g.R = g.C; g.ldr = ti.C; }
+          gnb_have = 0;
+          if (oi > 0 && u->ops[oi - 1].type == OP_GN && u->ops[oi - 1].out == o.in0) {
+            // the gradient being written is dy of the GroupNorm that is processed next: a split-K reduce also leaves
+            // that GroupNorm's backward slice statistics
+            const Op& gn = u->ops[oi - 1];
+            const Ten& tx = u->tens[gn.in0];
+            g.gnb_x = u->aptr(gn.in0); g.gnb_ldx = tx.C;
+            g.gnb_gamma = u->pf + gn.gamma_off; g.gnb_beta = u->pf + gn.beta_off; g.gnb_stats = u->f32a + gn.stats_off;
+            g.gnb_silu = gn.silu;
+            g.gn_part = u->small; g.gn_HW = tx.rows; g.gn_G = gn.groups; g.gn_done = &gnb_have;
+            gnb_for = oi - 1;
+          }
           u->flops_bwd += launch_gemm(dt, g, st);
           u->gready[o.in0] = 1;
         }
@@ -828,7 +841,8 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
         const Ten& t = u->tens[o.in0];
         launch_groupnorm_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->pf + o.gamma_off, u->pf + o.beta_off,
                              u->f32a + o.stats_off, u->gptr(o.in0), u->small, B, t.rows, t.C, o.groups, o.silu,
-                             u->gready[o.in0] ? 1 : 0, st);
+                             u->gready[o.in0] ? 1 : 0, st, gnb_have && gnb_for == oi);
+        gnb_have = 0;
         u->gready[o.in0] = 1;
         break;
       }

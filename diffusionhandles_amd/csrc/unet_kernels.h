@@ -5,6 +5,11 @@
 
 namespace dh {
 
+__device__ inline float silu_grad(float z) {
+  const float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONVT2 = 2 };
 
 struct GemmArgs {
@@ -24,6 +29,10 @@ struct GemmArgs {
   // optional: the output feeds a GroupNorm next.  When the launch goes through the split-K reduce, that kernel
   // also leaves the GroupNorm slice statistics (gn_partial layout) and *gn_done is set to 1.
   float* gn_part = nullptr; int gn_HW = 0, gn_G = 0; int* gn_done = nullptr;
+  // gnb_x != NULL: the output is the gradient dy of a GroupNorm(+SiLU) whose INPUT is gnb_x; the reduce then leaves the
+  // backward slice statistics (sum d, sum d*xhat with d = dy * gamma * act') in gn_part (k_gn_partial<bwd> layout)
+  const void* gnb_x = nullptr; long gnb_ldx = 0; const float *gnb_gamma = nullptr, *gnb_beta = nullptr, *gnb_stats = nullptr;
+  int gnb_silu = 0;
 };
 // D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
@@ -57,7 +66,7 @@ void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, v
 // dx (=|+=) d gn-act / d x
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
-                          int accumulate, hipStream_t st);
+                          int accumulate, hipStream_t st, int have_partials = 0);
 // LayerNorm over C per row; stats [rows][2]
 void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           int rows, int C, float eps, hipStream_t st);

@@ -97,10 +97,7 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
 
 // ----------------------------------------------------------------------------- GroupNorm
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
-__device__ __forceinline__ float silu_grad(float z) {
-  const float s = 1.f / (1.f + __expf(-z));
-  return s * (1.f + z * (1.f - s));
-}
+// silu_grad: unet_kernels.h (shared with the split-K reduce that produces the backward statistics)
 
 // GroupNorm statistics in two deterministic stages:
 //   k_gn_partial  grid (S, G/4, B): a workgroup owns one row slice x 4 adjacent groups, reads the 4*cpg
@@ -328,14 +325,14 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
 
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
-                          int accumulate, hipStream_t st) {
+                          int accumulate, hipStream_t st, int have_partials) {
   const int S = gn_slices(HW);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
   if (dtype == DH_DTYPE_F16) {
-    hipLaunchKernelGGL((k_gn_partial<f16, true>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    if (!have_partials) hipLaunchKernelGGL((k_gn_partial<f16, true>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_bwd_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate);
   } else {
-    hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
+    if (!have_partials) hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
     hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate);
   }
 }
