@@ -138,3 +138,21 @@ def test_batched_edits_match_single_edits(rig):
         err = rel(batched[e:e + 1], rig.gd.last_latents)
         print("batched vs single edit", e, err)
         assert err < 5e-2
+
+
+def test_guided_inference_is_bit_deterministic(rig):
+    """No float atomics anywhere on the path (split-K slabs in slice order, integer sign sums, fixed-tree GroupNorm /
+    attention merges): two runs of the whole 50-step guided loop give identical latents, bit for bit."""
+    from diffusionhandles_amd.depth_transform import transform_depth
+    if not hasattr(rig, "acts"):
+        test_initial_inference_matches_oracle(rig)
+    ang, tr = TRANSFORMS[3]
+    K = rig.gd.get_depth_intrinsics()
+    disp_e, corr = transform_depth(rig.depth.to(dev()), rig.bg.to(dev()), rig.mask.to(dev()), K, rot_angle=ang,
+                                   rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor(tr))
+    unc = rig.unc0[None].expand(50, -1, -1, -1).contiguous()
+    outs = []
+    for _ in range(2):
+        rig.gd.guided_inference(rig.noise.to(dev()), disp_e, unc, rig.prompt, rig.acts, corr)
+        outs.append(rig.gd.last_latents.clone())
+    assert torch.equal(outs[0], outs[1])
