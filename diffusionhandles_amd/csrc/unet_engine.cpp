@@ -89,6 +89,10 @@ struct dh_unet {
   int t_text = -1, t_kv = -1, t_conv_in_out = -1, t_final = -1, act_ids[3] = {-1, -1, -1};
   int act_op_end[3] = {0, 0, 0};   // ops [0, act_op_end[i]) produce captured activation i
   int saved_ops = 0;                // number of tape ops the saved forward executed
+  // the time-embedding chain (sinusoid -> MLP -> all resnet projections) depends on the timestep only: the 7 passes of
+  // a guided step share it.  temb_rows images hold the projections of timestep temb_t (0 rows = nothing cached).
+  int temb_ops = 0, temb_rows = 0;
+  float temb_t = 0.f;
   long temb_f32_off = -1;
   int temb_total = 0, kv_total = 0;
   // staging buffers (fixed addresses so a captured graph can be replayed) and graph cache
@@ -335,6 +339,7 @@ int build(dh_unet& u) {
   int t_temb = b.linear_w(e2, b.wt_temb, (long)b.temb_bias_off, -1, 0, 0, false, false);
   u.temb_f32_off = (long)b.f32_slot((size_t)c.max_batch * u.temb_total);
   { Op o; o.type = OP_T2F; o.in0 = t_temb; u.ops.push_back(o); }
+  u.temb_ops = (int)u.ops.size();      // ops [0, temb_ops) depend on the timestep only
 
   // ---- text: hoisted K|V projections of every cross-attention ------------------------------
   u.t_text = b.tensor(c.text_len, c.cross_attention_dim, true);
@@ -521,6 +526,7 @@ extern "C" int dh_unet_param_info(const dh_unet* u, int i, const char** name, in
 }
 
 extern "C" int dh_unet_load_param(dh_unet* u, int i, const float* src, void* stream) {
+  if (u) u->temb_rows = 0;      // cached time-embedding projections belong to the old weights
   DH_REQUIRE(u && src && i >= 0 && i < (int)u->params.size(), "bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const ParamInfo& p = u->params[i];
@@ -577,13 +583,13 @@ static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
   g.partial = u->partial; g.partial_elems = u->partial_elems;
 }
 
-static void forward_ops(dh_unet* u, int B, int n_ops, hipStream_t st) {
+static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, hipStream_t st) {
   const int dt = u->dtype;
   const dh_unet_config& c = u->cfg;
   u->flops_fwd = 0;
   int gn_have = 0;       // the op just executed left the GroupNorm slice statistics of its output in u->small
   launch_f32_to_t(dt, u->in_text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
-  for (int oi = 0; oi < n_ops; ++oi) {
+  for (int oi = first_op; oi < n_ops; ++oi) {
     const Op& o = u->ops[oi];
     switch (o.type) {
       case OP_TIMESTEP:
@@ -712,7 +718,11 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
       if (act_out && act_out[i]) n_ops = std::max(n_ops, u->act_op_end[i]);
     DH_REQUIRE(n_ops > 0, "nothing requested: eps_out and every act_out are null");
   }
-  int rc = run_graphed(u, 0x80000000u | (unsigned)B | ((unsigned)n_ops << 8), st, &u->flops_fwd, [&]() { forward_ops(u, B, n_ops, st); });
+  const bool temb_hit = u->temb_rows >= B && u->temb_t == timestep;
+  const int first_op = temb_hit ? u->temb_ops : 0;
+  int rc = run_graphed(u, 0x80000000u | (temb_hit ? 0x40000000u : 0u) | (unsigned)B | ((unsigned)n_ops << 8), st, &u->flops_fwd,
+                       [&]() { forward_ops(u, B, n_ops, first_op, st); });
+  if (!temb_hit) { u->temb_t = timestep; u->temb_rows = B; }
   if (rc != DH_OK) return rc;
   if (eps_out) DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
   if (act_out) {
