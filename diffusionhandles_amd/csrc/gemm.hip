@@ -147,16 +147,20 @@ enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
 // KG > 1: KG groups of four waves with a ring each work on DISJOINT K ranges of the block's tile (split-K inside
 // the workgroup): a GEMM with few output tiles and a long K loop is bounded by the serial depth of that loop
 // (~0.6 us per K tile), and this divides the depth by KG without partial slabs in HBM or a reduce launch.
-template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
-__global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
-  static_assert(WG == 1 || KG == 1, "one kind of wave grouping per instantiation");
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int NPA = BM / 32 / WG, NPB = BN / 32 / WG;     // 1-KiB pieces per wave per stage
+// MW = 2: eight waves laid out 4 (M) x 2 (N) over a 256-row tile, 64 x (BN/2) outputs per wave as before: the A and W
+// tiles are shared by twice the MFMA work, so the staging traffic per flop (the TA / LDS-DMA issue that bounds the
+// 4-wave kernel on big grids) drops by a quarter and two waves share every SIMD.  For grids that fill the machine.
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
+__global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) {
+  static_assert((WG == 1) + (KG == 1) + (MW == 1) >= 2, "one kind of wave grouping per instantiation");
+  constexpr int NWV = 4 * MW;                               // waves that share one staged tile
+  constexpr int TM = BM / 64 / MW, TN = BN / 64;
+  constexpr int NPA = BM / 32 / WG / MW, NPB = BN / 32 / WG / MW;     // 1-KiB pieces per wave per stage
   constexpr int NP = NPA + NPB;
   constexpr int STAGE = (BM + BN) * 128;
   __shared__ __attribute__((aligned(1024))) unsigned char smem_all[KG * ST * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & (NWV - 1);
   const int grp = WG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;     // wave-uniform (feeds m0 through dma16)
   const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
   unsigned char* smem = smem_all + kg * (ST * STAGE);
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
   int a_oy[NPA], a_ox[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
-    const int m = m0 + 8 * (wave + 4 * (j * WG + grp)) + prow;
+    const int m = m0 + 8 * (wave + NWV * (j * WG + grp)) + prow;
     a_ok[j] = m < p.M;
     if (MODE == GM_DENSE) {
       a_off[j] = (long)m * p.lda + lchunk * 8;
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
   const T* b_ptr[NPB];
 #pragma unroll
   for (int j = 0; j < NPB; ++j) {
-    const int row = 8 * (wave + 4 * (j * WG + grp));       // first row of the piece inside the BN tile
+    const int row = 8 * (wave + NWV * (j * WG + grp));     // first row of the piece inside the BN tile
     b_ptr[j] = Wg + ((size_t)((n0 + row) >> 6) * KT) * 4096 + (size_t)(row & 63) * 64 + lane * 8;
   }
   int tap = 0, c0 = 0;
@@ -221,13 +225,13 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
       const int j = q;
       if (MODE == GM_DENSE) {
         const T* ptr = Ag + a_off[j] + k0;
-        dma16(a_ok[j] ? ptr : zero, sbase + (j * WG + grp) * 4096);
+        dma16(a_ok[j] ? ptr : zero, sbase + (j * WG + grp) * (NWV * 1024));
       } else if (MODE == GM_CONV_S1) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const long toff = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda + c0;
         const bool ok = a_ok[j] && (unsigned)(a_oy[j] + ky - 1) < (unsigned)p.Hin && (unsigned)(a_ox[j] + kx - 1) < (unsigned)p.Win;
         const T* ptr = Ag + a_off[j] + toff;
-        dma16(ok ? ptr : zero, sbase + (j * WG + grp) * 4096);
+        dma16(ok ? ptr : zero, sbase + (j * WG + grp) * (NWV * 1024));
       } else {
         const int ky = tap / 3, kx = tap - ky * 3;
         bool ok = a_ok[j];
@@ -244,11 +248,11 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
         sy = sy < 0 ? 0 : (sy >= p.Hin ? p.Hin - 1 : sy);
         sx = sx < 0 ? 0 : (sx >= p.Win ? p.Win - 1 : sx);
         const T* ptr = Ag + (a_off[j] + (long)sy * p.Win + sx) * p.lda + c0 + lchunk * 8;
-        dma16(ok ? ptr : zero, sbase + (j * WG + grp) * 4096);
+        dma16(ok ? ptr : zero, sbase + (j * WG + grp) * (NWV * 1024));
       }
     } else {
       const int j = q - NPA;
-      dma16(b_ptr[j] + (size_t)(k0 >> 6) * 4096, sbase + BM * 128 + (j * WG + grp) * 4096);
+      dma16(b_ptr[j] + (size_t)(k0 >> 6) * 4096, sbase + BM * 128 + (j * WG + grp) * (NWV * 1024));
     }
   };
   auto next_tile = [&]() {
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
   if (pre_r) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / 2) + i * 32 + ln;
+      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
         fw[buf][j] = *reinterpret_cast<const uint4*>(sb + (wn * (BN / 2) + j * 32 + ln) * 128 + pc);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fx[buf][i] = *reinterpret_cast<const uint4*>(sa + (wm * (BM / 2) + i * 32 + ln) * 128 + pc);
+        fx[buf][i] = *reinterpret_cast<const uint4*>(sa + (wm * (BM / (2 * MW)) + i * 32 + ln) * 128 + pc);
     };
     load_frags(kk0, 0);
 #pragma unroll
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
   if (p.splits == 1 && p.wide_store) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / 2) + i * 32 + ln;
+      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
       if (m >= p.M) continue;                       // both lanes of a pair share m
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(256 * WG * KG) k_gemm_dma(const GemmK p) {
 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 32 + ln;
+    const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -626,6 +630,10 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles, K split over four
   // wave groups inside the workgroup (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
   if (k.M <= 64 || (cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles && ktiles < kSplitMinK)) { BM = 64; BN = 64; }
+  // grids that fill the machine: 256x128 tiles, eight waves (see MW)
+  static const int kMwBlocks = getenv("DH_GEMM_MW") ? atoi(getenv("DH_GEMM_MW")) : 64;
+  const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && (long)cdiv(k.M, 256) * cdiv(k.N, 128) >= kMwBlocks;
+  if (mw2) { BM = 256; BN = 128; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
   if (k.partial && tiles < kSplitTiles && ktiles >= kSplitMinK) {
@@ -685,6 +693,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 3 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 1>), grid, dim3(256), 0, st, k); }
+  else if (mw2) {
+    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_DENSE, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
+    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_CONV_S1, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_GENERIC, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
+  }
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 42) DH_LAUNCH_GEMM_KG(64, 64, 2, 4);
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 24) DH_LAUNCH_GEMM_KG(64, 64, 4, 2);
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 23) DH_LAUNCH_GEMM_KG(64, 64, 3, 2);
