@@ -687,6 +687,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   static const int kKg64 = getenv("DH_GEMM_KG64") ? atoi(getenv("DH_GEMM_KG64")) : 11;     // 64x64 tile: (groups, stages) as two digits; in situ no K grouping wins (27.9 vs 27.4 steps/s for 4 groups x 2 stages)
   static const int kKg2MinKt = getenv("DH_KG2_MINKT") ? atoi(getenv("DH_KG2_MINKT")) : 16;
   static const int kManyBlocks = getenv("DH_GEMM_MANY") ? atoi(getenv("DH_GEMM_MANY")) : 512;
+  static const int kMw128 = getenv("DH_GEMM_MW128") ? atoi(getenv("DH_GEMM_MW128")) : 1;   // min K tiles for 8 waves on 128x128
   static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 0;
   const int wg = kWg ? kWg : 1;
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
@@ -697,6 +698,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
     if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_DENSE, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
     else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_CONV_S1, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
     else hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_GENERIC, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
+  }
+  else if (kMw128 && BM == 128 && BN == 128 && tiles_per_split >= kMw128) {
+    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
+    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_GENERIC, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
   }
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 42) DH_LAUNCH_GEMM_KG(64, 64, 2, 4);
   else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 24) DH_LAUNCH_GEMM_KG(64, 64, 4, 2);
