@@ -7,58 +7,95 @@
 namespace dh {
 
 // ------------------------------------------------------------- tiny-channel convolutions
-// few input channels (<= 8), many outputs: y[p][co] = b[co] + sum_{tap,ci} x[p+off][ci] w[co][tap][ci]
+// few input channels (<= 8), many outputs: y[p][co] = b[co] + sum_{tap,ci} x[p+off][ci] w[co][tap][ci].
+// A workgroup owns CF_PIX consecutive pixels so that every weight is read once per CF_PIX pixels (one pixel per
+// workgroup re-read the whole matrix per pixel: 236 MB through L2 per 64x64 image).
+constexpr int CF_PIX = 4;
 template <class T>
 __global__ void k_conv_few_in(const float* x, const float* w, const float* bias, T* y, int B, int H, int W, int Ci,
                               int Co) {
-  const int p = blockIdx.x;   // pixel over B*H*W
-  const int b = p / (H * W), r = p - b * H * W, oy = r / W, ox = r - oy * W;
-  __shared__ float patch[9 * 8];
-  if (threadIdx.x < 9 * Ci) {
-    const int tap = threadIdx.x / Ci, ci = threadIdx.x - tap * Ci;
-    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-    patch[threadIdx.x] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * H + iy) * W + ix) * Ci + ci] : 0.f;
+  __shared__ float patch[CF_PIX][9 * 8];
+  const int K = 9 * Ci, total = B * H * W;
+  const int p0 = blockIdx.x * CF_PIX;
+  for (int i = threadIdx.x; i < CF_PIX * K; i += blockDim.x) {
+    const int lp = i / K, k = i - lp * K, p = p0 + lp;
+    float v = 0.f;
+    if (p < total) {
+      const int b = p / (H * W), r = p - b * H * W, oy = r / W, ox = r - oy * W;
+      const int tap = k / Ci, ci = k - tap * Ci;
+      const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * H + iy) * W + ix) * Ci + ci];
+    }
+    patch[lp][k] = v;
   }
   __syncthreads();
-  const int K = 9 * Ci;
   for (int co = threadIdx.x; co < Co; co += blockDim.x) {
-    float acc = bias ? bias[co] : 0.f;
+    float acc[CF_PIX];
+    const float b0 = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int lp = 0; lp < CF_PIX; ++lp) acc[lp] = b0;
     const float* wr = w + (size_t)co * K;
-    for (int k = 0; k < K; ++k) acc += patch[k] * wr[k];
-    y[(size_t)p * Co + co] = from_f32<T>(acc);
+    for (int k = 0; k < K; ++k) {
+      const float wk = wr[k];
+#pragma unroll
+      for (int lp = 0; lp < CF_PIX; ++lp) acc[lp] += patch[lp][k] * wk;
+    }
+#pragma unroll
+    for (int lp = 0; lp < CF_PIX; ++lp)
+      if (p0 + lp < total) y[(size_t)(p0 + lp) * Co + co] = from_f32<T>(acc[lp]);
   }
 }
 
-// many input channels, few outputs (<= 8): one wave per pixel, lanes split K = 9*Ci
+// many input channels, few outputs (<= 8): one wave per CF_PIX consecutive pixels (each weight feeds CF_PIX pixels),
+// lanes split K = 9*Ci
 template <class T>
 __global__ void k_conv_few_out(const T* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ci,
                                int Co, int accumulate) {
   const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (p >= B * H * W) return;
-  const int b = p / (H * W), r = p - b * H * W, oy = r / W, ox = r - oy * W;
-  float acc[8];
+  const int p0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * CF_PIX;
+  const int total = B * H * W;
+  if (p0 >= total) return;
+  float acc[CF_PIX][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int lp = 0; lp < CF_PIX; ++lp)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[lp][i] = 0.f;
+  int pb[CF_PIX], py[CF_PIX], px[CF_PIX];
+#pragma unroll
+  for (int lp = 0; lp < CF_PIX; ++lp) {
+    const int p = p0 + lp < total ? p0 + lp : total - 1;
+    pb[lp] = p / (H * W);
+    const int r = p - pb[lp] * H * W;
+    py[lp] = r / W; px[lp] = r - py[lp] * W;
+  }
   for (int tap = 0; tap < 9; ++tap) {
-    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    const T* xp = x + (((size_t)b * H + iy) * W + ix) * Ci;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     for (int ci = lane; ci < Ci; ci += 64) {
-      const float xv = to_f32<T>(xp[ci]);
+      float wv[8];
 #pragma unroll
-      for (int co = 0; co < 8; ++co)
-        if (co < Co) acc[co] += xv * w[((size_t)co * 9 + tap) * Ci + ci];
+      for (int co = 0; co < 8; ++co) wv[co] = co < Co ? w[((size_t)co * 9 + tap) * Ci + ci] : 0.f;
+#pragma unroll
+      for (int lp = 0; lp < CF_PIX; ++lp) {
+        const int iy = py[lp] + dy, ix = px[lp] + dx;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const float xv = to_f32<T>(x[(((size_t)pb[lp] * H + iy) * W + ix) * Ci + ci]);
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[lp][co] += xv * wv[co];
+      }
     }
   }
 #pragma unroll
-  for (int co = 0; co < 8; ++co) {
-    if (co >= Co) break;
-    float s = wave_sum(acc[co]);
-    if (lane == 0) {
-      s += bias ? bias[co] : 0.f;
-      float* o = y + (size_t)p * Co + co;
-      *o = accumulate ? *o + s : s;
+  for (int lp = 0; lp < CF_PIX; ++lp) {
+    if (p0 + lp >= total) break;
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+      if (co >= Co) break;
+      float s = wave_sum(acc[lp][co]);
+      if (lane == 0) {
+        s += bias ? bias[co] : 0.f;
+        float* o = y + (size_t)(p0 + lp) * Co + co;
+        *o = accumulate ? *o + s : s;
+      }
     }
   }
 }
@@ -67,14 +104,14 @@ void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* 
                            int y_is_f32, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
   if (x_is_f32) {   // few-in
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_conv_few_in<f16>), dim3(B * H * W), dim3(256), 0, st, (const float*)x, w, bias, (f16*)y, B, H, W, Cin, Cout);
+      hipLaunchKernelGGL((k_conv_few_in<f16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)x, w, bias, (f16*)y, B, H, W, Cin, Cout);
     else
-      hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(B * H * W), dim3(256), 0, st, (const float*)x, w, bias, (bf16*)y, B, H, W, Cin, Cout);
+      hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)x, w, bias, (bf16*)y, B, H, W, Cin, Cout);
   } else {
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const f16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
+      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const f16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
     else
-      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const bf16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
+      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const bf16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
   }
 }
 
@@ -84,14 +121,14 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
   // Cin/Cout here are those of the GRADIENT convolution: dy has Cin channels, dx has Cout
   if (dy_is_f32) {
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_conv_few_in<f16>), dim3(B * H * W), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (f16*)dx, B, H, W, Cin, Cout);
+      hipLaunchKernelGGL((k_conv_few_in<f16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (f16*)dx, B, H, W, Cin, Cout);
     else
-      hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(B * H * W), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (bf16*)dx, B, H, W, Cin, Cout);
+      hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (bf16*)dx, B, H, W, Cin, Cout);
   } else {
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const f16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
+      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const f16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
     else
-      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4)), dim3(256), 0, st, (const bf16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
+      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const bf16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
   }
 }
 
