@@ -252,3 +252,38 @@ def test_set_foreground_laplacian_blend_vs_oracle():
     import scipy.ndimage
     m = scipy.ndimage.binary_dilation(mask[0, 0].numpy(), iterations=15)
     assert torch.equal(out.cpu()[0, 0][~torch.from_numpy(m)], depth[0, 0][~torch.from_numpy(m)])
+
+
+def test_real_scene_edits_bit_exact_vs_reference_golden(golden):
+    """A scene of the reference's own test data (estimated depth, PIZ OpenEXR; tests/golden/scene_banana_fruits) with
+    its three transforms (identity, 91 degrees + shift, pure translation): integer maps bit-exact against what the
+    reference produced (tools/make_golden_scene.py)."""
+    import os
+    from oracle import depth_ref as D
+    from diffusionhandles_amd import depth_transform as DT
+    from diffusionhandles_amd import scene_io as S
+    g = golden("g11_scene.npz")
+    sc = S.load_scene(os.path.join(os.path.dirname(__file__), "golden", "scene_banana_fruits"), 512)
+    dev = _dev()
+    names = list(sc["transforms"].keys())
+    tf = []
+    for n in names:
+        kw = S.transform_args(sc["transforms"][n])
+        tf.append((kw["rot_angle"], kw["rot_axis"], kw["translation"]))
+    out, dbg = DT.reproject_edits(sc["depth"].to(dev), sc["bg_depth"].to(dev), sc["fg_mask"].to(dev), D.intrinsics_f32(), tf,
+                                  return_debug=True)
+    for e, n in enumerate(names):
+        disp, corr = out[e]
+        assert np.array_equal(corr.numpy(), g[f"{n}_corr"].astype(np.int64)), n
+        assert np.array_equal(np.packbits(dbg["raw_mask"][e].cpu().numpy() != 0), g[f"{n}_mask"]), n
+        assert np.array_equal(np.packbits(dbg["clean_mask"][e].cpu().numpy() != 0), g[f"{n}_cleaned"]), n
+        assert np.array_equal(np.packbits(dbg["vis"][e].cpu().numpy() != 0), g[f"{n}_vis"]), n
+        assert np.array_equal(dbg["zmap"][e].cpu().numpy()[::37, ::41], g[f"{n}_zmap_slice"]), n
+        d = disp[0, 0].cpu().numpy()
+        assert np.allclose(d[::5, ::7], g[f"{n}_disp_slice"], atol=2e-3, rtol=0), n
+        assert abs(float(d.astype(np.float64).sum()) - float(g[f"{n}_disp_sum"])) < 1.0 + 1e-6 * abs(float(g[f"{n}_disp_sum"])), n
+    # and through the public entry point, one edit at a time
+    kw = S.transform_args(sc["transforms"]["edit_002"])
+    disp1, corr1 = DT.transform_depth(sc["depth"].to(dev), sc["bg_depth"].to(dev), sc["fg_mask"].to(dev), D.intrinsics_f32(),
+                                      rot_angle=kw["rot_angle"], rot_axis=kw["rot_axis"], translation=kw["translation"])
+    assert np.array_equal(corr1.numpy(), g["edit_002_corr"].astype(np.int64))

@@ -1,0 +1,182 @@
+"""Scene-directory readers (PNG / OpenEXR) and the real-scene golden vectors, CPU only.
+
+The scene under tests/golden/scene_banana_fruits is a copy of DATA files of the reference's own test set
+(test/data/photogen/banana_fruits); g11_scene.npz holds what the reference's depth_transform produced on it
+(tools/make_golden_scene.py)."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from diffusionhandles_amd import scene_io as S
+
+SCENE = os.path.join(os.path.dirname(__file__), "golden", "scene_banana_fruits")
+
+
+def _png_bytes(a, depth, ctype, filters):
+    """Encode with a chosen filter per row (test-side forward filters)."""
+    h = a.shape[0]
+    rows = a.reshape(h, -1)
+    if depth == 16:
+        rows = a.astype(">u2").view(np.uint8).reshape(h, -1)
+    bpp = max(1, {0: 1, 2: 3, 4: 2, 6: 4}[ctype] * depth // 8)
+    raw, prev = b"", np.zeros(rows.shape[1], np.int32)
+    for y in range(h):
+        cur = rows[y].astype(np.int32)
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        ft = filters[y % len(filters)]
+        if ft == 0:
+            enc = cur
+        elif ft == 1:
+            enc = cur - left
+        elif ft == 2:
+            enc = cur - prev
+        elif ft == 3:
+            enc = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - ul
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            enc = cur - pred
+        raw += bytes([ft]) + (enc & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    w = a.shape[1]
+    comp = zlib.compress(raw)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) +
+            chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("depth,ctype,shape", [(8, 0, (13, 17)), (8, 2, (13, 17, 3)), (8, 6, (9, 11, 4)), (16, 0, (7, 9)),
+                                               (16, 2, (7, 9, 3)), (8, 4, (6, 5, 2))])
+def test_png_all_filters(tmp_path, depth, ctype, shape):
+    rng = np.random.default_rng(depth + ctype)
+    a = rng.integers(0, 1 << depth, shape).astype(np.uint16 if depth == 16 else np.uint8)
+    p = tmp_path / "a.png"
+    p.write_bytes(_png_bytes(a, depth, ctype, [0, 1, 2, 3, 4]))
+    b = S.read_png(str(p))
+    assert b.dtype == a.dtype and np.array_equal(a, b)
+
+
+def test_png_write_read_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.random((20, 31, 3)).astype(np.float32)
+    S.write_png(str(tmp_path / "x.png"), img)
+    assert np.array_equal(S.read_png(str(tmp_path / "x.png")), (img * 255.0).astype(np.uint8))   # truncation, like save_image
+    g = rng.integers(0, 256, (5, 4)).astype(np.uint8)
+    S.write_png(str(tmp_path / "g.png"), g)
+    assert np.array_equal(S.read_png(str(tmp_path / "g.png")), g)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.png").write_bytes(b"not a png")
+        S.read_png(str(tmp_path / "bad.png"))
+
+
+def _exr_bytes(chans, comp, decreasing=False):
+    """chans: list of (name, array [H,W] of f16 / f32 / u32).  Scanline file, compression 0 (none), 2 (zips) or 3 (zip)."""
+    names = sorted(chans)
+    h, w = chans[names[0]].shape
+    ptype = {np.dtype("uint32"): 0, np.dtype("float16"): 1, np.dtype("float32"): 2}
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<IB3xii", ptype[chans[n].dtype], 0, 1, 1) for n in names) + b"\0"
+    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([comp])) + \
+        attr("dataWindow", "box2i", struct.pack("<4i", 0, 0, w - 1, h - 1)) + \
+        attr("displayWindow", "box2i", struct.pack("<4i", 0, 0, w - 1, h - 1)) + \
+        attr("lineOrder", "lineOrder", bytes([1 if decreasing else 0])) + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + \
+        attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = {0: 1, 2: 1, 3: 16}[comp]
+    chunks = []
+    for y in range(0, h, lines):
+        raw = b"".join(chans[n][r].astype(chans[n].dtype.newbyteorder("<")).tobytes()
+                       for r in range(y, min(y + lines, h)) for n in names)
+        data = raw
+        if comp:
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int32)
+            d = t.copy()
+            d[1:] = (t[1:] - t[:-1] + 128 + 256) & 255
+            z = zlib.compress(d.astype(np.uint8).tobytes())
+            data = z if len(z) < len(raw) else raw
+        chunks.append((y, data))
+    order = chunks[::-1] if decreasing else chunks
+    off0 = len(hdr) + 8 * len(chunks)
+    offs, body = {}, b""
+    for y, data in order:
+        offs[y] = off0 + len(body)
+        body += struct.pack("<ii", y, len(data)) + data
+    return hdr + b"".join(struct.pack("<Q", offs[y]) for y, _ in chunks) + body
+
+
+@pytest.mark.parametrize("comp", [0, 2, 3])
+def test_exr_none_and_zip(tmp_path, comp):
+    rng = np.random.default_rng(comp)
+    yy, xx = np.mgrid[0:37, 0:29]
+    ch = {"Y": (1.0 + 0.01 * yy + 0.02 * xx).astype(np.float16), "Z": rng.random((37, 29)).astype(np.float32),
+          "id": rng.integers(0, 1 << 30, (37, 29)).astype(np.uint32)}
+    p = tmp_path / "a.exr"
+    p.write_bytes(_exr_bytes(ch, comp, decreasing=(comp == 3)))
+    out = S.read_exr(str(p))
+    assert np.array_equal(out["Y"], ch["Y"].astype(np.float32))
+    assert np.array_equal(out["Z"], ch["Z"]) and np.array_equal(out["id"], ch["id"])
+    assert np.array_equal(S.read_depth_exr(str(p)), ch["Y"].astype(np.float32))
+
+
+def test_exr_piz_reference_depth_maps(golden):
+    """The reference's own depth maps: one HALF channel, PIZ, decreasing line order."""
+    g = golden("g11_scene.npz")
+    d = S.read_depth_exr(os.path.join(SCENE, "depth.exr"))
+    b = S.read_depth_exr(os.path.join(SCENE, "bg_depth.exr"))
+    assert d.shape == (512, 512) and d.dtype == np.float32 and np.isfinite(d).all() and np.isfinite(b).all()
+    assert 0.5 < d.min() and d.max() < 10.0
+    assert np.array_equal(d.astype(np.float16).astype(np.float32), d)             # HALF payload
+    # a mis-decoded wavelet / Huffman stream is noise: a metric depth map is smooth almost everywhere
+    assert np.abs(np.diff(d, axis=0)).mean() < 0.02 and np.abs(np.diff(d, axis=1)).mean() < 0.02
+    m = S.read_png(os.path.join(SCENE, "mask.png")) > 127
+    assert d[m].mean() < b[m].mean() - 0.3                                        # the object stands in front of its background
+    assert np.abs(d[~m] - b[~m]).mean() < 0.3
+    assert np.array_equal(d[::37, ::41], g["depth_slice"])
+
+
+def test_load_scene_matches_reference_loader_steps(golden):
+    g = golden("g11_scene.npz")
+    sc = S.load_scene(SCENE, 512)
+    assert sc["prompt"] == "banana fruits on the table"
+    assert list(sc["transforms"].keys()) == ["edit_000", "edit_001", "edit_002"]
+    assert sc["img"].shape == (1, 3, 512, 512) and 0.0 <= float(sc["img"].min()) and float(sc["img"].max()) <= 1.0
+    assert sc["fg_mask"].shape == (1, 1, 512, 512) and set(np.unique(sc["fg_mask"].numpy())) <= {0.0, 1.0}
+    assert np.array_equal(np.packbits(sc["fg_mask"].numpy() != 0), g["mask_bits"])
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(sc["depth"].numpy()) == str(g["depth_sha"]) and sha(sc["bg_depth"].numpy()) == str(g["bg_depth_sha"])
+    kw = S.transform_args(sc["transforms"]["edit_001"])
+    assert kw["rot_angle"] == 91.0 and torch.equal(kw["rot_axis"], torch.tensor([0.0, 1.0, 0.0]))
+    assert torch.allclose(kw["translation"], torch.tensor([0.35, 0.0, 0.0]))
+    # resize path: antialiased bilinear to another resolution, non-square crop
+    x = torch.arange(6 * 10, dtype=torch.float32).reshape(1, 1, 6, 10)
+    y = S.crop_and_resize(x, 3)
+    assert y.shape == (1, 1, 3, 3)
+    assert torch.allclose(y, torch.nn.functional.interpolate(x[..., 2:8], size=(3, 3), mode="bilinear", antialias=True))
+
+
+def test_oracle_on_the_real_scene_vs_reference_golden(golden):
+    """oracle == reference on real (estimated, noisy) depth: one of the scene's edits, full arrays."""
+    from oracle import depth_ref as D
+    g = golden("g11_scene.npz")
+    sc = S.load_scene(SCENE, 512)
+    t = sc["transforms"]["edit_001"]
+    disp, corr, dbg = D.transform_depth_pc(sc["depth"], sc["bg_depth"], sc["fg_mask"], D.intrinsics_f32(),
+                                           rot_angle=t["rotation_angle"], rot_axis=t["rotation_axis"],
+                                           translation=t["translation"], return_debug=True)
+    assert np.array_equal(corr.numpy(), g["edit_001_corr"].astype(np.int64))
+    assert np.array_equal(np.packbits(dbg["cleaned"] != 0), g["edit_001_cleaned"])
+    assert np.array_equal(dbg["zmap"][::37, ::41], g["edit_001_zmap_slice"])
+    assert np.allclose(disp[0, 0].numpy()[::5, ::7], g["edit_001_disp_slice"], atol=1e-4, rtol=0)

@@ -5,41 +5,25 @@ scene directory, writing PNGs and the .npz identity cache with the reference's k
 (null_text_emb, init_noise, activations1..3, latent_image; test_diffusion_handles.py:106-113).
 
   python tools/run_edit.py --out /tmp/edit                       # synthetic sphere-on-plane scene
-  python tools/run_edit.py --scene DIR --out /tmp/edit           # DIR: input.npy [3,H,W] in [0,1], depth.npy, bg_depth.npy,
-                                                                 #      mask.npy, prompt.txt, transforms.json
+  python tools/run_edit.py --scene DIR --out /tmp/edit           # DIR laid out like the reference's test/data/<set>/<scene>:
+                                                                 #   input.png, mask.png, depth.exr, bg_depth.exr (or .npy),
+                                                                 #   prompt.txt, transforms.json {name: {translation,
+                                                                 #   rotation_axis, rotation_angle}}
+  python tools/run_edit.py --scene tests/golden/scene_banana_fruits --out /tmp/edit   # a scene of the reference's test data
+PNG / OpenEXR are read by diffusionhandles_amd.scene_io (no imaging library offline).
 Real weights: DIFFHANDLES_UNET_SAFETENSORS / DIFFHANDLES_VAE_SAFETENSORS / DIFFHANDLES_TEXT_ENCODER_DIR /
 DIFFHANDLES_TOKENIZER_DIR (otherwise seeded random U-Net weights and the synthetic side modules).
 """
 import argparse
 import json
 import os
-import struct
 import sys
 import time
-import zlib
 
 import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-
-
-def write_png(path, img):
-    """img: [H,W] or [H,W,3] float in [0,1] (or uint8).  Minimal zlib PNG writer (no imaging library offline)."""
-    a = np.asarray(img)
-    if a.dtype != np.uint8:
-        a = (np.clip(a, 0, 1) * 255 + 0.5).astype(np.uint8)
-    if a.ndim == 2:
-        a = a[..., None]
-    h, w, c = a.shape
-    raw = b"".join(b"\x00" + a[y].tobytes() for y in range(h))
-
-    def chunk(tag, data):
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
-
-    hdr = struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2}[c], 0, 0, 0)
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", hdr) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
 def main():
@@ -53,6 +37,7 @@ def main():
     args = ap.parse_args()
     from diffusionhandles_amd import DiffusionHandles
     from diffusionhandles_amd import conf as C
+    from diffusionhandles_amd.scene_io import load_scene, transform_args, write_png
     from diffusionhandles_amd.synthetic import TRANSFORMS, make_image, make_scene
     from diffusionhandles_amd.unet import SD2_DEPTH
     os.makedirs(args.out, exist_ok=True)
@@ -60,18 +45,16 @@ def main():
     conf = C.load_default()
     conf.depth_transform_mode = args.mode
     if args.scene:
-        ld = lambda n: torch.from_numpy(np.load(os.path.join(args.scene, n))).float()
-        img, depth, bg_depth, mask = ld("input.npy")[None], ld("depth.npy")[None, None], ld("bg_depth.npy")[None, None], ld("mask.npy")[None, None]
-        prompt = open(os.path.join(args.scene, "prompt.txt")).read().strip()
-        transforms = json.load(open(os.path.join(args.scene, "transforms.json")))
-        res = depth.shape[-1]
+        sc = load_scene(args.scene, args.res)
+        img, depth, bg_depth, mask, prompt, res = sc["img"], sc["depth"], sc["bg_depth"], sc["fg_mask"], sc["prompt"], args.res
+        transforms = [dict(name=n, **transform_args(t)) for n, t in sc["transforms"].items()]
     else:
         res = args.res
         depth, bg_depth, mask = make_scene(res)
         img = make_image(res)
         prompt = "a sphere on a plane"
-        transforms = [dict(name=f"edit{i}", rotation=TRANSFORMS[i][0], axis=[0, 1, 0], translation=list(TRANSFORMS[i][1]))
-                      for i in (2, 4)]
+        transforms = [dict(name=f"edit{i}", rot_angle=float(TRANSFORMS[i][0]), rot_axis=torch.tensor([0.0, 1.0, 0.0]),
+                           translation=torch.tensor(TRANSFORMS[i][1], dtype=torch.float32)) for i in (2, 4)]
     dh = DiffusionHandles(conf, dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16,
                           unet_config=dict(SD2_DEPTH, sample_size=res // 8)).to(dev)
     depth, bg_depth, mask, img = depth.to(dev), bg_depth.to(dev), mask.to(dev), img.to(dev)
@@ -92,15 +75,14 @@ def main():
     report = dict(resolution=res, mode=args.mode, identity_s=round(t_identity, 2), edits=[])
     for tf in transforms:
         t0 = time.time()
-        out = dh.transform_foreground(depth, prompt, mask, bg_depth, null_text, noise, acts, rot_angle=float(tf["rotation"]),
-                                      rot_axis=torch.tensor(tf.get("axis", [0, 1, 0]), dtype=torch.float32),
-                                      translation=torch.tensor(tf["translation"], dtype=torch.float32))
+        out = dh.transform_foreground(depth, prompt, mask, bg_depth, null_text, noise, acts, rot_angle=tf["rot_angle"],
+                                      rot_axis=tf["rot_axis"], translation=tf["translation"])
         torch.cuda.synchronize()
         dt = time.time() - t0
         edited, disparity = out[0], out[1]
         name = tf.get("name", f"edit{len(report['edits'])}")
         write_png(os.path.join(args.out, f"{name}.png"), edited[0].permute(1, 2, 0).float().cpu().numpy())
-        write_png(os.path.join(args.out, f"{name}_disparity.png"), (disparity[0, 0] / 255.0).float().cpu().numpy())
+        write_png(os.path.join(args.out, f"{name}_disparity.png"), (disparity[0, 0] / disparity.max()).float().cpu().numpy())
         report["edits"].append(dict(name=name, seconds=round(dt, 3)))
     json.dump(report, open(os.path.join(args.out, "report.json"), "w"), indent=1)
     print(json.dumps(report))
