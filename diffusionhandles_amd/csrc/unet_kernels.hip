@@ -460,17 +460,17 @@ void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, v
 // one wave per row; C/8 sixteen-byte chunks spread over the lanes (C <= 4096)
 constexpr int LN_MAXCH = 8;
 
-template <class T>
-__global__ void __launch_bounds__(256) k_ln_fwd(const T* x, const float* gamma, const float* beta, T* y, float* stats, int rows, int C,
+template <class T, int NCH>      // NCH: 8-element chunks per lane (C <= 512 * NCH)
+__global__ void __launch_bounds__(256, NCH <= 3 ? 4 : 1) k_ln_fwd(const T* x, const float* gamma, const float* beta, T* y, float* stats, int rows, int C,
                          float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = C / 8;
-  uint4 raw[LN_MAXCH];
+  uint4 raw[NCH];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int ch = lane + 64 * k;
     if (ch < nch) {
       raw[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * C + ch * 8);
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const T* x, const float* gamma, 
   const float mean = wave_sum(s) / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int ch = lane + 64 * k;
     if (ch < nch) {
       const T* v = reinterpret_cast<const T*>(&raw[k]);
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const T* x, const float* gamma, 
   const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
   if (lane == 0 && stats) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int ch = lane + 64 * k;
     if (ch < nch) {
       const T* v = reinterpret_cast<const T*>(&raw[k]);
@@ -508,35 +508,41 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const T* x, const float* gamma, 
   }
 }
 
-template <class T>
-__global__ void __launch_bounds__(256) k_ln_bwd(const T* x, const T* dy, const float* gamma, const float* stats, const T* add, T* dx,
-                         int rows, int C) {
+// One wave per row.  x and dy of the row stay in registers as loaded (16-bit); gamma and the residual gradient are
+// fetched where they are used, so the kernel fits 128 VGPRs and four waves share a SIMD (the version that kept every
+// operand of the row live needed 272 registers: one wave per SIMD, 0.9 TB/s on the batched passes).
+template <class T, int NCH>      // NCH: 8-element chunks per lane (C <= 512 * NCH)
+__global__ void __launch_bounds__(256, NCH == 1 ? 8 : (NCH <= 3 ? 4 : 1)) k_ln_bwd(const T* x, const T* dy, const float* gamma, const float* stats,
+                                                                  const T* add, T* dx, int rows, int C) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = C / 8;
-  const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
-  uint4 rx[LN_MAXCH], rd[LN_MAXCH], ra[LN_MAXCH];
-  float s1 = 0.f, s2 = 0.f;
+  const size_t base = (size_t)row * C;
+  uint4 rx[NCH], rd[NCH];
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {       // every load of the row is issued before the first reduction
+  for (int k = 0; k < NCH; ++k) {
     const int ch = lane + 64 * k;
     if (ch < nch) {
-      rx[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * C + ch * 8);
-      rd[k] = *reinterpret_cast<const uint4*>(dy + (size_t)row * C + ch * 8);
-      ra[k] = add ? *reinterpret_cast<const uint4*>(add + (size_t)row * C + ch * 8) : make_uint4(0, 0, 0, 0);
+      rx[k] = *reinterpret_cast<const uint4*>(x + base + ch * 8);
+      rd[k] = *reinterpret_cast<const uint4*>(dy + base + ch * 8);
     }
   }
+  const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int ch = lane + 64 * k;
     if (ch < nch) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       const T* xv = reinterpret_cast<const T*>(&rx[k]);
       const T* dv = reinterpret_cast<const T*>(&rd[k]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
-        const float d = to_f32<T>(dv[i]) * gamma[ch * 8 + i];
+        const float d = to_f32<T>(dv[i]) * g[i];
         s1 += d;
         s2 += d * xh;
       }
@@ -545,39 +551,52 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const T* x, const T* dy, const f
   s1 = wave_sum(s1) / (float)C;
   s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int ch = lane + 64 * k;
     if (ch < nch) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      uint4 ra = make_uint4(0, 0, 0, 0);
+      if (add) ra = *reinterpret_cast<const uint4*>(add + base + ch * 8);
       const T* xv = reinterpret_cast<const T*>(&rx[k]);
       const T* dv = reinterpret_cast<const T*>(&rd[k]);
-      const T* av = reinterpret_cast<const T*>(&ra[k]);
+      const T* av = reinterpret_cast<const T*>(&ra);
       T o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
-        const float d = to_f32<T>(dv[i]) * gamma[ch * 8 + i];
+        const float d = to_f32<T>(dv[i]) * g[i];
         float r = rstd * (d - s1 - xh * s2);
         if (add) r += to_f32<T>(av[i]);
         o[i] = from_f32<T>(r);
       }
-      *reinterpret_cast<uint4*>(dx + (size_t)row * C + ch * 8) = *reinterpret_cast<uint4*>(o);
+      *reinterpret_cast<uint4*>(dx + base + ch * 8) = *reinterpret_cast<uint4*>(o);
     }
   }
 }
 
 void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           int rows, int C, float eps, hipStream_t st) {
-  if (dtype == DH_DTYPE_F16)
-    hipLaunchKernelGGL((k_ln_fwd<f16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const f16*)x, gamma, beta, (f16*)y, stats, rows, C, eps);
-  else
-    hipLaunchKernelGGL((k_ln_fwd<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, stats, rows, C, eps);
+#define DH_LN_FWD(TT, N) hipLaunchKernelGGL((k_ln_fwd<TT, N>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const TT*)x, gamma, beta, (TT*)y, stats, rows, C, eps)
+  const int n = C <= 512 ? 1 : (C <= 1024 ? 2 : (C <= 1536 ? 3 : LN_MAXCH));
+  if (dtype == DH_DTYPE_F16) {
+    if (n == 1) DH_LN_FWD(f16, 1); else if (n == 2) DH_LN_FWD(f16, 2); else if (n == 3) DH_LN_FWD(f16, 3); else DH_LN_FWD(f16, LN_MAXCH);
+  } else {
+    if (n == 1) DH_LN_FWD(bf16, 1); else if (n == 2) DH_LN_FWD(bf16, 2); else if (n == 3) DH_LN_FWD(bf16, 3); else DH_LN_FWD(bf16, LN_MAXCH);
+  }
+#undef DH_LN_FWD
 }
 void launch_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
                           const void* add, void* dx, int rows, int C, hipStream_t st) {
-  if (dtype == DH_DTYPE_F16)
-    hipLaunchKernelGGL((k_ln_bwd<f16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, stats, (const f16*)add, (f16*)dx, rows, C);
-  else
-    hipLaunchKernelGGL((k_ln_bwd<bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, stats, (const bf16*)add, (bf16*)dx, rows, C);
+#define DH_LN_BWD(TT, N) hipLaunchKernelGGL((k_ln_bwd<TT, N>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const TT*)x, (const TT*)dy, gamma, stats, (const TT*)add, (TT*)dx, rows, C)
+  const int n = C <= 512 ? 1 : (C <= 1024 ? 2 : (C <= 1536 ? 3 : LN_MAXCH));
+  if (dtype == DH_DTYPE_F16) {
+    if (n == 1) DH_LN_BWD(f16, 1); else if (n == 2) DH_LN_BWD(f16, 2); else if (n == 3) DH_LN_BWD(f16, 3); else DH_LN_BWD(f16, LN_MAXCH);
+  } else {
+    if (n == 1) DH_LN_BWD(bf16, 1); else if (n == 2) DH_LN_BWD(bf16, 2); else if (n == 3) DH_LN_BWD(bf16, 3); else DH_LN_BWD(bf16, LN_MAXCH);
+  }
+#undef DH_LN_BWD
 }
 
 // --------------------------------------------------------------------------------- GEGLU

@@ -6,14 +6,15 @@ import torch
 from diffusionhandles_amd.unet import HipUNet
 
 dt = torch.float16
-u = HipUNet(dtype=dt, max_batch=2)
+BATCHES = tuple(int(b) for b in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 2)
+u = HipUNet(dtype=dt, max_batch=max(BATCHES))
 u.init_synthetic(0)
 print("weights GB", u.weight_bytes() / 1e9, "workspace GB", u.workspace_bytes() / 1e9)
 dev = u.device
 g = torch.Generator(device=dev).manual_seed(0)
 side = torch.cuda.Stream()
 torch.cuda.set_stream(side)
-for B in (1, 2):
+for B in BATCHES:
     x = torch.randn(B, 64, 64, 5, generator=g, device=dev)
     txt = torch.randn(B, 77, 1024, generator=g, device=dev)
     da = [None, torch.randn((B,) + u.act_shapes[1], generator=g, device=dev).to(dt) * 1e-2,
