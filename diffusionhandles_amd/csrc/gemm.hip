@@ -74,7 +74,8 @@ __device__ __forceinline__ uint2 epilogue_pack(const GemmK& p, int m, int n, flo
                                                bool have_r, uint2 rpre, bool have_b, float4 bpre) {
   float v[4] = {v0, v1, v2, v3};
   if (p.bias) {
-    const float4 b = have_b ? bpre : *reinterpret_cast<const float4*>(p.bias + n);
+    float4 b = bpre;        // (not `have_b ? bpre : *ptr`: a conditional of two lvalues selects an ADDRESS, which puts bpre on the stack)
+    if (!have_b) b = *reinterpret_cast<const float4*>(p.bias + n);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   }
   if (p.rowvec) {
@@ -85,17 +86,19 @@ __device__ __forceinline__ uint2 epilogue_pack(const GemmK& p, int m, int n, flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
   }
+  typedef T T4 __attribute__((ext_vector_type(4)));      // register-only views: an address-taken local costs a scratch slot
   if (p.R) {
     const T* r = reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n;
-    uint2 raw = have_r ? rpre : *reinterpret_cast<const uint2*>(r);
-    const T* rv = reinterpret_cast<const T*>(&raw);
+    uint2 raw = rpre;
+    if (!have_r) raw = *reinterpret_cast<const uint2*>(r);
+    const T4 rv = __builtin_bit_cast(T4, raw);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += to_f32<T>(rv[i]);
   }
-  T o[4];
+  T4 o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(v[i]);
-  return *reinterpret_cast<uint2*>(o);
+  return __builtin_bit_cast(uint2, o);
 }
 template <class T>
 __device__ __forceinline__ void epilogue_store(const GemmK& p, int m, int n, float v0, float v1, float v2, float v3,
