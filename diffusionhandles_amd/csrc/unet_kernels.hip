@@ -266,17 +266,23 @@ __device__ __forceinline__ void gn_combine(const float* part, int b, int G, int 
   __syncthreads();
 }
 
-// thread = 8 consecutive channels of one pixel; grid (chunks of HW*C/8, B)
-template <class T>
+// thread = 8 consecutive channels of one pixel, `iters` such chunks per thread (blockDim apart); grid (blocks, B).
+// Every workgroup first merges the slice statistics of its image (a dependent chain of small loads): on big tensors
+// `iters` > 1 spreads that prologue over more elements (one chunk per thread left the batched passes at 2.4 TB/s).
+template <class T, bool WIDE>      // WIDE: >= 8 channels per group
 __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma, const float* beta, const float* part,
-                                                  float* stats, T* y, int HW, int C, int G, int S, float eps, int silu) {
+                                                  float* stats, T* y, int HW, int C, int G, int S, float eps, int silu,
+                                                  int iters) {
   __shared__ float2 sm_stats[64];
   const int b = blockIdx.y;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cchunks = C / 8;
-  const bool live = idx < (size_t)HW * cchunks;
-  const size_t row = (size_t)b * HW + (live ? idx / cchunks : 0);
-  const int c0 = (int)(idx % cchunks) * 8, cpg = C / G;
+  const int cchunks = C / 8, cpg = C / G;
+  const float inv_cpg = 1.f / (float)cpg;
+  const unsigned total = (unsigned)HW * cchunks;                      // 32-bit element indices (a 64-bit division per chunk is ~100 instructions)
+  unsigned idx = blockIdx.x * iters * blockDim.x + threadIdx.x;
+  bool live = idx < total;
+  unsigned pix = live ? idx / cchunks : 0;
+  size_t row = (size_t)b * HW + pix;
+  int c0 = (int)(idx - pix * cchunks) * 8;
   uint4 raw = *reinterpret_cast<const uint4*>(x + row * C + c0);      // in flight under the slice combine
   float gmv[8], btv[8];                                               // so are the affine parameters of the 8 channels
   *reinterpret_cast<float4*>(gmv) = *reinterpret_cast<const float4*>(gamma + c0);
@@ -284,45 +290,84 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
   *reinterpret_cast<float4*>(btv) = *reinterpret_cast<const float4*>(beta + c0);
   *reinterpret_cast<float4*>(btv + 4) = *reinterpret_cast<const float4*>(beta + c0 + 4);
   gn_combine(part, b, G, S, eps, sm_stats, blockIdx.x == 0 ? stats : nullptr);
-  if (!live) return;
-  const T* xv = reinterpret_cast<const T*>(&raw);
-  T o[8];
+  for (int it = 0; it < iters; ++it) {
+    if (!live) return;                                                // chunks are ascending: nothing live follows
+    uint4 nraw = raw;
+    float ngm[8], nbt[8];
+    const unsigned nidx = idx + blockDim.x;
+    const bool nlive = it + 1 < iters && nidx < total;
+    size_t nrow = row;
+    int nc0 = c0;
+    if (nlive) {                                                      // next chunk's loads fly under this chunk's math
+      const unsigned npix = nidx / cchunks;
+      nrow = (size_t)b * HW + npix;
+      nc0 = (int)(nidx - npix * cchunks) * 8;
+      nraw = *reinterpret_cast<const uint4*>(x + nrow * C + nc0);
+      *reinterpret_cast<float4*>(ngm) = *reinterpret_cast<const float4*>(gamma + nc0);
+      *reinterpret_cast<float4*>(ngm + 4) = *reinterpret_cast<const float4*>(gamma + nc0 + 4);
+      *reinterpret_cast<float4*>(nbt) = *reinterpret_cast<const float4*>(beta + nc0);
+      *reinterpret_cast<float4*>(nbt + 4) = *reinterpret_cast<const float4*>(beta + nc0 + 4);
+    }
+    typedef T T8 __attribute__((ext_vector_type(8)));
+    const T8 xv = __builtin_bit_cast(T8, raw);
+    T8 o;
+    // the 8 channels lie in at most two groups (cpg >= 8): one reciprocal multiply instead of eight integer divisions
+    // (the divisions made this kernel VALU-bound: 2.4 TB/s on big tensors)
+    const int g0 = (int)(((float)c0 + 0.5f) * inv_cpg), bnd = (g0 + 1) * cpg - c0;
+    const float2 st0 = sm_stats[g0], st1 = sm_stats[g0 + 1 < G ? g0 + 1 : g0];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i;
-    const float2 st = sm_stats[c / cpg];
-    float z = (to_f32<T>(xv[i]) - st.x) * st.y * gmv[i] + btv[i];
-    if (silu) z = silu_f(z);
-    o[i] = from_f32<T>(z);
+    for (int i = 0; i < 8; ++i) {
+      const float2 st = WIDE ? (i < bnd ? st0 : st1) : sm_stats[(c0 + i) / cpg];
+      float z = (to_f32<T>(xv[i]) - st.x) * st.y * gmv[i] + btv[i];
+      if (silu) z = silu_f(z);
+      o[i] = from_f32<T>(z);
+    }
+    *reinterpret_cast<uint4*>(y + row * C + c0) = __builtin_bit_cast(uint4, o);
+    if (!nlive) return;
+    idx = nidx; row = nrow; c0 = nc0; raw = nraw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gmv[i] = ngm[i]; btv[i] = nbt[i]; }
   }
-  *reinterpret_cast<uint4*>(y + row * C + c0) = *reinterpret_cast<uint4*>(o);
+}
+
+// chunks per thread of the two apply kernels: keep >= ~1024 workgroups in flight
+static inline int gn_apply_iters(size_t blocks_total) {
+  size_t it = blocks_total / 1024;
+  return it < 1 ? 1 : (it > 8 ? 8 : (int)it);
 }
 
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                           int have_partials) {
   const int S = gn_slices(HW);
-  dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
+  const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
+  const int iters = gn_apply_iters(blocks0 * B);
+  dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);
   if (dtype == DH_DTYPE_F16) {
     if (!have_partials) hipLaunchKernelGGL((k_gn_partial<f16, false>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
-    hipLaunchKernelGGL((k_gn_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu);
+    if (C / G >= 8) hipLaunchKernelGGL((k_gn_apply<f16, true>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu, iters);
+    else hipLaunchKernelGGL((k_gn_apply<f16, false>), g2, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu, iters);
   } else {
     if (!have_partials) hipLaunchKernelGGL((k_gn_partial<bf16, false>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, (const float*)nullptr, scratch, HW, C, G, S, silu);
-    hipLaunchKernelGGL((k_gn_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu);
+    if (C / G >= 8) hipLaunchKernelGGL((k_gn_apply<bf16, true>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu, iters);
+    else hipLaunchKernelGGL((k_gn_apply<bf16, false>), g2, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu, iters);
   }
 }
 
-template <class T>
+template <class T, bool WIDE>
 __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, const float* gamma, const float* beta,
                                                       const float* stats, const float* part, T* dx, int HW, int C, int G,
-                                                      int S, int silu, int accumulate) {
+                                                      int S, int silu, int accumulate, int iters) {
   __shared__ float4 sm_st[64];     // mean, rstd, mean(dxhat), mean(dxhat*xhat)
   const int b = blockIdx.y, cpg = C / G;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float inv_cpg = 1.f / (float)cpg;
   const int cchunks = C / 8;
-  const bool live = idx < (size_t)HW * cchunks;
-  const size_t row = (size_t)b * HW + (live ? idx / cchunks : 0);
-  const int c0 = (int)(idx % cchunks) * 8;
+  const unsigned total = (unsigned)HW * cchunks;                      // 32-bit element indices (a 64-bit division per chunk is ~100 instructions)
+  unsigned idx = blockIdx.x * iters * blockDim.x + threadIdx.x;
+  bool live = idx < total;
+  unsigned pix = live ? idx / cchunks : 0;
+  size_t row = (size_t)b * HW + pix;
+  int c0 = (int)(idx - pix * cchunks) * 8;
   uint4 rx = *reinterpret_cast<const uint4*>(x + row * C + c0);       // in flight under the slice combine
   uint4 rd = *reinterpret_cast<const uint4*>(dy + row * C + c0);
   uint4 ro = make_uint4(0, 0, 0, 0);
@@ -340,37 +385,65 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
     sm_st[g] = make_float4(stats[2 * (b * G + g)], stats[2 * (b * G + g) + 1], a * inv, c * inv);
   }
   __syncthreads();
-  if (!live) return;
-  const T* xv = reinterpret_cast<const T*>(&rx);
-  const T* dv = reinterpret_cast<const T*>(&rd);
-  const T* ov = reinterpret_cast<const T*>(&ro);
-  T o[8];
+  typedef T T8 __attribute__((ext_vector_type(8)));
+  for (int it = 0; it < iters; ++it) {
+    if (!live) return;
+    const unsigned nidx = idx + blockDim.x;
+    const bool nlive = it + 1 < iters && nidx < total;
+    size_t nrow = row;
+    int nc0 = c0;
+    uint4 nrx = rx, nrd = rd, nro = ro;
+    float ngm[8], nbt[8];
+    if (nlive) {                                                      // next chunk's loads fly under this chunk's math
+      const unsigned npix = nidx / cchunks;
+      nrow = (size_t)b * HW + npix;
+      nc0 = (int)(nidx - npix * cchunks) * 8;
+      nrx = *reinterpret_cast<const uint4*>(x + nrow * C + nc0);
+      nrd = *reinterpret_cast<const uint4*>(dy + nrow * C + nc0);
+      if (accumulate) nro = *reinterpret_cast<const uint4*>(dx + nrow * C + nc0);
+      *reinterpret_cast<float4*>(ngm) = *reinterpret_cast<const float4*>(gamma + nc0);
+      *reinterpret_cast<float4*>(ngm + 4) = *reinterpret_cast<const float4*>(gamma + nc0 + 4);
+      *reinterpret_cast<float4*>(nbt) = *reinterpret_cast<const float4*>(beta + nc0);
+      *reinterpret_cast<float4*>(nbt + 4) = *reinterpret_cast<const float4*>(beta + nc0 + 4);
+    }
+    const T8 xv = __builtin_bit_cast(T8, rx), dv = __builtin_bit_cast(T8, rd), ov = __builtin_bit_cast(T8, ro);
+    T8 o;
+    const int g0 = (int)(((float)c0 + 0.5f) * inv_cpg), bnd = (g0 + 1) * cpg - c0;     // see k_gn_apply
+    const float4 st0 = sm_st[g0], st1 = sm_st[g0 + 1 < G ? g0 + 1 : g0];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i;
-    const float4 st = sm_st[c / cpg];
-    const float xh = (to_f32<T>(xv[i]) - st.x) * st.y;
-    float d = to_f32<T>(dv[i]);
-    if (silu) d *= silu_grad(xh * gmv[i] + btv[i]);
-    d *= gmv[i];
-    float r = st.y * (d - st.z - xh * st.w);
-    if (accumulate) r += to_f32<T>(ov[i]);
-    o[i] = from_f32<T>(r);
+    for (int i = 0; i < 8; ++i) {
+      const float4 st = WIDE ? (i < bnd ? st0 : st1) : sm_st[(c0 + i) / cpg];
+      const float xh = (to_f32<T>(xv[i]) - st.x) * st.y;
+      float d = to_f32<T>(dv[i]);
+      if (silu) d *= silu_grad(xh * gmv[i] + btv[i]);
+      d *= gmv[i];
+      float r = st.y * (d - st.z - xh * st.w);
+      if (accumulate) r += to_f32<T>(ov[i]);
+      o[i] = from_f32<T>(r);
+    }
+    *reinterpret_cast<uint4*>(dx + row * C + c0) = __builtin_bit_cast(uint4, o);
+    if (!nlive) return;
+    idx = nidx; row = nrow; c0 = nc0; rx = nrx; rd = nrd; ro = nro;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gmv[i] = ngm[i]; btv[i] = nbt[i]; }
   }
-  *reinterpret_cast<uint4*>(dx + row * C + c0) = *reinterpret_cast<uint4*>(o);
 }
 
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st, int have_partials) {
   const int S = gn_slices(HW);
-  dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)(((size_t)HW * (C / 8) + 255) / 256), B);
+  const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
+  const int iters = gn_apply_iters(blocks0 * B);
+  dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);
   if (dtype == DH_DTYPE_F16) {
     if (!have_partials) hipLaunchKernelGGL((k_gn_partial<f16, true>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
-    hipLaunchKernelGGL((k_gn_bwd_apply<f16>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate);
+    if (C / G >= 8) hipLaunchKernelGGL((k_gn_bwd_apply<f16, true>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate, iters);
+    else hipLaunchKernelGGL((k_gn_bwd_apply<f16, false>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate, iters);
   } else {
     if (!have_partials) hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
-    hipLaunchKernelGGL((k_gn_bwd_apply<bf16>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate);
+    if (C / G >= 8) hipLaunchKernelGGL((k_gn_bwd_apply<bf16, true>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate, iters);
+    else hipLaunchKernelGGL((k_gn_bwd_apply<bf16, false>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate, iters);
   }
 }
 
