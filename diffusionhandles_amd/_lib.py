@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffhandles_hip.so")
+# DIFFHANDLES_LIB: another build of the same library (A/B timing of two builds on one box); never a different backend
+LIB_PATH = os.environ.get("DIFFHANDLES_LIB") or os.path.join(_HERE, "libdiffhandles_hip.so")
 _LIB = None
 
 c_p = ctypes.c_void_p

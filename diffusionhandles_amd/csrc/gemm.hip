@@ -452,7 +452,7 @@ __global__ void k_splitk_reduce(const GemmK p) {
   const size_t total = (size_t)p.M * p.N / 4;
   if (q >= total) return;
   const size_t e = q * 4;
-  const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
+  const int m = (int)((unsigned)e / (unsigned)p.N), n = (int)((unsigned)e - (unsigned)m * (unsigned)p.N);     // M * N < 2^32
   // every load of the element group is issued before the first add: bias / residual first, slabs four at a time
   const bool have_r = p.R != nullptr, have_b = p.bias != nullptr;
   const uint2 rpre = have_r ? *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n) : make_uint2(0, 0);

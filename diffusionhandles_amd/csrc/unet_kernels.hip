@@ -165,10 +165,11 @@ __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, con
   }
   if (rr < RP) {
     int gi[8];
+    const int gfirst = (int)(((float)(ch * 8) + 0.5f) * (1.f / (float)cpg)), gbnd = (gfirst + 1) * cpg - ch * 8;
     float a[8], q[8], pv[8], gm[8], bt[8], mu[8], rs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {          // a chunk may straddle groups: per-element group index
-      gi[i] = (ch * 8 + i) / cpg;
+      gi[i] = cpg >= 8 ? gfirst + (i >= gbnd) : (ch * 8 + i) / cpg;      // a chunk spans at most two groups when cpg >= 8
       a[i] = 0.f; q[i] = 0.f; pv[i] = 0.f;
 #pragma unroll
       for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
@@ -475,10 +476,11 @@ __global__ void __launch_bounds__(256) k_concat_gn(const T* a, int Ca, const T* 
   if (rr < RP && g0 * cpg + ch * 8 < C) {
     const int n = g0 * cpg + ch * 8;
     int gi[8];
+    const int gfirst = (int)(((float)(ch * 8) + 0.5f) * (1.f / (float)cpg)), gbnd = (gfirst + 1) * cpg - ch * 8;
     float av[8], qv[8], pv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      gi[i] = (ch * 8 + i) / cpg;
+      gi[i] = cpg >= 8 ? gfirst + (i >= gbnd) : (ch * 8 + i) / cpg;      // a chunk spans at most two groups when cpg >= 8
       av[i] = 0.f; qv[i] = 0.f; pv[i] = 0.f;
 #pragma unroll
       for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
@@ -683,8 +685,9 @@ __global__ void k_geglu_fwd(const T* x, T* y, size_t rows, int F) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int fch = F / 8;
   if (idx >= rows * fch) return;
-  const size_t row = idx / fch;
-  const int j0 = (int)(idx - row * fch) * 8;
+  const unsigned row32 = (unsigned)idx / (unsigned)fch;          // the grid (a 32-bit count of 256-thread blocks) bounds idx below 2^40; tensors here are < 2^32 elements: 32-bit division
+  const size_t row = row32;
+  const int j0 = (int)((unsigned)idx - row32 * (unsigned)fch) * 8;
   uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + j0);
   uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + F + j0);
   const T* h = reinterpret_cast<const T*>(&rh);
@@ -700,8 +703,9 @@ __global__ void k_geglu_bwd(const T* x, const T* dy, T* dx, size_t rows, int F) 
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int fch = F / 8;
   if (idx >= rows * fch) return;
-  const size_t row = idx / fch;
-  const int j0 = (int)(idx - row * fch) * 8;
+  const unsigned row32 = (unsigned)idx / (unsigned)fch;          // the grid (a 32-bit count of 256-thread blocks) bounds idx below 2^40; tensors here are < 2^32 elements: 32-bit division
+  const size_t row = row32;
+  const int j0 = (int)((unsigned)idx - row32 * (unsigned)fch) * 8;
   uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + j0);
   uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + F + j0);
   uint4 rd = *reinterpret_cast<const uint4*>(dy + row * F + j0);
@@ -736,8 +740,9 @@ __global__ void k_copy_cols(const T* src, long lds_, T* dst, long ldd, size_t ro
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cch = cols / 8;
   if (idx >= rows * cch) return;
-  const size_t row = idx / cch;
-  const int c0 = (int)(idx - row * cch) * 8;
+  const unsigned row32 = (unsigned)idx / (unsigned)cch;
+  const size_t row = row32;
+  const int c0 = (int)((unsigned)idx - row32 * (unsigned)cch) * 8;
   uint4 v = *reinterpret_cast<const uint4*>(src + row * lds_ + c0);
   if (accumulate) {
     uint4 o = *reinterpret_cast<const uint4*>(dst + row * ldd + c0);
@@ -764,8 +769,9 @@ __global__ void k_split_cols(const T* src, long lds_, T* dstA, long ldA, int col
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cch = (colsA + colsB) / 8;
   if (idx >= rows * cch) return;
-  const size_t row = idx / cch;
-  const int c0 = (int)(idx - row * cch) * 8;
+  const unsigned row32 = (unsigned)idx / (unsigned)cch;
+  const size_t row = row32;
+  const int c0 = (int)((unsigned)idx - row32 * (unsigned)cch) * 8;
   uint4 v = *reinterpret_cast<const uint4*>(src + row * lds_ + c0);
   const bool left = c0 < colsA;
   T* dst = left ? dstA + row * ldA + c0 : dstB + row * ldB + (c0 - colsA);
@@ -794,10 +800,10 @@ __global__ void k_pool2x2(const T* src, T* dst, int B, int h, int w, int C, int 
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cch = C / 8;
   if (idx >= (size_t)B * h * w * cch) return;
-  const size_t pix = idx / cch;
-  const int c0 = (int)(idx - pix * cch) * 8;
-  const int b = (int)(pix / ((size_t)h * w));
-  const int r = (int)(pix - (size_t)b * h * w), y = r / w, x = r - y * w;
+  const unsigned pix = (unsigned)idx / (unsigned)cch;
+  const int c0 = (int)((unsigned)idx - pix * (unsigned)cch) * 8;
+  const int b = (int)(pix / (unsigned)(h * w));
+  const int r = (int)(pix - (unsigned)b * (unsigned)(h * w)), y = r / w, x = r - y * w;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
