@@ -60,6 +60,12 @@ struct Arena {
 typedef _Float16 f16;
 typedef __bf16 bf16;
 
+// m / d for 0 <= m < 2^22 and a quotient below a few hundred, from a float reciprocal of d (1 ulp): the product
+// (m + 0.5) * inv is at least 0.5 / d away from an integer, far more than its rounding error, so truncation is exact.
+// An integer division is ~30 dependent instructions and sits in front of the first load of every conv tile.
+__device__ __forceinline__ int div_small(int m, float inv) { return (int)(((float)m + 0.5f) * inv); }
+__device__ __forceinline__ float rcp_fast(int d) { return __builtin_amdgcn_rcpf((float)d); }
+
 template <class T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<f16>(f16 x) { return (float)x; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 x) { return (float)x; }

@@ -68,10 +68,6 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
 
 constexpr int BK = 64;
 
-// m / d for 0 <= m < 2^22 and a quotient below a few hundred, from a float reciprocal of d (1 ulp): the product
-// (m + 0.5) * inv is at least 0.5 / d away from an integer, far more than its rounding error, so truncation is exact.
-// An integer division is ~30 dependent instructions and sits in front of the first load of every conv tile.
-__device__ __forceinline__ int div_small(int m, float inv) { return (int)(((float)m + 0.5f) * inv); }
 
 // bias / per-image vector / SiLU / residual of four consecutive outputs of row m, rounded to the storage type
 template <class T>
@@ -486,20 +482,18 @@ __global__ void k_splitk_reduce(const GemmK p) {
 // row, applies the epilogue, stores the 16-bit result and accumulates the pivot-shifted sums of the ROUNDED values.
 template <class T, bool BWD>
 __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
-  __shared__ float sm_piv[GN_GB];
   __shared__ float sm_red[4][2 * GN_GB];
   const int HW = p.gn_HW, G = p.gn_G, S = p.gn_S;
-  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = p.N / G;
-  const int W = GN_GB * cpg, nch = W / 8;
-  const int RP = (int)blockDim.x / nch;
-  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
+  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = div_small(p.N, rcp_fast(G));
+  const int W = GN_GB * cpg, nch = W >> 3;
+  const float inv_nch = rcp_fast(nch), inv_S = rcp_fast(S), inv_cpg = rcp_fast(cpg);
+  const int RP = div_small((int)blockDim.x, inv_nch);
+  const int r0 = div_small(HW * s, inv_S), r1 = div_small(HW * (s + 1), inv_S);
   const size_t slab = (size_t)p.M * p.N;
   // sums are NOT pivot-shifted here (a pivot would cost a dependent pass over the slabs before the main one): conv /
   // linear outputs are zero-centred to within a few standard deviations, where E[x^2] - E[x]^2 over the <= 10^4
   // elements of a slice is accurate to ~1e-6 relative in f32; slices are merged with Chan's formula in the apply kernel
-  if ((int)threadIdx.x < GN_GB) sm_piv[threadIdx.x] = 0.f;
-  __syncthreads();
-  const int rr = threadIdx.x / nch, ch = threadIdx.x - rr * nch;
+  const int rr = div_small((int)threadIdx.x, inv_nch), ch = threadIdx.x - rr * nch;
   float ga[GN_GB], gq[GN_GB];
 #pragma unroll
   for (int gl = 0; gl < GN_GB; ++gl) { ga[gl] = 0.f; gq[gl] = 0.f; }
@@ -509,10 +503,8 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
     float av[8], qv[8], pv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      gi[i] = (ch * 8 + i) / cpg;
+      gi[i] = div_small(ch * 8 + i, inv_cpg);
       av[i] = 0.f; qv[i] = 0.f; pv[i] = 0.f;
-#pragma unroll
-      for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? sm_piv[gl] : pv[i];
     }
     float bias8[8];
 #pragma unroll
@@ -620,7 +612,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
     } else {
       const float cnt = (float)(r1 - r0) * (float)cpg;
       float* o = p.gn_part + ((size_t)(b * G + g) * 3) * S + s;
-      o[0] = cnt; o[S] = sm_piv[gl] + sa / cnt; o[2 * S] = sq - sa * sa / cnt;
+      o[0] = cnt; o[S] = sa / cnt; o[2 * S] = sq - sa * sa / cnt;
     }
   }
 }

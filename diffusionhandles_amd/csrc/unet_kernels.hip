@@ -151,12 +151,15 @@ template <class T, bool BWD>
 __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, const float* gamma, const float* beta,
                                                     const float* stats, float* part, int HW, int C, int G, int S, int silu) {
   __shared__ float sm_red[4][2 * GN_GB];
-  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = C / G;
-  const int W = GN_GB * cpg, nch = W / 8;
-  const int RP = (int)blockDim.x / nch;
-  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
+  // index arithmetic by float reciprocals (div_small): the integer divisions of this prologue were ~500 instructions
+  // in front of the first load
+  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = div_small(C, rcp_fast(G));
+  const int W = GN_GB * cpg, nch = W >> 3;
+  const float inv_nch = rcp_fast(nch), inv_S = rcp_fast(S);
+  const int RP = div_small((int)blockDim.x, inv_nch);
+  const int r0 = div_small(HW * s, inv_S), r1 = div_small(HW * (s + 1), inv_S);
   const size_t base = (size_t)b * HW * C + (size_t)g0 * cpg;
-  const int rr = threadIdx.x / nch, ch = threadIdx.x - rr * nch;
+  const int rr = div_small((int)threadIdx.x, inv_nch), ch = threadIdx.x - rr * nch;
   float ga[GN_GB], gq[GN_GB], pg[GN_GB];
 #pragma unroll
   for (int gl = 0; gl < GN_GB; ++gl) {
@@ -165,11 +168,11 @@ __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, con
   }
   if (rr < RP) {
     int gi[8];
-    const int gfirst = (int)(((float)(ch * 8) + 0.5f) * (1.f / (float)cpg)), gbnd = (gfirst + 1) * cpg - ch * 8;
+    const float inv_cpg = rcp_fast(cpg);
     float a[8], q[8], pv[8], gm[8], bt[8], mu[8], rs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {          // a chunk may straddle groups: per-element group index
-      gi[i] = cpg >= 8 ? gfirst + (i >= gbnd) : (ch * 8 + i) / cpg;      // a chunk spans at most two groups when cpg >= 8
+      gi[i] = div_small(ch * 8 + i, inv_cpg);
       a[i] = 0.f; q[i] = 0.f; pv[i] = 0.f;
 #pragma unroll
       for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
@@ -455,11 +458,12 @@ __global__ void __launch_bounds__(256) k_concat_gn(const T* a, int Ca, const T* 
                                                    int S) {
   __shared__ float sm_red[4][2 * GN_GB];
   const int C = Ca + Cb;
-  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = C / G;
-  const int W = GN_GB * cpg, nch = W / 8;
-  const int RP = (int)blockDim.x / nch;
-  const int r0 = (int)((long)HW * s / S), r1 = (int)((long)HW * (s + 1) / S);
-  const int rr = threadIdx.x / nch, ch = threadIdx.x - rr * nch;
+  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = div_small(C, rcp_fast(G));
+  const int W = GN_GB * cpg, nch = W >> 3;
+  const float inv_nch = rcp_fast(nch), inv_S = rcp_fast(S);
+  const int RP = div_small((int)blockDim.x, inv_nch);
+  const int r0 = div_small(HW * s, inv_S), r1 = div_small(HW * (s + 1), inv_S);
+  const int rr = div_small((int)threadIdx.x, inv_nch), ch = threadIdx.x - rr * nch;
   auto load8 = [&](size_t m, int n) {          // n: channel of the result, multiple of 8; a chunk never straddles a | b
     return n < Ca ? *reinterpret_cast<const uint4*>(a + m * Ca + n) : *reinterpret_cast<const uint4*>(bsrc + m * Cb + (n - Ca));
   };
@@ -476,11 +480,11 @@ __global__ void __launch_bounds__(256) k_concat_gn(const T* a, int Ca, const T* 
   if (rr < RP && g0 * cpg + ch * 8 < C) {
     const int n = g0 * cpg + ch * 8;
     int gi[8];
-    const int gfirst = (int)(((float)(ch * 8) + 0.5f) * (1.f / (float)cpg)), gbnd = (gfirst + 1) * cpg - ch * 8;
+    const float inv_cpg = rcp_fast(cpg);
     float av[8], qv[8], pv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      gi[i] = cpg >= 8 ? gfirst + (i >= gbnd) : (ch * 8 + i) / cpg;      // a chunk spans at most two groups when cpg >= 8
+      gi[i] = div_small(ch * 8 + i, inv_cpg);
       av[i] = 0.f; qv[i] = 0.f; pv[i] = 0.f;
 #pragma unroll
       for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
