@@ -506,9 +506,11 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
       gi[i] = div_small(ch * 8 + i, inv_cpg);
       av[i] = 0.f; qv[i] = 0.f; pv[i] = 0.f;
     }
-    float bias8[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bias8[i] = p.bias ? p.bias[n + i] : 0.f;
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      *reinterpret_cast<float4*>(bias8) = *reinterpret_cast<const float4*>(p.bias + n);
+      *reinterpret_cast<float4*>(bias8 + 4) = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    }
     float gm[8], bt[8], mu[8], rs[8];
     if (BWD) {           // output = dy of a GroupNorm: accumulate sum d and sum d * xhat (d = dy * gamma * act')
       *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(p.gnb_gamma + n);
@@ -723,7 +725,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   if (splits > 1) {
     if (k.gn_part && k.gn_G > 0 && k.gn_HW > 0 && k.N % k.gn_G == 0 && (GN_GB * (k.N / k.gn_G)) % 8 == 0 &&
         GN_GB * (k.N / k.gn_G) <= 2048 && k.M % k.gn_HW == 0) {
-      k.gn_S = gn_slices(k.gn_HW);
+      k.gn_S = gn_slices(k.gn_HW, k.M / k.gn_HW);
       if (k.gnb_x) hipLaunchKernelGGL((k_splitk_reduce_gn<T, true>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
       else hipLaunchKernelGGL((k_splitk_reduce_gn<T, false>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
       if (gn_done) *gn_done = 1;

@@ -58,7 +58,7 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                           int have_partials = 0);
-int gn_slices(int HW);          // number of row slices of the GroupNorm statistics for HW rows per image
+int gn_slices(int HW, int B);   // number of row slices of the GroupNorm statistics for HW rows per image, B images
 constexpr int GN_GB = 4;        // groups per statistics workgroup
 // out[m][0..Ca) = a[m], out[m][Ca..Ca+Cb) = b[m], plus the GroupNorm slice statistics of out (G groups)
 void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, void* out, float* gn_part, int B, int HW,

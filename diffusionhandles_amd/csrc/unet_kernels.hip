@@ -144,8 +144,13 @@ __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z))
 //   the apply kernel combines the S <= 16 slices (8 lanes per group, butterfly, Chan's formula) before
 //   normalising; block x == 0 also publishes (mean, rstd) for backward.
 // partial layout: [b][g][3][S]  (n | mean | M2 planes)
-static int gn_slice_cap() { static const int v = getenv("DH_GN_SLICES") ? atoi(getenv("DH_GN_SLICES")) : 16; return v; }
-int gn_slices(int HW) { const int cap = gn_slice_cap(); int s = HW / 4; return s < 1 ? 1 : (s > cap ? cap : s); }
+// slices per image: 32 for one or two images (the statistics kernels then launch 256 workgroups, one per CU), 16 for
+// bigger batches, where the batch dimension already fills the chip and the apply kernels' combine costs more
+static int gn_slice_cap(int B) {
+  static const int v = getenv("DH_GN_SLICES") ? atoi(getenv("DH_GN_SLICES")) : 0;
+  return v > 0 ? v : (B <= 2 ? 32 : 16);
+}
+int gn_slices(int HW, int B) { const int cap = gn_slice_cap(B); int s = HW / 4; return s < 1 ? 1 : (s > cap ? cap : s); }
 
 template <class T, bool BWD>
 __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, const float* gamma, const float* beta,
@@ -343,7 +348,7 @@ static inline int gn_apply_iters(size_t blocks_total) {
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                           int have_partials) {
-  const int S = gn_slices(HW);
+  const int S = gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);
@@ -436,7 +441,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st, int have_partials) {
-  const int S = gn_slices(HW);
+  const int S = gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);
@@ -527,7 +532,7 @@ __global__ void __launch_bounds__(256) k_concat_gn(const T* a, int Ca, const T* 
 
 void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, void* out, float* gn_part, int B, int HW,
                       int G, hipStream_t st) {
-  const int S = gn_slices(HW);
+  const int S = gn_slices(HW, B);
   dim3 grid(S, cdiv(G, GN_GB), B);
   if (dtype == DH_DTYPE_F16)
     hipLaunchKernelGGL((k_concat_gn<f16>), grid, dim3(256), 0, st, (const f16*)a, Ca, (const f16*)b, Cb, (f16*)out, gn_part, HW, G, S);
