@@ -148,7 +148,7 @@ __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z))
 // bigger batches, where the batch dimension already fills the chip and the apply kernels' combine costs more
 static int gn_slice_cap(int B) {
   static const int v = getenv("DH_GN_SLICES") ? atoi(getenv("DH_GN_SLICES")) : 0;
-  return v > 0 ? v : (B <= 2 ? 32 : 16);
+  return v > 0 ? (v > 64 ? 64 : v) : (B <= 2 ? 32 : 16);      // <= 64: gn_combine holds 8 slices per lane
 }
 int gn_slices(int HW, int B) { const int cap = gn_slice_cap(B); int s = HW / 4; return s < 1 ? 1 : (s > cap ? cap : s); }
 
@@ -252,19 +252,33 @@ __global__ void __launch_bounds__(256) k_gn_partial(const T* x, const T* dy, con
   }
 }
 
-// combine the S slices of every group of batch item b into sm_stats[g] = (mean, rstd)
+// combine the S slices of every group of batch item b into sm_stats[g] = (mean, rstd).  Every (n, mean, M2) triple of
+// the lane is loaded before the first use: one memory round trip instead of two dependent ones (the partials were
+// written by the previous kernel on other XCDs, so each trip goes to memory)
+constexpr int GN_COMBINE_K = 8;      // slices per lane: S <= 64
 __device__ __forceinline__ void gn_combine(const float* part, int b, int G, int S, float eps, float2* sm_stats,
                                            float* stats_out) {
   const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
   const bool act = g < G;
   const float* p = part + ((size_t)(b * G + (act ? g : 0)) * 3) * S;
+  float cn[GN_COMBINE_K], cm[GN_COMBINE_K], cq[GN_COMBINE_K];
+#pragma unroll
+  for (int k = 0; k < GN_COMBINE_K; ++k) {
+    const int s = sub + 8 * k;
+    const bool on = act && s < S;
+    cn[k] = on ? p[s] : 0.f;
+    cm[k] = on ? p[S + s] : 0.f;
+    cq[k] = on ? p[2 * S + s] : 0.f;
+  }
   float n = 0.f, sm = 0.f;
-  if (act) for (int s = sub; s < S; s += 8) { n += p[s]; sm += p[s] * p[S + s]; }
+#pragma unroll
+  for (int k = 0; k < GN_COMBINE_K; ++k) { n += cn[k]; sm += cn[k] * cm[k]; }
 #pragma unroll
   for (int o = 4; o > 0; o >>= 1) { n += __shfl_xor(n, o, 64); sm += __shfl_xor(sm, o, 64); }
   const float mean = sm / n;
   float m2 = 0.f;
-  if (act) for (int s = sub; s < S; s += 8) { const float d = p[S + s] - mean; m2 += p[2 * S + s] + p[s] * d * d; }
+#pragma unroll
+  for (int k = 0; k < GN_COMBINE_K; ++k) { const float d = cm[k] - mean; m2 += cq[k] + cn[k] * d * d; }
 #pragma unroll
   for (int o = 4; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
   if (act && sub == 0) {
@@ -386,12 +400,24 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
   *reinterpret_cast<float4*>(gmv + 4) = *reinterpret_cast<const float4*>(gamma + c0 + 4);
   *reinterpret_cast<float4*>(btv) = *reinterpret_cast<const float4*>(beta + c0);
   *reinterpret_cast<float4*>(btv + 4) = *reinterpret_cast<const float4*>(beta + c0 + 4);
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    const float* p = part + ((size_t)(b * G + g) * S) * 2;
+  {   // slice sums of (sum d, sum d * xhat): 8 lanes per group, every pair loaded before the first add (G <= 32, S <= 64)
+    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const bool act = g < G;
+    const float2* p = reinterpret_cast<const float2*>(part) + (size_t)(b * G + (act ? g : 0)) * S;
+    float2 v[GN_COMBINE_K];
+#pragma unroll
+    for (int k = 0; k < GN_COMBINE_K; ++k) {
+      const int s = sub + 8 * k;
+      v[k] = act && s < S ? p[s] : make_float2(0.f, 0.f);
+    }
+    float2 st = act ? *reinterpret_cast<const float2*>(stats + 2 * (b * G + g)) : make_float2(0.f, 0.f);
     float a = 0.f, c = 0.f;
-    for (int s = 0; s < S; ++s) { a += p[2 * s]; c += p[2 * s + 1]; }
+#pragma unroll
+    for (int k = 0; k < GN_COMBINE_K; ++k) { a += v[k].x; c += v[k].y; }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
     const float inv = 1.f / ((float)HW * (float)cpg);
-    sm_st[g] = make_float4(stats[2 * (b * G + g)], stats[2 * (b * G + g) + 1], a * inv, c * inv);
+    if (act && sub == 0) sm_st[g] = make_float4(st.x, st.y, a * inv, c * inv);
   }
   __syncthreads();
   typedef T T8 __attribute__((ext_vector_type(8)));
