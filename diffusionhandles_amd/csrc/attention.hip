@@ -203,6 +203,9 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
     s[1] = tile_times_frags<T>(sK, 32, ln, hi, qf);
     if (k0 + 64 > Nk) {            // ragged last tile: mask the keys past Nk
+      // (the empty asm keeps this a real branch: flattened into selects it cost 32 compares + 32 selects + the key
+      // index arithmetic in EVERY tile of a loop that is bound by its softmax VALU work)
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -367,10 +370,15 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
     for (int t2 = 0; t2 < 2; ++t2) {
       v16f s = tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
       const v16f dp = tile_times_frags<T>(sV, t2 * 32, ln, hi, dof);
+      if (ragged) {                // keys past Nk (a real branch, see k_attn_fwd): their probabilities are zero
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + t2 * 32 + acc_row(r, hi) >= Nk) s[r] = -INFINITY;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(__builtin_fmaf(s[r], CEXP, -lse_q));
-        if (ragged && k0 + t2 * 32 + acc_row(r, hi) >= Nk) p = 0.f;
+        const float p = fast_exp2(__builtin_fmaf(s[r], CEXP, -lse_q));
         s[r] = p * (dp[r] - del_q) * SCALE;
       }
 #pragma unroll
