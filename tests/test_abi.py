@@ -89,3 +89,33 @@ def test_ddim_scheduler_scalars_match_oracle():
         assert at == float(b.alpha(t)) and ap == float(b.alpha(t - 20))
         af, an = a.inversion_alphas(t)
         assert af == float(b.alpha(min(t - 20, 999))) and an == float(b.alphas_cumprod[t])
+
+
+def test_kernel_registers_and_scratch_audit():
+    """Code-object metadata of the built library (tools/check_isa.py; no GPU): the regressions an ISA pass found in
+    round 1 stay out -- kernels that silently use scratch (address-taken locals, spills), memory-bound elementwise
+    kernels with so many registers that one wave fills a SIMD, workgroups that cannot launch."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    lib = os.path.join(ROOT, "diffusionhandles_amd", "libdiffhandles_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(check_isa.LLVM, "llvm-readelf")):
+        pytest.skip("library or llvm-readelf not present")
+    ks = check_isa.kernels(lib)
+    assert len(ks) > 200
+    for k in ks:
+        waves = (k["max_threads"] + 63) // 64
+        # registers: a workgroup must fit one CU (512 unified registers per lane and SIMD, waves spread over 4 SIMDs)
+        assert k["vgpr"] <= 512 // ((waves + 3) // 4), k
+        assert k["lds"] <= 160 * 1024, k
+        # scratch: only the known 8-byte spill of the 16-wave attention forward
+        assert k["scratch"] <= (8 if "k_attn_fwd" in k["name"] else 0), k
+    by = lambda frag: [k for k in ks if frag in k["name"]]
+    # streaming kernels of the U-Net keep >= 4 waves per SIMD (<= 128 registers) for the row lengths SD-2 has
+    for frag in ("k_ln_fwdIDF16_Li1E", "k_ln_fwdIDF16_Li2E", "k_ln_fwdIDF16_Li3E", "k_ln_bwdIDF16_Li1E", "k_ln_bwdIDF16_Li2E",
+                 "k_ln_bwdIDF16_Li3E", "k_gn_apply", "k_gn_bwd_apply", "k_geglu_fwd", "k_geglu_bwd", "k_splitk_reduceI",
+                 "k_gn_partial", "k_concat_gn", "k_copy_cols", "k_split_cols"):
+        sel = by(frag)
+        assert sel, frag
+        for k in sel:
+            assert k["vgpr"] <= 128, k
