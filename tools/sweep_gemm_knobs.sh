@@ -1,15 +1,14 @@
 #!/bin/bash
-# A/B of the GEMM dispatch knobs on one box (run through gpurun): per-pass U-Net time at batch 1 for each setting
+# A/B of dispatch knobs on one box (run through gpurun), judged on the guided step of bench.py (policy changes that win
+# on the repeated full pass of tools/time_unet.py have lost here)
 cd ${GRAFT_REPO_ROOT:-$PWD}
-run() { echo "== $*"; env "$@" timeout 120 python tools/time_unet.py ${BATCHES:-1} 2>&1 | grep "B="; }
+run() { echo "== $*: $(env "$@" timeout 200 python bench.py --no-time-edit --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"; }
 run X=0
-run DH_SPLITK_TARGET=128
-run DH_SPLITK_TARGET=160
-run DH_SPLITK_TARGET=192
-run DH_SPLITK_TARGET=224
-run DH_SPLITK_TARGET=192 DH_BIG_TILES=96
-run DH_SPLITK_TARGET=192 DH_SPLITK_MINKT=32
-run DH_SPLITK_TARGET=192 DH_BIG_TILES=96 DH_SPLITK_MINKT=32
-run DH_SPLITK_TARGET=160 DH_BIG_TILES=96
+run DH_BIG_TILES=128 DH_SPLITK_MINKT=32
+run DH_BIG_TILES=128 DH_SPLITK_MINKT=40
+run DH_BIG_TILES=128 DH_SPLITK_MINKT=48
+run DH_BIG_TILES=200 DH_SPLITK_MINKT=32
+run DH_BIG_TILES=200 DH_SPLITK_MINKT=40
+run DH_BIG_TILES=256 DH_SPLITK_MINKT=32
 run X=0
-run DH_SPLITK_TARGET=192
+run DH_BIG_TILES=128 DH_SPLITK_MINKT=32
