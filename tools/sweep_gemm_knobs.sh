@@ -4,11 +4,13 @@
 cd ${GRAFT_REPO_ROOT:-$PWD}
 run() { echo "== $*: $(env "$@" timeout 200 python bench.py --no-time-edit --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"; }
 run X=0
-run DH_BIG_TILES=128 DH_SPLITK_MINKT=32
-run DH_BIG_TILES=128 DH_SPLITK_MINKT=40
-run DH_BIG_TILES=128 DH_SPLITK_MINKT=48
-run DH_BIG_TILES=200 DH_SPLITK_MINKT=32
-run DH_BIG_TILES=200 DH_SPLITK_MINKT=40
-run DH_BIG_TILES=256 DH_SPLITK_MINKT=32
+run DH_SPLITK_TARGET=288
+run DH_SPLITK_TILES=160
+run DH_SPLITK_TILES=256
+run DH_GEMM_MW=48
+run DH_GEMM_MW=96
+run DH_GEMM_MANY=256
+run DH_GEMM_MANY=1024
+run DH_KG2_MINKT=24
+run DH_GEMM_MW128=0
 run X=0
-run DH_BIG_TILES=128 DH_SPLITK_MINKT=32
