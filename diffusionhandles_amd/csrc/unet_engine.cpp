@@ -457,6 +457,9 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
   DH_REQUIRE(cfg->n_levels == 4, "n_levels must be 4");
   DH_REQUIRE(cfg->dtype == DH_DTYPE_F16 || cfg->dtype == DH_DTYPE_BF16, "dtype must be f16 or bf16");
   DH_REQUIRE(cfg->max_batch >= 1 && cfg->sample_size % 8 == 0 && cfg->sample_size >= 8, "bad batch / sample size");
+  // the kernels index rows with float-reciprocal divisions that are exact below 2^21 rows (common.h div_small)
+  DH_REQUIRE((long)cfg->max_batch * cfg->sample_size * cfg->sample_size < (1L << 21), "max_batch * sample_size^2 must stay below 2^21 rows");
+  DH_REQUIRE(cfg->norm_groups >= 1 && cfg->norm_groups <= 32, "1..32 GroupNorm groups");
   DH_REQUIRE(cfg->in_channels <= 8 && cfg->out_channels <= 8, "in/out channels must be <= 8");
   DH_REQUIRE(cfg->cross_attention_dim % 64 == 0, "cross_attention_dim must be a multiple of 64");
   for (int i = 0; i < 4; ++i) {
