@@ -16,5 +16,6 @@ S=$(ls /tmp/prof_bench/*/*kernel_stats.csv | head -1)
 cp $S $O/rocprofv3_kernel_stats.csv
 python tools/step_types.py $T 3 > $O/step_kernel_types.txt
 python tools/step_breakdown.py $T 3 > $O/step_breakdown_by_grid.txt
+python tools/step_gaps.py $T > $O/step_gaps.txt
 head -3 $O/bench_n1.json | cut -c1-400
 head -12 $O/step_kernel_types.txt
