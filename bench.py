@@ -42,13 +42,17 @@ def parse():
 
 
 def cpu_baseline():
-    """The oracle (torch fp32 CPU restatement of the same U-Net, kind 'port') timed on this host's
-    cores on a bounded sample: ONE U-Net forward (B=1, 0.804 of the step's 6.99 algorithmic TFLOP) at
-    the full SD-2-depth size, second run (warm); scaled to steps/s by the FLOP ratio."""
+    """The oracle (torch fp32 CPU restatement of the same U-Net, kind 'port') timed on this host's cores on a bounded
+    sample of the step (about 10-20 s of CPU work): one cold forward, one warm forward (B=1) and one warm
+    forward + backward-to-input (B=1, gradient of the two guided activations), at the full SD-2-depth size.  A guided
+    step is 3 x (forward + backward, B=1) + one CFG forward at B=2, timed as two B=1 forwards; the energy and the
+    elementwise updates are left out (they favour the CPU figure)."""
     from oracle import unet_torch as U
     threads = min(os.cpu_count() or 1, 32)      # more threads than this oversubscribes torch's CPU kernels
     torch.set_num_threads(threads)
     unet = U.UNetTorch(U.SD2_DEPTH).eval()      # default torch init: values do not matter for timing
+    for p_ in unet.parameters():
+        p_.requires_grad_(False)
     g = torch.Generator().manual_seed(1)
     cond = torch.randn(1, 77, 1024, generator=g)
     x = torch.randn(1, 5, 64, 64, generator=g)
@@ -59,10 +63,20 @@ def cpu_baseline():
             unet(x, torch.tensor(940), encoder_hidden_states=cond, return_dict=False)
             times.append(time.time() - t0)
     t_fwd = times[-1]
-    step_s = t_fwd * STEP_TFLOP / 0.804
+    t_fb, note = None, ""
+    try:
+        xg = x.clone().requires_grad_(True)
+        t0 = time.time()
+        out = unet(xg, torch.tensor(940), encoder_hidden_states=cond, return_dict=False)
+        (out[5].float().sum() + out[6].float().sum()).backward()
+        t_fb = time.time() - t0
+    except Exception as exc:              # noqa: BLE001 - e.g. host memory: fall back to the FLOP-scaled forward
+        note = f"; forward+backward not timed ({type(exc).__name__}), step scaled from the forward by 6.99/0.804 TFLOP"
+    step_s = 3.0 * t_fb + 2.0 * t_fwd if t_fb is not None else t_fwd * STEP_TFLOP / 0.804
+    fb = f", forward+backward-to-input B=1 = {t_fb:.2f}s" if t_fb is not None else ""
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"oracle torch-CPU fp32 full SD2-depth U-Net, one forward B=1 (0.804 TFLOP) = {t_fwd:.2f}s warm "
-                      f"({times[0]:.2f}s cold); step time scaled by 6.99/0.804 = {step_s:.1f}s"}
+            "sample": f"oracle torch-CPU fp32 full SD2-depth U-Net: forward B=1 = {t_fwd:.2f}s warm ({times[0]:.2f}s cold){fb}; "
+                      f"step = 3 x (fwd+bwd) + CFG forward at B=2 (2 x fwd) = {step_s:.1f}s{note}"}
 
 
 def main():
