@@ -180,3 +180,54 @@ def test_oracle_on_the_real_scene_vs_reference_golden(golden):
     assert np.array_equal(np.packbits(dbg["cleaned"] != 0), g["edit_001_cleaned"])
     assert np.array_equal(dbg["zmap"][::37, ::41], g["edit_001_zmap_slice"])
     assert np.allclose(disp[0, 0].numpy()[::5, ::7], g["edit_001_disp_slice"], atol=1e-4, rtol=0)
+
+
+def test_png_low_bit_depths_and_palette(tmp_path):
+    """1/2/4-bit gray rows are packed MSB first and scaled to 0..255; palette images come back as RGB."""
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    rng = np.random.default_rng(7)
+    for depth in (1, 2, 4):
+        w, h = 13, 5
+        a = rng.integers(0, 1 << depth, (h, w)).astype(np.uint8)
+        per = 8 // depth
+        stride = (w * depth + 7) // 8
+        rows = b""
+        for y in range(h):
+            padded = np.zeros(stride * per, np.uint8)
+            padded[:w] = a[y]
+            packed = np.zeros(stride, np.uint8)
+            for k in range(per):
+                packed |= (padded[k::per] << ((per - 1 - k) * depth)).astype(np.uint8)
+            rows += b"\x00" + packed.tobytes()
+        p = tmp_path / f"g{depth}.png"
+        p.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 0, 0, 0, 0)) +
+                      chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b""))
+        assert np.array_equal(S.read_png(str(p)), a * (255 // ((1 << depth) - 1)))
+    # 8-bit palette
+    pal = rng.integers(0, 256, (7, 3)).astype(np.uint8)
+    idx = rng.integers(0, 7, (6, 9)).astype(np.uint8)
+    rows = b"".join(b"\x00" + idx[y].tobytes() for y in range(6))
+    p = tmp_path / "pal.png"
+    p.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 9, 6, 8, 3, 0, 0, 0)) + chunk(b"PLTE", pal.tobytes()) +
+                  chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b""))
+    assert np.array_equal(S.read_png(str(p)), pal[idx])
+    # interlaced files are refused, not mis-read
+    p = tmp_path / "il.png"
+    p.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 8, 0, 0, 0, 1)) +
+                  chunk(b"IDAT", zlib.compress(b"\x00\x00\x00" * 2)) + chunk(b"IEND", b""))
+    with pytest.raises(ValueError):
+        S.read_png(str(p))
+
+
+def test_exr_rejects_what_it_cannot_read(tmp_path):
+    ch = {"Y": np.ones((4, 4), np.float16)}
+    raw = bytearray(_exr_bytes(ch, 0))
+    bad = bytes(raw).replace(b"compression\0compression\0\x01\x00\x00\x00\x00", b"compression\0compression\0\x01\x00\x00\x00\x05")   # PXR24
+    (tmp_path / "pxr.exr").write_bytes(bad)
+    with pytest.raises(ValueError):
+        S.read_exr(str(tmp_path / "pxr.exr"))
+    (tmp_path / "junk.exr").write_bytes(b"\0" * 64)
+    with pytest.raises(ValueError):
+        S.read_exr(str(tmp_path / "junk.exr"))
