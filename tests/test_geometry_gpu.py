@@ -287,3 +287,18 @@ def test_real_scene_edits_bit_exact_vs_reference_golden(golden):
     disp1, corr1 = DT.transform_depth(sc["depth"].to(dev), sc["bg_depth"].to(dev), sc["fg_mask"].to(dev), D.intrinsics_f32(),
                                       rot_angle=kw["rot_angle"], rot_axis=kw["rot_axis"], translation=kw["translation"])
     assert np.array_equal(corr1.numpy(), g["edit_002_corr"].astype(np.int64))
+
+
+def test_set_foreground_on_the_real_scene_vs_oracle():
+    """The reference's scene at full size: two independently estimated depth maps (image / in-painted background) blended
+    around the object; GPU CG vs the oracle's sparse direct solve."""
+    import os
+    from oracle import depth_ref as D
+    from diffusionhandles_amd import depth_transform as DT
+    from diffusionhandles_amd import scene_io as S
+    sc = S.load_scene(os.path.join(os.path.dirname(__file__), "golden", "scene_banana_fruits"), 512)
+    out = DT.laplacian_depth_blend(sc["depth"].to(_dev()), sc["bg_depth"].to(_dev()), sc["fg_mask"].to(_dev()))
+    ref = D.set_foreground(sc["depth"], sc["fg_mask"], sc["bg_depth"])
+    assert out.shape == (1, 1, 512, 512)
+    assert float((out.cpu() - ref).abs().max()) < 1e-4
+    assert float((out.cpu() - sc["bg_depth"]).abs().max()) > 1e-3          # the blend did change the background depth
