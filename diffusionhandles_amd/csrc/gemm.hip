@@ -285,8 +285,9 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   // the residual tile is fetched now and added in the epilogue: its cold load flies under the K loop instead of
   // sitting at the tail of the kernel (these loads are younger than the prologue DMAs and older than every later one,
   // so the counted vmcnt waits below can only become stricter)
-  const bool pre_r = p.R != nullptr && p.pre_r && p.splits == 1 && (WG == 1 || grp == 0) && (KG == 1 || kg == 0);
-  const bool pre_b = p.bias != nullptr && p.pre_r && p.splits == 1;
+  constexpr bool PRE = TM * TN <= 8;               // the prefetched tiles cost 8 registers per 32x32 output tile
+  const bool pre_r = PRE && p.R != nullptr && p.pre_r && p.splits == 1 && (WG == 1 || grp == 0) && (KG == 1 || kg == 0);
+  const bool pre_b = PRE && p.bias != nullptr && p.pre_r && p.splits == 1;
   float4 bpre[TN][4];
   if (pre_b) {
 #pragma unroll
@@ -634,6 +635,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles, K split over four
   // wave groups inside the workgroup (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
   if (k.M <= 64 || (cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles && ktiles < kSplitMinK)) { BM = 64; BN = 64; }
+  // N = 320 (the 64x64-latent convolutions and linears) with enough rows to fill the chip: one 128x320 tile per 128 rows,
+  // so the A tile is staged once instead of five times (batched edits; a single image has only 32 such tiles)
+  static const int kN320 = getenv("DH_GEMM_N320") ? atoi(getenv("DH_GEMM_N320")) : 128;     // >= 128 row tiles (batch 8: U-Net pass -4.5 %); slower below
+  const bool n320 = kN320 > 0 && k.N == 320 && BM == 128 && BN == 64 && cdiv(k.M, 128) >= kN320;
+  if (n320) BN = 320;
   // grids that fill the machine: 256x128 tiles, eight waves (see MW)
   static const int kMwBlocks = getenv("DH_GEMM_MW") ? atoi(getenv("DH_GEMM_MW")) : 64;
   const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && (long)cdiv(k.M, 256) * cdiv(k.N, 128) >= kMwBlocks;
@@ -714,7 +720,8 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (kKg != 1 && BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) DH_LAUNCH_GEMM_KG(128, 64, 3, 2);
   else if (kKg == 2 && BM == 128 && BN == 128) DH_LAUNCH_GEMM_KG(128, 128, 2, 2);
   else
-  if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
+  if (BN == 320) DH_LAUNCH_GEMM_WG(128, 320, 2, 1);
+  else if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
   else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) DH_LAUNCH_GEMM(128, 128, 2);   // 64 KiB: two workgroups per CU
   else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
   else DH_LAUNCH_GEMM(128, 64, 5);
