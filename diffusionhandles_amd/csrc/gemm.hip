@@ -637,7 +637,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   if (k.M <= 64 || (cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles && ktiles < kSplitMinK)) { BM = 64; BN = 64; }
   // N = 320 (the 64x64-latent convolutions and linears) with enough rows to fill the chip: one 128x320 tile per 128 rows,
   // so the A tile is staged once instead of five times (batched edits; a single image has only 32 such tiles)
-  static const int kN320 = getenv("DH_GEMM_N320") ? atoi(getenv("DH_GEMM_N320")) : 128;     // >= 128 row tiles (batch 8: U-Net pass -4.5 %); slower below
+  static const int kN320 = getenv("DH_GEMM_N320") ? atoi(getenv("DH_GEMM_N320")) : 224;     // row tiles that fill the CUs (256 at batch 8: U-Net pass -4.5 %); 144 tiles (768^2, B = 2) lose 1 %
   const bool n320 = kN320 > 0 && k.N == 320 && BM == 128 && BN == 64 && cdiv(k.M, 128) >= kN320;
   if (n320) BN = 320;
   // grids that fill the machine: 256x128 tiles, eight waves (see MW)
