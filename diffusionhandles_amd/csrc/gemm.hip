@@ -630,7 +630,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
   const int ktiles = k.K / BK;
   // tuning knob: long-K GEMMs whose 128x128 tiling has at most this many tiles use the 128x64 tile (two wave groups)
-  static const int kNarrowTiles = getenv("DH_NARROW_TILES") ? atoi(getenv("DH_NARROW_TILES")) : 0;
+  static const int kNarrowTiles = getenv("DH_NARROW_TILES") ? atoi(getenv("DH_NARROW_TILES")) : 40;     // 0 -> 40 and
   if (BN == 128 && ktiles >= 16 && cdiv(k.M, 128) * cdiv(k.N, 128) <= kNarrowTiles) BN = 64;
   // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles, K split over four
   // wave groups inside the workgroup (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
@@ -695,7 +695,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   } while (0)
   static const int kKg = getenv("DH_GEMM_KG") ? atoi(getenv("DH_GEMM_KG")) : 0;
   static const int kKg64 = getenv("DH_GEMM_KG64") ? atoi(getenv("DH_GEMM_KG64")) : 11;     // 64x64 tile: (groups, stages) as two digits; in situ no K grouping wins (27.9 vs 27.4 steps/s for 4 groups x 2 stages)
-  static const int kKg2MinKt = getenv("DH_KG2_MINKT") ? atoi(getenv("DH_KG2_MINKT")) : 16;
+  static const int kKg2MinKt = getenv("DH_KG2_MINKT") ? atoi(getenv("DH_KG2_MINKT")) : 4;       // 16 -> 4 on the final kernels: +1.4 % on the guided step (bench.py A/B), batch-8 and 768^2 unchanged
   static const int kManyBlocks = getenv("DH_GEMM_MANY") ? atoi(getenv("DH_GEMM_MANY")) : 512;
   static const int kMw128 = getenv("DH_GEMM_MW128") ? atoi(getenv("DH_GEMM_MW128")) : 1;   // min K tiles for 8 waves on 128x128
   static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 0;

@@ -4,13 +4,10 @@
 cd ${GRAFT_REPO_ROOT:-$PWD}
 run() { echo "== $*: $(env "$@" timeout 200 python bench.py --no-time-edit --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"; }
 run X=0
-run DH_SPLITK_TARGET=288
-run DH_SPLITK_TILES=160
-run DH_SPLITK_TILES=256
-run DH_GEMM_MW=48
-run DH_GEMM_MW=96
-run DH_GEMM_MANY=256
-run DH_GEMM_MANY=1024
-run DH_KG2_MINKT=24
-run DH_GEMM_MW128=0
+run DH_NARROW_TILES=40 DH_KG2_MINKT=8
+run DH_NARROW_TILES=40 DH_KG2_MINKT=4
+run DH_NARROW_TILES=64 DH_KG2_MINKT=8
+run DH_NARROW_TILES=48 DH_KG2_MINKT=6
+run DH_NARROW_TILES=0 DH_KG2_MINKT=8
+run DH_NARROW_TILES=40 DH_KG2_MINKT=12
 run X=0
