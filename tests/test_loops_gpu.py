@@ -156,3 +156,28 @@ def test_guided_inference_is_bit_deterministic(rig):
         rig.gd.guided_inference(rig.noise.to(dev()), disp_e, unc, rig.prompt, rig.acts, corr)
         outs.append(rig.gd.last_latents.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_scene_harness_end_to_end_on_the_reference_scene(tmp_path):
+    """tools/run_edit.py on the scene directory of the reference's test data (PNG + PIZ OpenEXR inputs), full-size
+    U-Net with seeded random weights: the counterpart of the reference's test_diffusion_handles.py writes its
+    outputs, and the disparity it writes is the re-projection the golden vectors pin."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from diffusionhandles_amd import scene_io as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "edit")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_edit.py"), "--scene",
+                        os.path.join(root, "tests", "golden", "scene_banana_fruits"), "--out", out, "--skip-inversion",
+                        "--no-identity-cache", "--max-edits", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [e["name"] for e in rep["edits"]] == ["edit_000", "edit_001"] and rep["resolution"] == 512
+    for f in ("recon.png", "edit_000.png", "edit_000_disparity.png", "edit_001.png", "edit_001_disparity.png", "report.json"):
+        assert os.path.exists(os.path.join(out, f)), f
+    img = S.read_png(os.path.join(out, "edit_001.png"))
+    disp = S.read_png(os.path.join(out, "edit_001_disparity.png"))
+    assert img.shape == (512, 512, 3) and disp.shape == (512, 512) and disp.max() == 255 and disp.min() < 64
+    assert not os.path.exists(os.path.join(out, "identity.npz"))

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--mode", default="pc", choices=["pc", "mesh"])
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--skip-inversion", action="store_true", help="generate the image from noise instead of inverting an input")
+    ap.add_argument("--no-identity-cache", action="store_true", help="do not write identity.npz (1 GB at 512x512)")
+    ap.add_argument("--max-edits", type=int, default=0, help="run only the first N transforms")
     args = ap.parse_args()
     from diffusionhandles_amd import DiffusionHandles
     from diffusionhandles_amd import conf as C
@@ -66,10 +68,13 @@ def main():
     null_text, noise, acts, latent = dh.generate_input_image(depth, prompt, null_text, noise)
     torch.cuda.synchronize()
     t_identity = time.time() - t0
-    np.savez(os.path.join(args.out, "identity.npz"), null_text_emb=null_text.float().cpu().numpy(),
-             init_noise=noise.float().cpu().numpy(), activations1=acts[0].float().cpu().numpy(),
-             activations2=acts[1].float().cpu().numpy(), activations3=acts[2].float().cpu().numpy(),
-             latent_image=latent.float().cpu().numpy())
+    if args.max_edits > 0:
+        transforms = transforms[:args.max_edits]
+    if not args.no_identity_cache:
+        np.savez(os.path.join(args.out, "identity.npz"), null_text_emb=null_text.float().cpu().numpy(),
+                 init_noise=noise.float().cpu().numpy(), activations1=acts[0].float().cpu().numpy(),
+                 activations2=acts[1].float().cpu().numpy(), activations3=acts[2].float().cpu().numpy(),
+                 latent_image=latent.float().cpu().numpy())
     recon = dh.diffuser.decode_latent_image(latent)
     write_png(os.path.join(args.out, "recon.png"), recon[0].permute(1, 2, 0).float().cpu().numpy())
     report = dict(resolution=res, mode=args.mode, identity_s=round(t_identity, 2), edits=[])
