@@ -109,6 +109,20 @@ def test_engine_sd2_depth_full_size_bf16_batch2():
     run_case(U.SD2_DEPTH, torch.bfloat16, 2, 261.0, 3e-2, 5e-2, check_text=False)   # measured 1.1e-2 / 1.5e-2
 
 
+def test_engine_sd2_depth_latent96_fp16():
+    """768x768 images: 96x96 latents, so 9216 / 2304 / 576 / 144 rows per image (not powers of two) through the
+    reciprocal index arithmetic, the GroupNorm slices and the split-K policy."""
+    from oracle import unet_torch as U
+    run_case(dict(U.SD2_DEPTH, sample_size=96), torch.float16, 1, 740.0, 2e-2, 6e-2, check_text=False)
+
+
+def test_engine_sd2_depth_batch8_fp16():
+    """Eight images per pass (the batched-edits mode): 256 row tiles per 64x64 layer, i.e. the 128x320 GEMM tile and the
+    16-slice GroupNorm statistics, against the torch restatement."""
+    from oracle import unet_torch as U
+    run_case(U.SD2_DEPTH, torch.float16, 8, 120.0, 2e-2, 6e-2, check_text=False)
+
+
 def test_engine_truncated_forward_matches_full():
     """want_eps=False stops the tape after the last requested activation: that activation and the
     gradient from it must be bit-identical to the full pass (same kernels, same order)."""
