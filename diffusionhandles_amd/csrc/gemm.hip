@@ -60,6 +60,14 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   int act_silu;
   int pre_r;        // fetch the residual tile before the K loop
   int wide_store;   // 16-byte epilogue stores (N % 32 == 0, C and ldc 16-byte aligned)
+#ifdef DH_TUNING
+  int w_nt;         // non-temporal weight DMA (measured: no gain at <= 2 row tiles, a loss beyond; tuning builds only)
+  int lnf_abl;      // timing-only ablation of the folded LayerNorm: 1 = no sums in the K loop, 2 = no exchange, 4 = no epilogue transform
+#endif
+  // LayerNorm folded into this GEMM (LNF instantiations): A is the LayerNorm INPUT x, W holds W * gamma, and
+  // out = rstd * (x W'^T - mean * ln_s) + ln_t with ln_s[n] = sum_k W'[n][k], ln_t[n] = sum_k beta[k] W[n][k] (+ bias);
+  // the row statistics come out of the K loop and are saved to ln_stats ([M][2]: mean, rstd) for the LayerNorm backward
+  const float* ln_s; const float* ln_t; float* ln_stats; float ln_eps;
   float* partial;
   int splits, k_per_split;
   float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
@@ -140,9 +148,55 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// the same with the non-temporal hint: weight tiles that only one or two workgroups read (small M) stream through
+// without displacing the activations / code / kernel arguments that the next kernels re-read from L2 and MALL
+__device__ __forceinline__ void dma16_nt(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
+#ifdef DH_TUNING
+#define LNF_ABL(bit) && !(p.lnf_abl & (bit))
+#else
+#define LNF_ABL(bit)
+#endif
+
+// sum and sum of squares of the 8 16-bit values of an MFMA operand fragment (f32 accumulate, v_dot2c)
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ void frag_sums(const uint4& f, float& s1, float& s2);
+// (the empty asm pins the fragment as ONE 128-bit register tuple: without it the compiler scalarises the uint4, re-groups
+// the LDS reads of the A fragments into ds_read_b96 + ds_read2st64_b32 pieces, and those break the conflict-free
+// ds_read_b128 pattern the tile swizzle is built for)
+template <> __device__ __forceinline__ void frag_sums<f16>(const uint4& f_in, float& s1, float& s2) {
+  const v2h one = {(_Float16)1.f, (_Float16)1.f};
+  u4v f = __builtin_bit_cast(u4v, f_in);
+  asm("" : "+v"(f));
+  const unsigned w[4] = {f[0], f[1], f[2], f[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const v2h h = __builtin_bit_cast(v2h, w[i]);
+    s1 = __builtin_amdgcn_fdot2(h, one, s1, false);
+    s2 = __builtin_amdgcn_fdot2(h, h, s2, false);
+  }
+}
+template <> __device__ __forceinline__ void frag_sums<bf16>(const uint4& f_in, float& s1, float& s2) {
+  const v2b one = {(__bf16)1.f, (__bf16)1.f};
+  u4v f = __builtin_bit_cast(u4v, f_in);
+  asm("" : "+v"(f));
+  const unsigned w[4] = {f[0], f[1], f[2], f[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const v2b h = __builtin_bit_cast(v2b, w[i]);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(h, one, s1, false);
+    s2 = __builtin_amdgcn_fdot2_f32_bf16(h, h, s2, false);
+  }
+}
 
 // WG = 2: two groups of four waves share every staged tile; group g multiplies k-steps [g, g+1) * KK/2 of it and
 // issues half of the DMA pieces, and the groups' accumulators are added through LDS before the epilogue.  Same
@@ -154,9 +208,10 @@ enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
 // MW = 2: eight waves laid out 4 (M) x 2 (N) over a 256-row tile, 64 x (BN/2) outputs per wave as before: the A and W
 // tiles are shared by twice the MFMA work, so the staging traffic per flop (the TA / LDS-DMA issue that bounds the
 // 4-wave kernel on big grids) drops by a quarter and two waves share every SIMD.  For grids that fill the machine.
-template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1, bool LNF = false>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
 __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) {
   static_assert((WG == 1) + (KG == 1) + (MW == 1) >= 2, "one kind of wave grouping per instantiation");
+  static_assert(!LNF || (WG == 1 && MODE == GM_DENSE), "the folded LayerNorm needs every k-step of a row in one wave group");
   constexpr int NWV = 4 * MW;                               // waves that share one staged tile
   constexpr int TM = BM / 64 / MW, TN = BN / 64;
   constexpr int NPA = BM / 32 / WG / MW, NPB = BN / 32 / WG / MW;     // 1-KiB pieces per wave per stage
@@ -258,6 +313,10 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
       }
     } else {
       const int j = q - NPA;
+#ifdef DH_TUNING
+      if (p.w_nt) dma16_nt(b_ptr[j] + (size_t)(k0 >> 6) * 4096, sbase + BM * 128 + (j * WG + grp) * (NWV * 1024));
+      else
+#endif
       dma16(b_ptr[j] + (size_t)(k0 >> 6) * 4096, sbase + BM * 128 + (j * WG + grp) * (NWV * 1024));
     }
   };
@@ -278,6 +337,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int wn_u = __builtin_amdgcn_readfirstlane(wn);       // wave-uniform copy (scalar branch in the K loop)
+  float ln1[TM], ln2[TM];          // LNF: per-lane partial sum x / sum x^2 of the lane's rows (this lane's half of every k-step)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { ln1[i] = 0.f; ln2[i] = 0.f; }
+
 #pragma unroll
   for (int s = 0; s < ST - 1; ++s)
     if (s < ntiles) issue(s, s);
@@ -296,6 +360,19 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
         bpre[j][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
+  // folded LayerNorm: the per-column vectors are fetched under the K loop as well (their loads were the exposed tail)
+  constexpr bool PRE_LN = LNF && PRE && !(MW == 2 && BM == 256);     // (the 256x128 eight-wave tile has no registers to spare: it would spill)
+  float4 lsp[PRE_LN ? TN : 1][4], ltp[PRE_LN ? TN : 1][4];
+  if (PRE_LN) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+        lsp[PRE_LN ? j : 0][g] = n < p.N ? *reinterpret_cast<const float4*>(p.ln_s + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ltp[PRE_LN ? j : 0][g] = n < p.N ? *reinterpret_cast<const float4*>(p.ln_t + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
   uint2 rpre[TM][TN][4];
@@ -345,6 +422,12 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[kk & 1][j], fx[kk & 1][i], acc[i][j]);
+      // the two waves that share a row block (wn = 0 / 1) read the same A fragments: each sums every other k-step, so the
+      // v_dot2c work per wave is half and fits under the MFMAs of the step; the halves are exchanged after the loop
+      if (LNF && (kk & 1) == wn_u LNF_ABL(1)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) frag_sums<T>(fx[kk & 1][i], ln1[i], ln2[i]);
+      }
       // the DMA of tile kt+ST-1 is issued piecewise behind the MFMAs (address VALU co-issues with the matrix pipe)
       if (more) {
 #pragma unroll
@@ -354,10 +437,25 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     if (more) next_tile();
   }
 
+  if (LNF LNF_ABL(2)) {
+    // exchange the row sums with the partner wave (wave ^ 1: same rows, the other k-steps) through the idle rings
+    float* xb = reinterpret_cast<float*>(smem_all);
+    const int wid = tid >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { xb[(wid * 2 * TM + 2 * i) * 64 + lane] = ln1[i]; xb[(wid * 2 * TM + 2 * i + 1) * 64 + lane] = ln2[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ln1[i] += xb[((wid ^ 1) * 2 * TM + 2 * i) * 64 + lane];
+      ln2[i] += xb[((wid ^ 1) * 2 * TM + 2 * i + 1) * 64 + lane];
+    }
+  }
+
   if (WG > 1 || KG > 1) {
     // add the other groups' partial sums in group order: f32 through the (now idle) rings, [value][lane] per wave
     constexpr int NG = WG * KG;
-    constexpr int SLOT = TM * TN * 16 * 64;
+    constexpr int SLOT = (TM * TN * 16 + (LNF ? 2 * TM : 0)) * 64;
     static_assert((NG - 1) * 4 * SLOT * 4 <= KG * ST * STAGE, "merge buffer does not fit the stage rings");
     const int g = WG > 1 ? grp : kg;
     float* cb = reinterpret_cast<float*>(smem_all);
@@ -370,6 +468,10 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) slot[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+      if (LNF) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { slot[(TM * TN * 16 + 2 * i) * 64] = ln1[i]; slot[(TM * TN * 16 + 2 * i + 1) * 64] = ln2[i]; }
+      }
     }
     __syncthreads();
     if (g > 0) return;
@@ -382,6 +484,40 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((i * TN + j) * 16 + r) * 64];
+      if (LNF) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ln1[i] += slot[(TM * TN * 16 + 2 * i) * 64]; ln2[i] += slot[(TM * TN * 16 + 2 * i + 1) * 64]; }
+      }
+    }
+  }
+
+  if (LNF LNF_ABL(4)) {
+    // row statistics: the two lanes of a row (lane, lane ^ 32) hold the halves of every k-step; then
+    // acc <- rstd * (acc - mean * s[n]) + t[n], and the ordinary epilogue follows (bias is inside t)
+    const float inv_k = 1.f / (float)p.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float a = ln1[i] + __shfl_xor(ln1[i], 32, 64), q = ln2[i] + __shfl_xor(ln2[i], 32, 64);
+      const float mean = a * inv_k;
+      float var = q * inv_k - mean * mean;
+      var = var > 0.f ? var : 0.f;
+      const float rstd = rsqrtf(var + p.ln_eps);
+      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      if (blockIdx.y == 0 && wn == 0 && hi == 0 && m < p.M) { p.ln_stats[2 * (size_t)m] = mean; p.ln_stats[2 * (size_t)m + 1] = rstd; }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+          if (n >= p.N) continue;
+          float4 sv, tv;
+          if (PRE_LN) { sv = lsp[PRE_LN ? j : 0][g]; tv = ltp[PRE_LN ? j : 0][g]; }
+          else { sv = *reinterpret_cast<const float4*>(p.ln_s + n); tv = *reinterpret_cast<const float4*>(p.ln_t + n); }
+          acc[i][j][4 * g] = rstd * (acc[i][j][4 * g] - mean * sv.x) + tv.x;
+          acc[i][j][4 * g + 1] = rstd * (acc[i][j][4 * g + 1] - mean * sv.y) + tv.y;
+          acc[i][j][4 * g + 2] = rstd * (acc[i][j][4 * g + 2] - mean * sv.z) + tv.z;
+          acc[i][j][4 * g + 3] = rstd * (acc[i][j][4 * g + 3] - mean * sv.w) + tv.w;
+        }
     }
   }
 
@@ -620,33 +756,60 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
   }
 }
 
+// one tile configuration, the A-operand mode and the folded-LayerNorm variant picked at run time
+template <class T, int BM, int BN, int ST, int WG, int KG, int MW>
+static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k) {
+  constexpr int TH = 256 * WG * KG * MW;
+  if (gm == GM_DENSE) {
+    if constexpr (WG == 1) {
+      if (lnf) { hipLaunchKernelGGL((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true>), grid, dim3(TH), 0, st, k); return; }
+    }
+    hipLaunchKernelGGL((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW>), grid, dim3(TH), 0, st, k);
+  } else if (gm == GM_CONV_S1) {
+    hipLaunchKernelGGL((k_gemm_dma<T, BM, BN, ST, GM_CONV_S1, 0, WG, KG, MW>), grid, dim3(TH), 0, st, k);
+  } else {
+    hipLaunchKernelGGL((k_gemm_dma<T, BM, BN, ST, GM_GENERIC, 0, WG, KG, MW>), grid, dim3(TH), 0, st, k);
+  }
+}
+
+// Tile / split-K policy.  The constants are the round-1/2 bench.py A/B winners; a tuning build (-DDH_TUNING,
+// tools/build_tuning.sh) reads them from the environment instead, the product library carries no knobs.
+#ifdef DH_TUNING
+#define DH_KNOB(name, env, dflt) static const int name = getenv(env) ? atoi(getenv(env)) : (dflt)
+#else
+#define DH_KNOB(name, env, dflt) constexpr int name = (dflt)
+#endif
+
 template <class T>
 static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn_done) {
-  // tile / split-K policy (environment overrides are for tuning runs only)
-  static const int kSplitTiles = getenv("DH_SPLITK_TILES") ? atoi(getenv("DH_SPLITK_TILES")) : 200;
-  static const int kSplitMinK = getenv("DH_SPLITK_MINKT") ? atoi(getenv("DH_SPLITK_MINKT")) : 32;    // 24 -> 32 and
-  static const int kSplitTarget = getenv("DH_SPLITK_TARGET") ? atoi(getenv("DH_SPLITK_TARGET")) : 256;
-  static const int kBigTiles = getenv("DH_BIG_TILES") ? atoi(getenv("DH_BIG_TILES")) : 128;         // 48 -> 128 on the final kernels: +1 % on the guided step, +2 % at 768^2 (bench.py A/B)
+  DH_KNOB(kSplitTiles, "DH_SPLITK_TILES", 200);     // split K only under this many output tiles ...
+  DH_KNOB(kSplitMinK, "DH_SPLITK_MINKT", 32);       // ... and from this many K tiles (24 -> 32: +1 % on the guided step)
+  DH_KNOB(kSplitTarget, "DH_SPLITK_TARGET", 256);   // workgroups aimed at
+  DH_KNOB(kBigTiles, "DH_BIG_TILES", 128);          // fewer big tiles than this and a short K loop: 64x64 tiles (48 -> 128: +1 % step, +2 % at 768^2)
+  DH_KNOB(kNarrowTiles, "DH_NARROW_TILES", 40);     // long-K GEMMs with at most this many 128x128 tiles use the 128x64 tile
+  DH_KNOB(kN320, "DH_GEMM_N320", 224);              // row tiles from which N = 320 runs as one 128x320 tile (256 at batch 8: pass -4.5 %; 144 tiles lose 1 %)
+  DH_KNOB(kMwBlocks, "DH_GEMM_MW", 64);             // 256x128 eight-wave tiles from this many of them
+  DH_KNOB(kKg2MinKt, "DH_KG2_MINKT", 4);            // K tiles per split from which the 128x64 tile splits K over two wave groups (16 -> 4: +1.4 % step)
+  DH_KNOB(kManyBlocks, "DH_GEMM_MANY", 512);        // 128x128 grids from this size use two stages (two workgroups per CU)
+  DH_KNOB(kMw128, "DH_GEMM_MW128", 1);              // min K tiles for eight waves on the 128x128 tile
+  DH_KNOB(kWnt, "DH_W_NT", 0);                      // non-temporal weight DMA for GEMMs of at most this many row tiles (0 = never)
+  const bool lnf = k.ln_s != nullptr;
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
   const int ktiles = k.K / BK;
-  // tuning knob: long-K GEMMs whose 128x128 tiling has at most this many tiles use the 128x64 tile (two wave groups)
-  static const int kNarrowTiles = getenv("DH_NARROW_TILES") ? atoi(getenv("DH_NARROW_TILES")) : 40;     // 0 -> 40 and
   if (BN == 128 && ktiles >= 16 && cdiv(k.M, 128) * cdiv(k.N, 128) <= kNarrowTiles) BN = 64;
-  // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles, K split over four
-  // wave groups inside the workgroup (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
+  // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles
+  // (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
   if (k.M <= 64 || (cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles && ktiles < kSplitMinK)) { BM = 64; BN = 64; }
   // N = 320 (the 64x64-latent convolutions and linears) with enough rows to fill the chip: one 128x320 tile per 128 rows,
   // so the A tile is staged once instead of five times (batched edits; a single image has only 32 such tiles)
-  static const int kN320 = getenv("DH_GEMM_N320") ? atoi(getenv("DH_GEMM_N320")) : 224;     // row tiles that fill the CUs (256 at batch 8: U-Net pass -4.5 %); 144 tiles (768^2, B = 2) lose 1 %
   const bool n320 = kN320 > 0 && k.N == 320 && BM == 128 && BN == 64 && cdiv(k.M, 128) >= kN320;
   if (n320) BN = 320;
   // grids that fill the machine: 256x128 tiles, eight waves (see MW)
-  static const int kMwBlocks = getenv("DH_GEMM_MW") ? atoi(getenv("DH_GEMM_MW")) : 64;
   const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && (long)cdiv(k.M, 256) * cdiv(k.N, 128) >= kMwBlocks;
   if (mw2) { BM = 256; BN = 128; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
-  if (k.partial && tiles < kSplitTiles && ktiles >= kSplitMinK) {
+  if (k.partial && !lnf && tiles < kSplitTiles && ktiles >= kSplitMinK) {
     splits = kSplitTarget / tiles;
     if (splits > ktiles / 4) splits = ktiles / 4;
     if (splits > 32) splits = 32;
@@ -658,6 +821,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   splits = cdiv(ktiles, tiles_per_split);
   k.splits = splits;
   k.k_per_split = tiles_per_split * BK;
+#ifdef DH_TUNING
+  k.w_nt = kWnt > 0 && tm <= kWnt;
+  static const int kLnfAbl = getenv("DH_LNF_ABL") ? atoi(getenv("DH_LNF_ABL")) : 0;
+  k.lnf_abl = kLnfAbl;
+#endif
   dim3 grid(tm, tn, splits);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof.on) {
@@ -674,60 +842,24 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   int gm = GM_GENERIC;
   if (k.mode == A_DENSE) gm = GM_DENSE;
   else if (k.mode == A_CONV3 && k.stride == 1 && k.up == 0) gm = GM_CONV_S1;
-#define DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, WG_)                                                                            \
-  do {                                                                                                                    \
-    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_DENSE, 0, WG_>), grid, dim3(256 * WG_), 0, st, k);        \
-    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1, 0, WG_>), grid, dim3(256 * WG_), 0, st, k); \
-    else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC, 0, WG_>), grid, dim3(256 * WG_), 0, st, k);                    \
-  } while (0)
-#define DH_LAUNCH_GEMM(BM_, BN_, ST_)                         \
-  do {                                                        \
-    if (wg == 2) DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, 2);         \
-    else DH_LAUNCH_GEMM_WG(BM_, BN_, ST_, 1);                 \
-  } while (0)
-  // two wave groups per block: measured ahead only on the 128x64 tile with a long K loop (conv 4096x320x2880:
-  // 28.5 -> 24.9 us, x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge)
-#define DH_LAUNCH_GEMM_KG(BM_, BN_, ST_, KG_)                                                                               \
-  do {                                                                                                                      \
-    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_DENSE, 0, 1, KG_>), grid, dim3(256 * KG_), 0, st, k);        \
-    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_CONV_S1, 0, 1, KG_>), grid, dim3(256 * KG_), 0, st, k); \
-    else hipLaunchKernelGGL((k_gemm_dma<T, BM_, BN_, ST_, GM_GENERIC, 0, 1, KG_>), grid, dim3(256 * KG_), 0, st, k);                    \
-  } while (0)
-  static const int kKg = getenv("DH_GEMM_KG") ? atoi(getenv("DH_GEMM_KG")) : 0;
-  static const int kKg64 = getenv("DH_GEMM_KG64") ? atoi(getenv("DH_GEMM_KG64")) : 11;     // 64x64 tile: (groups, stages) as two digits; in situ no K grouping wins (27.9 vs 27.4 steps/s for 4 groups x 2 stages)
-  static const int kKg2MinKt = getenv("DH_KG2_MINKT") ? atoi(getenv("DH_KG2_MINKT")) : 4;       // 16 -> 4 on the final kernels: +1.4 % on the guided step (bench.py A/B), batch-8 and 768^2 unchanged
-  static const int kManyBlocks = getenv("DH_GEMM_MANY") ? atoi(getenv("DH_GEMM_MANY")) : 512;
-  static const int kMw128 = getenv("DH_GEMM_MW128") ? atoi(getenv("DH_GEMM_MW128")) : 1;   // min K tiles for 8 waves on 128x128
-  static const int kWg = getenv("DH_GEMM_WG") ? atoi(getenv("DH_GEMM_WG")) : 0;
-  const int wg = kWg ? kWg : 1;
+#ifdef DH_TUNING
+  // ablations of the K loop (timing only): 1 = no LDS reads / MFMA, 2 = no DMA in the loop, 3 = 1 on the dense kernel
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
   if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 3 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 1>), grid, dim3(256), 0, st, k); }
-  else if (mw2) {
-    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_DENSE, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
-    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_CONV_S1, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
-    else hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_GENERIC, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
-  }
-  else if (kMw128 && BM == 128 && BN == 128 && tiles_per_split >= kMw128) {
-    if (gm == GM_DENSE) hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
-    else if (gm == GM_CONV_S1) hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
-    else hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_GENERIC, 0, 1, 1, 2>), grid, dim3(512), 0, st, k);
-  }
-  else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 42) DH_LAUNCH_GEMM_KG(64, 64, 2, 4);
-  else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 24) DH_LAUNCH_GEMM_KG(64, 64, 4, 2);
-  else if (kKg != 1 && BM == 64 && tiles_per_split >= 8 && kKg64 == 23) DH_LAUNCH_GEMM_KG(64, 64, 3, 2);
-  else if (kKg != 1 && BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) DH_LAUNCH_GEMM_KG(128, 64, 3, 2);
-  else if (kKg == 2 && BM == 128 && BN == 128) DH_LAUNCH_GEMM_KG(128, 128, 2, 2);
   else
-  if (BN == 320) DH_LAUNCH_GEMM_WG(128, 320, 2, 1);
-  else if (BM == 64) DH_LAUNCH_GEMM(64, 64, 4);
-  else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) DH_LAUNCH_GEMM(128, 128, 2);   // 64 KiB: two workgroups per CU
-  else if (BN == 128) DH_LAUNCH_GEMM(128, 128, 4);
-  else DH_LAUNCH_GEMM(128, 64, 5);
-#undef DH_LAUNCH_GEMM
-#undef DH_LAUNCH_GEMM_WG
-#undef DH_LAUNCH_GEMM_KG
+#endif
+  if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k);
+  else if (kMw128 && BM == 128 && BN == 128 && tiles_per_split >= kMw128) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k);
+  // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
+  // x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge; 64x64 tiles: no K grouping wins in situ)
+  else if (BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k);
+  else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 1>(gm, lnf, grid, st, k);
+  else if (BM == 64) launch_tile<T, 64, 64, 4, 1, 1, 1>(gm, lnf, grid, st, k);
+  else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) launch_tile<T, 128, 128, 2, 1, 1, 1>(gm, lnf, grid, st, k);   // 64 KiB: two workgroups per CU
+  else if (BN == 128) launch_tile<T, 128, 128, 4, 1, 1, 1>(gm, lnf, grid, st, k);
+  else launch_tile<T, 128, 64, 5, 1, 1, 1>(gm, lnf, grid, st, k);
   if (e1) (void)hipEventRecord(e1, st);
   if (splits > 1) {
     if (k.gn_part && k.gn_G > 0 && k.gn_HW > 0 && k.N % k.gn_G == 0 && (GN_GB * (k.N / k.gn_G)) % 8 == 0 &&
@@ -742,6 +874,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
     }
   }
 }
+#undef DH_KNOB
 
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   GemmK k;
@@ -753,10 +886,9 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   k.inv_rows_per_batch = 1.f / (float)k.rows_per_batch;
   k.R = a.R; k.ldr = a.ldr; k.C = a.C; k.ldc = a.ldc; k.act_silu = a.act_silu;
   k.partial = a.partial; k.splits = 1; k.k_per_split = a.K;
-  static const int kPreR = getenv("DH_GEMM_PRE_R") ? atoi(getenv("DH_GEMM_PRE_R")) : 1;
-  k.pre_r = kPreR;
-  static const int kWide = getenv("DH_GEMM_WIDE_STORE") ? atoi(getenv("DH_GEMM_WIDE_STORE")) : 1;
-  k.wide_store = kWide && a.N % 32 == 0 && a.ldc % 8 == 0 && ((size_t)a.C & 15) == 0;
+  k.pre_r = 1;
+  k.wide_store = a.N % 32 == 0 && a.ldc % 8 == 0 && ((size_t)a.C & 15) == 0;
+  k.ln_s = a.ln_s; k.ln_t = a.ln_t; k.ln_stats = a.ln_stats; k.ln_eps = a.ln_eps;
   k.gn_part = a.gn_part; k.gn_HW = a.gn_HW; k.gn_G = a.gn_G; k.gn_S = 0;
   k.gnb_x = a.gnb_x; k.gnb_ldx = a.gnb_ldx; k.gnb_gamma = a.gnb_gamma; k.gnb_beta = a.gnb_beta; k.gnb_stats = a.gnb_stats;
   k.gnb_silu = a.gnb_silu;

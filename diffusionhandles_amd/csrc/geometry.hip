@@ -505,6 +505,19 @@ static int ellipse_offsets(int k, int2* out) {
 
 constexpr int MAX_OFFS = 4096;
 
+}  // namespace dh
+// test hook (host only, no device call): the (dx, dy) offsets of the k x k elliptical structuring element the mask
+// clean-up uses, so the CPU suite can pin them to OpenCV's published tables
+extern "C" int dh_dbg_ellipse_offsets(int k, int32_t* xy, int cap, int* n_out) {
+  DH_REQUIRE(k >= 1 && (long)k * k <= dh::MAX_OFFS && xy && n_out && cap >= k * k, "bad arguments");
+  static int2 tmp[dh::MAX_OFFS];
+  const int n = dh::ellipse_offsets(k, tmp);
+  for (int i = 0; i < n; ++i) { xy[2 * i] = tmp[i].x; xy[2 * i + 1] = tmp[i].y; }
+  *n_out = n;
+  return DH_OK;
+}
+namespace dh {
+
 struct ReprojectWs {
   Xf* xf;
   float* cen;

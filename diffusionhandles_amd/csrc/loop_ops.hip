@@ -32,24 +32,19 @@ __global__ void k_adam(float* p, const float* g, float* m, float* v, float lr, f
   p[i] = p[i] - (lr / bc1) * (mi / denom);
 }
 
-__global__ void k_mse(const float* a, const float* b, int n, double* part, float* d_a) {
-  __shared__ double sm[4];
+// one workgroup: the latent has 16 K - 300 K elements, and a single-block reduction needs no partials buffer
+// (nothing process-global, legal inside stream capture, deterministic summation order)
+__global__ void __launch_bounds__(1024) k_mse(const float* a, const float* b, int n, float* out, float* d_a) {
+  __shared__ double sm[16];
   double l = 0.0;
   const float k = 2.f / (float)n;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     float d = a[i] - b[i];
     l += (double)d * (double)d;
     if (d_a) d_a[i] = k * d;
   }
   l = block_sum(l, sm);
-  if (threadIdx.x == 0) part[blockIdx.x] = l;
-}
-__global__ void k_mse_final(const double* part, int nb, int n, float* out) {
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += part[i];
-    out[0] = (float)(s / (double)n);
-  }
+  if (threadIdx.x == 0) out[0] = (float)(l / (double)n);
 }
 
 }  // namespace dh
@@ -86,14 +81,10 @@ extern "C" int dh_adam_step(float* p, const float* g, float* m, float* v, float 
   return DH_OK;
 }
 
-static double* g_mse_part = nullptr;
 extern "C" int dh_mse_fwd_bwd(const float* rec, const float* target, int n, float* loss_out, float* d_rec,
                               void* stream) {
   DH_REQUIRE(rec && target && loss_out && n > 0, "bad arguments");
-  const int nb = 64;
-  if (!g_mse_part) DH_CHECK_HIP(hipMalloc(&g_mse_part, nb * sizeof(double)));
-  hipLaunchKernelGGL(k_mse, dim3(nb), dim3(256), 0, (hipStream_t)stream, rec, target, n, g_mse_part, d_rec);
-  hipLaunchKernelGGL(k_mse_final, dim3(1), dim3(64), 0, (hipStream_t)stream, g_mse_part, nb, n, loss_out);
+  hipLaunchKernelGGL(k_mse, dim3(1), dim3(1024), 0, (hipStream_t)stream, rec, target, n, loss_out, d_rec);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

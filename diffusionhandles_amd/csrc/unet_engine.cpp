@@ -65,6 +65,11 @@ struct Op {
   int heads = 0, Nq = 0, Nk = 0, cross = 0, kv_col = 0; size_t lse_off = 0;
   // concat: in0 | in1
   int gn_next = -1;         // index of the GroupNorm op that consumes `out` right after this op (statistics fused here)
+  // LayerNorm folded into the GEMM that consumes it (forward only; the backward pass still runs the LayerNorm op):
+  // on the GEMM, ln_fold = index of the LayerNorm op and ln_s_off / ln_t_off = the per-column vectors (f32 param arena);
+  // on the LayerNorm op, folded = 1 (the forward skips it: its statistics come out of the GEMM)
+  int ln_fold = -1, folded = 0;
+  long ln_s_off = -1, ln_t_off = -1;
 };
 
 }  // namespace dh
@@ -93,13 +98,15 @@ struct dh_unet {
   // a guided step share it.  temb_rows images hold the projections of timestep temb_t (0 rows = nothing cached).
   int temb_ops = 0, temb_rows = 0;
   float temb_t = 0.f;
+  hipStream_t temb_stream = nullptr;   // the stream the cached projections were produced on (another stream = miss)
   long temb_f32_off = -1;
   int temb_total = 0, kv_total = 0;
   // staging buffers (fixed addresses so a captured graph can be replayed) and graph cache
   float *in_sample = nullptr, *in_text = nullptr, *io_eps = nullptr, *out_dsample = nullptr, *out_dtext = nullptr, *t_dev = nullptr;
-  std::map<unsigned, hipGraphExec_t> graphs;
-  std::map<unsigned, double> graph_flops;
+  std::map<uint64_t, hipGraphExec_t> graphs;      // 64-bit keys: every field has its own bit range (graph_key_*)
+  std::map<uint64_t, double> graph_flops;
   bool use_graphs = true;
+  bool fold_dirty = true;           // a parameter was (re)loaded: W * gamma and the s / t vectors of the folded LayerNorms are stale
   // run state
   int saved_batch = 0;
   const float* saved_sample = nullptr;
@@ -239,6 +246,18 @@ struct Builder {
     return o.out;
   }
 
+  // the GEMM op just pushed consumes the LayerNorm op pushed right before it: fold that LayerNorm into it
+  void fold_ln_into_last_gemm() {
+    const int gi = (int)u.ops.size() - 1, li = gi - 1;
+    Op& g = u.ops[gi];
+    Op& l = u.ops[li];
+    if (g.type != OP_GEMM || l.type != OP_LN || g.in0 != l.out || g.mode != A_DENSE || g.in_col != 0) return;
+    const int N = u.wts[g.wt].N;
+    g.ln_fold = li; l.folded = 1;
+    g.ln_s_off = (long)u.pf_elems; u.pf_elems += align_up((size_t)N, 64);
+    g.ln_t_off = (long)u.pf_elems; u.pf_elems += align_up((size_t)N, 64);
+  }
+
   int temb_cursor = 0, kv_cursor = 0;
   int wt_temb = -1, wt_kv = -1;
   size_t temb_bias_off = 0;
@@ -270,6 +289,7 @@ struct Builder {
     bind_mat(b + ".attn1.to_k.weight", wqkv, C, C, C, 1);
     bind_mat(b + ".attn1.to_v.weight", wqkv, C, 2 * C, C, 1);
     int qkv = linear_w(n1, wqkv, -1, -1);
+    fold_ln_into_last_gemm();
     Op a;
     a.type = OP_ATTN; a.in0 = qkv; a.heads = heads; a.Nq = N; a.Nk = N; a.cross = 0;
     a.out = tensor(N, C);
@@ -279,6 +299,7 @@ struct Builder {
     // cross attention: q GEMM; k|v come from the hoisted text projection
     int n2 = ln(t1, b + ".norm2");
     int q2 = linear(n2, b + ".attn2.to_q", C, false, -1);
+    fold_ln_into_last_gemm();
     bind_mat(b + ".attn2.to_k.weight", wt_kv, C, kv_cursor, u.cfg.cross_attention_dim, 1);
     bind_mat(b + ".attn2.to_v.weight", wt_kv, C, kv_cursor + C, u.cfg.cross_attention_dim, 1);
     Op c;
@@ -292,6 +313,7 @@ struct Builder {
     // feed forward (GEGLU)
     int n3 = ln(t2, b + ".norm3");
     int gg = linear(n3, b + ".ff.net.0.proj", 8 * C, true, -1);
+    fold_ln_into_last_gemm();
     Op g;
     g.type = OP_GEGLU; g.in0 = gg; g.out = tensor(N, 4 * C);
     u.ops.push_back(g);
@@ -449,6 +471,46 @@ __global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, 
   }
 }
 
+// LayerNorm fold (one workgroup per output column n of a dense weight [N][K]): reads the unfolded 16-bit W[n][k] from the
+// input-gradient copy (rows k, columns n: it is never folded), writes W'[n][k] = round16(W[n][k] * gamma[k]) into the
+// forward copy, and leaves s[n] = sum_k W'[n][k] (of the ROUNDED values the MFMA will multiply) and
+// t[n] = sum_k beta[k] W[n][k] (+ bias[n]).
+template <class D>
+__global__ void __launch_bounds__(256) k_fold_ln(const D* bwd, int bwd_K, const float* gamma, const float* beta, const float* bias,
+                                                 D* fwd, int K, float* s_out, float* t_out) {
+  __shared__ float sm[8];
+  const int n = blockIdx.x;
+  float s = 0.f, t = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float w = to_f32<D>(bwd[wt_index(k, n, bwd_K)]);
+    const D wf = from_f32<D>(w * gamma[k]);
+    fwd[wt_index(n, k, K)] = wf;
+    s += to_f32<D>(wf);
+    t += beta[k] * w;
+  }
+  s = block_sum(s, sm);
+  __syncthreads();
+  t = block_sum(t, sm);
+  if (threadIdx.x == 0) { s_out[n] = s; t_out[n] = t + (bias ? bias[n] : 0.f); }
+}
+
+// (re)compute the folded weights and vectors of every LayerNorm-consuming GEMM; runs on `st` before the pass that needs them
+static void fold_layernorms(dh_unet* u, hipStream_t st) {
+  for (const Op& g : u->ops) {
+    if (g.type != OP_GEMM || g.ln_fold < 0) continue;
+    const Op& l = u->ops[g.ln_fold];
+    const Wt& w = u->wts[g.wt];
+    const float* bias = g.bias_off >= 0 ? u->pf + g.bias_off : nullptr;
+    if (u->dtype == DH_DTYPE_F16)
+      hipLaunchKernelGGL((k_fold_ln<f16>), dim3(w.N), dim3(256), 0, st, (const f16*)(u->w16 + w.bwd_off), w.N, u->pf + l.gamma_off,
+                         u->pf + l.beta_off, bias, (f16*)(u->w16 + w.fwd_off), w.K, u->pf + g.ln_s_off, u->pf + g.ln_t_off);
+    else
+      hipLaunchKernelGGL((k_fold_ln<bf16>), dim3(w.N), dim3(256), 0, st, (const bf16*)(u->w16 + w.bwd_off), w.N, u->pf + l.gamma_off,
+                         u->pf + l.beta_off, bias, (bf16*)(u->w16 + w.fwd_off), w.K, u->pf + g.ln_s_off, u->pf + g.ln_t_off);
+  }
+  u->fold_dirty = false;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -456,7 +518,7 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
   DH_REQUIRE(cfg && out, "null pointer");
   DH_REQUIRE(cfg->n_levels == 4, "n_levels must be 4");
   DH_REQUIRE(cfg->dtype == DH_DTYPE_F16 || cfg->dtype == DH_DTYPE_BF16, "dtype must be f16 or bf16");
-  DH_REQUIRE(cfg->max_batch >= 1 && cfg->sample_size % 8 == 0 && cfg->sample_size >= 8, "bad batch / sample size");
+  DH_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch < 4096 && cfg->sample_size % 8 == 0 && cfg->sample_size >= 8, "bad batch / sample size");
   // the kernels index rows with float-reciprocal divisions that are exact below 2^21 rows (common.h div_small)
   DH_REQUIRE((long)cfg->max_batch * cfg->sample_size * cfg->sample_size < (1L << 21), "max_batch * sample_size^2 must stay below 2^21 rows");
   DH_REQUIRE(cfg->norm_groups >= 1 && cfg->norm_groups <= 32, "1..32 GroupNorm groups");
@@ -529,7 +591,7 @@ extern "C" int dh_unet_param_info(const dh_unet* u, int i, const char** name, in
 }
 
 extern "C" int dh_unet_load_param(dh_unet* u, int i, const float* src, void* stream) {
-  if (u) u->temb_rows = 0;      // cached time-embedding projections belong to the old weights
+  if (u) { u->temb_rows = 0; u->fold_dirty = true; }     // cached time-embedding projections / folded LayerNorm weights belong to the old parameters
   DH_REQUIRE(u && src && i >= 0 && i < (int)u->params.size(), "bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const ParamInfo& p = u->params[i];
@@ -584,6 +646,12 @@ static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
   g.C = u->aptr(o.out); g.ldc = to.C;
   g.act_silu = o.act_silu;
   g.partial = u->partial; g.partial_elems = u->partial_elems;
+  if (o.ln_fold >= 0) {          // A = the LayerNorm's INPUT; the normalisation happens in the epilogue (bias is inside ln_t)
+    const Op& l = u->ops[o.ln_fold];
+    g.A = u->aptr(l.in0); g.lda = u->tens[l.in0].C;
+    g.bias = nullptr;
+    g.ln_s = u->pf + o.ln_s_off; g.ln_t = u->pf + o.ln_t_off; g.ln_stats = u->f32a + l.stats_off; g.ln_eps = l.eps;
+  }
 }
 
 static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, hipStream_t st) {
@@ -635,6 +703,7 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, hipStream_t 
         break;
       }
       case OP_LN: {
+        if (o.folded) break;           // normalised inside the GEMM that follows (fill_gemm)
         const Ten& t = u->tens[o.in0];
         launch_layernorm_fwd(dt, u->aptr(o.in0), u->pf + o.gamma_off, u->pf + o.beta_off, u->aptr(o.out),
                              u->f32a + o.stats_off, B * t.rows, t.C, o.eps, st);
@@ -680,8 +749,18 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, hipStream_t 
 }
 
 // run `body` through a cached hipGraph (captured on first use of `key`) or eagerly
+// graph cache keys: batch in bits 0-11 (max_batch < 2^12 by dh_unet_create), the tape length in 12-27, the
+// backward's activation mask in 28-30, its flags in 31-33, time-embedding hit in 34, forward / backward in 35
+static uint64_t graph_key_fwd(int B, int n_ops, bool temb_hit) {
+  return (uint64_t)B | ((uint64_t)n_ops << 12) | ((uint64_t)(temb_hit ? 1 : 0) << 34);
+}
+static uint64_t graph_key_bwd(int B, unsigned mask, bool eps, bool sample, bool text) {
+  return (uint64_t)B | ((uint64_t)(mask & 7u) << 28) | ((uint64_t)(eps ? 1 : 0) << 31) | ((uint64_t)(sample ? 1 : 0) << 32) |
+         ((uint64_t)(text ? 1 : 0) << 33) | (1ull << 35);
+}
+
 template <class F>
-static int run_graphed(dh_unet* u, unsigned key, hipStream_t st, double* flops_slot, F body) {
+static int run_graphed(dh_unet* u, uint64_t key, hipStream_t st, double* flops_slot, F body) {
   // the legacy default stream (0) cannot be captured: callers that want graph replay run on a created stream
   if (!u->use_graphs || st == nullptr || gemm_profiling_on()) { body(); return DH_OK; }
   auto it = u->graphs.find(key);
@@ -721,12 +800,13 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
       if (act_out && act_out[i]) n_ops = std::max(n_ops, u->act_op_end[i]);
     DH_REQUIRE(n_ops > 0, "nothing requested: eps_out and every act_out are null");
   }
-  const bool temb_hit = u->temb_rows >= B && u->temb_t == timestep;
+  if (u->fold_dirty) fold_layernorms(u, st);
+  const bool temb_hit = u->temb_rows >= B && u->temb_t == timestep && u->temb_stream == st;
   const int first_op = temb_hit ? u->temb_ops : 0;
-  int rc = run_graphed(u, 0x80000000u | (temb_hit ? 0x40000000u : 0u) | (unsigned)B | ((unsigned)n_ops << 8), st, &u->flops_fwd,
+  int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit), st, &u->flops_fwd,
                        [&]() { forward_ops(u, B, n_ops, first_op, st); });
-  if (!temb_hit) { u->temb_t = timestep; u->temb_rows = B; }
-  if (rc != DH_OK) return rc;
+  if (rc != DH_OK) { u->temb_rows = 0; return rc; }      // nothing cached after a failed capture / launch
+  if (!temb_hit) { u->temb_t = timestep; u->temb_rows = B; u->temb_stream = st; }
   if (eps_out) DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
   if (act_out) {
     for (int i = 0; i < 3; ++i)
@@ -946,8 +1026,7 @@ extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_e
         mask |= 1u << i;
       }
   if (d_eps) DH_CHECK_HIP(hipMemcpyAsync(u->io_eps, d_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
-  const unsigned key = 0x1000u | (unsigned)B | (mask << 4) | (d_eps ? 0x100u : 0) | (d_sample ? 0x200u : 0) |
-                       (d_text ? 0x400u : 0);
+  const uint64_t key = graph_key_bwd(B, mask, d_eps != nullptr, d_sample != nullptr, d_text != nullptr);
   int rc = run_graphed(u, key, st, &u->flops_bwd,
                        [&]() { backward_ops(u, B, mask, d_eps != nullptr, d_sample != nullptr, d_text != nullptr, st); });
   if (rc != DH_OK) return rc;

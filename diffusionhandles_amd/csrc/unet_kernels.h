@@ -33,6 +33,9 @@ struct GemmArgs {
   // backward slice statistics (sum d, sum d*xhat with d = dy * gamma * act') in gn_part (k_gn_partial<bwd> layout)
   const void* gnb_x = nullptr; long gnb_ldx = 0; const float *gnb_gamma = nullptr, *gnb_beta = nullptr, *gnb_stats = nullptr;
   int gnb_silu = 0;
+  // LayerNorm folded into the GEMM (dense, no split-K): A = the LayerNorm input, W = W * gamma (load-time fold),
+  // ln_s[n] = sum_k W'[n][k], ln_t[n] = sum_k beta[k] W[n][k] + bias[n]; the row statistics are written to ln_stats [M][2]
+  const float* ln_s = nullptr; const float* ln_t = nullptr; float* ln_stats = nullptr; float ln_eps = 1e-5f;
 };
 // D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);

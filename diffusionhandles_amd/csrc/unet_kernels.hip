@@ -6,6 +6,17 @@
 
 namespace dh {
 
+// Timing-only ablation (tuning builds, -DDH_TUNING; compiled out of the product library): DH_ABLATE_SKIP is a bit mask of
+// launcher families that return without launching (results are garbage) -- the step time it removes divided by the
+// launches it removes is what a launch of that family costs in situ.  1 = LayerNorm, 2 = GroupNorm, 4 = GEGLU,
+// 8 = copies / concat / split / pool
+#ifdef DH_TUNING
+static int ablate_mask() { static const int m = getenv("DH_ABLATE_SKIP") ? atoi(getenv("DH_ABLATE_SKIP")) : 0; return m; }
+#define DH_ABLATE(bit) do { if (ablate_mask() & (bit)) return; } while (0)
+#else
+#define DH_ABLATE(bit) do { } while (0)
+#endif
+
 // ------------------------------------------------------------- tiny-channel convolutions
 // few input channels (<= 8), many outputs: y[p][co] = b[co] + sum_{tap,ci} x[p+off][ci] w[co][tap][ci].
 // A workgroup owns CF_PIX consecutive pixels so that every weight is read once per CF_PIX pixels (one pixel per
@@ -362,6 +373,7 @@ static inline int gn_apply_iters(size_t blocks_total) {
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                           int have_partials) {
+  DH_ABLATE(2);
   const int S = gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
@@ -467,6 +479,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st, int have_partials) {
+  DH_ABLATE(2);
   const int S = gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
@@ -558,6 +571,7 @@ __global__ void __launch_bounds__(256) k_concat_gn(const T* a, int Ca, const T* 
 
 void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, void* out, float* gn_part, int B, int HW,
                       int G, hipStream_t st) {
+  DH_ABLATE(8);
   const int S = gn_slices(HW, B);
   dim3 grid(S, cdiv(G, GN_GB), B);
   if (dtype == DH_DTYPE_F16)
@@ -688,6 +702,7 @@ __global__ void __launch_bounds__(256, NCH == 1 ? 8 : (NCH <= 3 ? 4 : 1)) k_ln_b
 
 void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           int rows, int C, float eps, hipStream_t st) {
+  DH_ABLATE(1);
 #define DH_LN_FWD(TT, N) hipLaunchKernelGGL((k_ln_fwd<TT, N>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const TT*)x, gamma, beta, (TT*)y, stats, rows, C, eps)
   const int n = C <= 512 ? 1 : (C <= 1024 ? 2 : (C <= 1536 ? 3 : LN_MAXCH));
   if (dtype == DH_DTYPE_F16) {
@@ -699,6 +714,7 @@ void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const fl
 }
 void launch_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
                           const void* add, void* dx, int rows, int C, hipStream_t st) {
+  DH_ABLATE(1);
 #define DH_LN_BWD(TT, N) hipLaunchKernelGGL((k_ln_bwd<TT, N>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const TT*)x, (const TT*)dy, gamma, stats, (const TT*)add, (TT*)dx, rows, C)
   const int n = C <= 512 ? 1 : (C <= 1024 ? 2 : (C <= 1536 ? 3 : LN_MAXCH));
   if (dtype == DH_DTYPE_F16) {
@@ -759,11 +775,13 @@ __global__ void k_geglu_bwd(const T* x, const T* dy, T* dx, size_t rows, int F) 
 }
 
 void launch_geglu_fwd(int dtype, const void* x, void* y, int rows, int F, hipStream_t st) {
+  DH_ABLATE(4);
   const unsigned nb = (unsigned)(((size_t)rows * (F / 8) + 255) / 256);
   if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_geglu_fwd<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, (f16*)y, (size_t)rows, F);
   else hipLaunchKernelGGL((k_geglu_fwd<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (bf16*)y, (size_t)rows, F);
 }
 void launch_geglu_bwd(int dtype, const void* x, const void* dy, void* dx, int rows, int F, hipStream_t st) {
+  DH_ABLATE(4);
   const unsigned nb = (unsigned)(((size_t)rows * (F / 8) + 255) / 256);
   if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_geglu_bwd<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, (const f16*)dy, (f16*)dx, (size_t)rows, F);
   else hipLaunchKernelGGL((k_geglu_bwd<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, (size_t)rows, F);
@@ -792,6 +810,7 @@ __global__ void k_copy_cols(const T* src, long lds_, T* dst, long ldd, size_t ro
 }
 void launch_copy_cols(int dtype, const void* src, long lds_, void* dst, long ldd, int rows, int cols, int accumulate,
                       hipStream_t st) {
+  DH_ABLATE(8);
   const unsigned nb = (unsigned)(((size_t)rows * (cols / 8) + 255) / 256);
   if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_copy_cols<f16>), dim3(nb), dim3(256), 0, st, (const f16*)src, lds_, (f16*)dst, ldd, (size_t)rows, cols, accumulate);
   else hipLaunchKernelGGL((k_copy_cols<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)src, lds_, (bf16*)dst, ldd, (size_t)rows, cols, accumulate);
@@ -823,6 +842,7 @@ __global__ void k_split_cols(const T* src, long lds_, T* dstA, long ldA, int col
 }
 void launch_split_cols(int dtype, const void* src, long lds_, void* dstA, long ldA, int colsA, int accA, void* dstB, long ldB,
                        int colsB, int accB, int rows, hipStream_t st) {
+  DH_ABLATE(8);
   const unsigned nb = (unsigned)(((size_t)rows * ((colsA + colsB) / 8) + 255) / 256);
   if (dtype == DH_DTYPE_F16)
     hipLaunchKernelGGL((k_split_cols<f16>), dim3(nb), dim3(256), 0, st, (const f16*)src, lds_, (f16*)dstA, ldA, colsA, accA, (f16*)dstB, ldB, colsB, accB, (size_t)rows);
@@ -864,6 +884,7 @@ __global__ void k_pool2x2(const T* src, T* dst, int B, int h, int w, int C, int 
 }
 void launch_pool2x2_sum(int dtype, const void* src, void* dst, int B, int h, int w, int C, int accumulate,
                         hipStream_t st) {
+  DH_ABLATE(8);
   const unsigned nb = (unsigned)(((size_t)B * h * w * (C / 8) + 255) / 256);
   if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_pool2x2<f16>), dim3(nb), dim3(256), 0, st, (const f16*)src, (f16*)dst, B, h, w, C, accumulate);
   else hipLaunchKernelGGL((k_pool2x2<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, B, h, w, C, accumulate);

@@ -308,10 +308,12 @@ class GuidedStableDiffuser(GuidedDiffuser):
         return energy_and_grad(act, st.orig[k][t_idx], st.pc, fgw, bgw, self.conf.fg_patch_size, self.conf.bg_patch_size,
                                st.size, self.conf.bg_loss_type, grad_scale=self.grad_scale)[1]
 
-    def guided_step(self, st, x, t_idx, t, uncond, record=None):
+    def guided_step(self, st, x, t_idx, t, uncond, record=None, images=None):
         """One guided-denoise step (guided_stable_diffuser.py:377-479): up to num_optsteps x
         {U-Net forward, energy + gradient, backward-to-latent, latent update}, then the CFG
-        forward (B=2) and the DDIM step.  x: [1,H,W,4] f32 channels-last."""
+        forward (B=2) and the DDIM step.  x: [1,H,W,4] f32 channels-last.  `images` (save_denoising_steps): this
+        timestep's list, which receives the decoded image after the optimisation loop and after the DDIM step
+        (reference :385-386, 446-448, 476-478)."""
         L = _lib.lib()
         iteration = 0
         while iteration < self.conf.num_optsteps and t_idx < self.conf.guidance_max_step:
@@ -332,8 +334,13 @@ class GuidedStableDiffuser(GuidedDiffuser):
             if record is not None:
                 record.setdefault("opt", []).append(x.permute(0, 3, 1, 2).clone())
             iteration += 1
+        if images is not None:
+            images.append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
         eu, ec = self._cfg_eps(x, st.depth_nhwc, t, uncond, st.cond)
-        return self.ddim_step(x, eu, ec, t)
+        x = self.ddim_step(x, eu, ec, t)
+        if images is not None:
+            images.append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
+        return x
 
     # ---- batched edits: K transforms of ONE image identity in one U-Net batch (BASELINE config 3) ------
     def guided_step_batch(self, sts, x, t_idx, t, uncond):
@@ -400,11 +407,12 @@ class GuidedStableDiffuser(GuidedDiffuser):
             denoising_steps = {"opt": [], "post-opt": []} if save_denoising_steps else None
             x = _nhwc(latents.to(self.device, torch.float32))
             for t_idx, t in enumerate(timesteps):
-                x = self.guided_step(st, x, t_idx, t, uncond_embeddings[t_idx], record)
+                if save_denoising_steps:      # one list per timestep in 'opt': [after the optimisation, after the DDIM step];
+                    denoising_steps["opt"].append([])         # 'post-opt' stays empty, as in the reference
+                x = self.guided_step(st, x, t_idx, t, uncond_embeddings[t_idx], record,
+                                     denoising_steps["opt"][-1] if save_denoising_steps else None)
                 if record is not None:
                     record.setdefault("step", []).append(x.permute(0, 3, 1, 2).clone())
-                if save_denoising_steps:      # the reference appends the post-step image to 'opt' (never 'post-opt')
-                    denoising_steps["opt"].append([self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu()])
             self.last_latents = x.permute(0, 3, 1, 2)
             image = self.decode_latent_image(self.last_latents)
         return (image, denoising_steps) if save_denoising_steps else image

@@ -79,40 +79,59 @@ class StableNullInverter(NullInverter):
         return image_rec, self.ddim_loop(lat_nhwc, context, depth)
 
     @torch.no_grad()
-    def null_optimization(self, latents, context, depth, num_inner_steps, epsilon, max_timesteps=None):
+    def null_step(self, cur, uncond, cond, depth, i, target, num_inner_steps, epsilon, record=None):
+        """The inner Adam loop of timestep index i (reference stable_null_inverter.py:141-158): up to num_inner_steps x
+        {eps_u = unet(cur, uncond); loss = mse(prev_step(eps_u + w (eps_c - eps_u)), target); Adam step on uncond}, fresh
+        optimiser state, lr = 1e-2 (1 - i/100), early stop at loss < epsilon + 2e-5 i.  Updates `uncond` in place and
+        returns the number of inner steps taken.  d loss / d uncond comes from ONE explicit engine backward per inner
+        step (eps -> text embedding), seeded with the closed-form d loss / d eps_u."""
         L = _lib.lib()
+        n = cur.numel()
+        loss_dev = torch.zeros(1, dtype=torch.float32, device=cur.device)
+        d_rec = torch.empty_like(cur)
+        S = self.eps_grad_scale
+        m = torch.zeros_like(uncond)
+        v = torch.zeros_like(uncond)
+        lr = 1e-2 * (1.0 - i / 100.0)
+        t = self.scheduler.timesteps[i]
+        a_t, a_p = self.scheduler.step_alphas(t)
+        # d rec / d eps_u = (1 - w) * (sqrt(1-a_p) - sqrt(a_p) sqrt(1-a_t) / sqrt(a_t))
+        k = (1.0 - self.guidance_scale) * ((1 - a_p) ** 0.5 - (a_p ** 0.5) * ((1 - a_t) ** 0.5) / (a_t ** 0.5))
+        eps_c = self.get_noise_pred_single(cur, t, cond, depth)
+        taken = 0
+        for j in range(num_inner_steps):
+            eps_u = self.get_noise_pred_single(cur, t, uncond, depth, save=True)
+            rec = self._step(cur, eps_u, eps_c, self.guidance_scale, a_t, a_p)
+            _lib.check(L.dh_mse_fwd_bwd(_lib.ptr(rec), _lib.ptr(target), n, _lib.ptr(loss_dev), _lib.ptr(d_rec),
+                                        _lib.stream_ptr()), "dh_mse_fwd_bwd")
+            d_eps = (d_rec * (k * S)).contiguous()
+            _, d_text = self.model.unet.backward(None, d_eps, want_sample_grad=False, want_text_grad=True)
+            g = (d_text / S).contiguous()
+            _lib.check(L.dh_adam_step(_lib.ptr(uncond), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), lr, 0.9, 0.999, 1e-8,
+                                      j + 1, uncond.numel(), _lib.stream_ptr()), "dh_adam_step")
+            taken = j + 1
+            loss = loss_dev.item()                             # the reference's early stop (one sync per inner step)
+            if record is not None:
+                record.setdefault("loss", []).append(loss)
+                record.setdefault("grad", []).append(g.clone())
+            if loss < epsilon + i * 2e-5:
+                break
+        return taken
+
+    @torch.no_grad()
+    def null_optimization(self, latents, context, depth, num_inner_steps, epsilon, max_timesteps=None):
         uncond, cond = context.chunk(2)
         uncond = uncond.clone().contiguous()
         cond = cond.contiguous()
         out = []
         cur = latents[-1]
-        n = cur.numel()
-        loss_dev = torch.zeros(1, dtype=torch.float32, device=cur.device)
-        d_rec = torch.empty_like(cur)
-        S = self.eps_grad_scale
         steps = self.num_ddim_steps if max_timesteps is None else max_timesteps
+        self.inner_steps_taken = []
         for i in range(steps):
-            m = torch.zeros_like(uncond)
-            v = torch.zeros_like(uncond)
-            lr = 1e-2 * (1.0 - i / 100.0)
             target = latents[len(latents) - i - 2]
             t = self.scheduler.timesteps[i]
             a_t, a_p = self.scheduler.step_alphas(t)
-            # d rec / d eps_u = (1 - w) * (sqrt(1-a_p) - sqrt(a_p) sqrt(1-a_t) / sqrt(a_t))
-            k = (1.0 - self.guidance_scale) * ((1 - a_p) ** 0.5 - (a_p ** 0.5) * ((1 - a_t) ** 0.5) / (a_t ** 0.5))
-            eps_c = self.get_noise_pred_single(cur, t, cond, depth)
-            for j in range(num_inner_steps):
-                eps_u = self.get_noise_pred_single(cur, t, uncond, depth, save=True)
-                rec = self._step(cur, eps_u, eps_c, self.guidance_scale, a_t, a_p)
-                _lib.check(L.dh_mse_fwd_bwd(_lib.ptr(rec), _lib.ptr(target), n, _lib.ptr(loss_dev), _lib.ptr(d_rec),
-                                            _lib.stream_ptr()), "dh_mse_fwd_bwd")
-                d_eps = (d_rec * (k * S)).contiguous()
-                _, d_text = self.model.unet.backward(None, d_eps, want_sample_grad=False, want_text_grad=True)
-                g = (d_text / S).contiguous()
-                _lib.check(L.dh_adam_step(_lib.ptr(uncond), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), lr, 0.9, 0.999, 1e-8,
-                                          j + 1, uncond.numel(), _lib.stream_ptr()), "dh_adam_step")
-                if loss_dev.item() < epsilon + i * 2e-5:       # the reference's early stop (one sync per inner step)
-                    break
+            self.inner_steps_taken.append(self.null_step(cur, uncond, cond, depth, i, target, num_inner_steps, epsilon))
             out.append(uncond[:1].clone())
             eu, ec = self.model._cfg_eps(cur, depth, t, uncond, cond)
             cur = self._step(cur, eu, ec, self.guidance_scale, a_t, a_p)

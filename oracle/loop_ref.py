@@ -135,8 +135,9 @@ def _eps_single(unet, x, depth64, t, ctx):
 
 
 def null_text_inversion(unet, sched, latent0, disparity, uncond0, cond, num_inner_steps=5, eps0=1e-5,
-                        num_steps=50, null_steps=None):
-    """Returns (ddim_latents list[51], uncond [50,1,77,C])."""
+                        num_steps=50, null_steps=None, record=None):
+    """Returns (ddim_latents list[51], uncond [50,1,77,C]).  `record` (a list) receives per timestep a dict with the
+    state the inner loop started from (cur, uncond) and what it did (losses, gradient of the first inner step)."""
     sched.set_timesteps(num_steps)
     s = unet.config.sample_size
     depth64 = init_depth(disparity, (s, s))
@@ -157,15 +158,22 @@ def null_text_inversion(unet, sched, latent0, disparity, uncond0, cond, num_inne
         t = sched.timesteps[i]
         with torch.no_grad():
             e_c = _eps_single(unet, cur, depth64, t, cond)
+        if record is not None:
+            record.append(dict(cur=cur.clone(), uncond=unc.detach().clone(), target=target, loss=[], grad=[]))
         for j in range(num_inner_steps):
             e_u = _eps_single(unet, cur, depth64, t, unc)
             rec = sched.step(e_u + CFG_SCALE * (e_c - e_u), t, cur)
             loss = F.mse_loss(rec, target)
             opt.zero_grad()
             loss.backward()
+            if record is not None:
+                record[-1]["loss"].append(loss.item())
+                record[-1]["grad"].append(unc.grad.detach().clone())
             opt.step()
             if loss.item() < eps0 + i * 2e-5:
                 break
+        if record is not None:
+            record[-1]["uncond_out"] = unc.detach().clone()
         out.append(unc[:1].detach())
         with torch.no_grad():
             cur = sched.step(_eps_cfg(unet, cur, depth64, t, unc.detach(), cond), t, cur)

@@ -96,21 +96,193 @@ def test_guided_inference_matches_oracle(rig):
     assert len(rec_p["opt"]) == 38 * 3 and len(rec_p["step"]) == 50
 
 
-def test_null_inversion_matches_oracle(rig):
+def test_adam_and_mse_kernels_match_torch():
+    """dh_adam_step against torch.optim.Adam (defaults: betas (0.9, 0.999), eps 1e-8, fresh state) and dh_mse_fwd_bwd
+    against F.mse_loss + autograd: the two f32 pieces of a null-text inner step outside the U-Net."""
+    from diffusionhandles_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=dev()).manual_seed(21)
+    p0 = torch.randn(1, 77, 64, generator=g, device=dev())
+    grads = [torch.randn(1, 77, 64, generator=g, device=dev()) * (10.0 ** -k) for k in range(5)]
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=7.3e-3)
+    p = p0.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for j, gr in enumerate(grads):
+        ref.grad = gr.clone()
+        opt.step()
+        _lib.check(L.dh_adam_step(_lib.ptr(p), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v), 7.3e-3, 0.9, 0.999, 1e-8, j + 1,
+                                  p.numel(), _lib.stream_ptr()))
+        assert float((p - ref.detach()).abs().max()) < 2e-6 * 7.3e-3 / 1e-3, j          # a few f32 ulps of the lr-sized step
+    a = torch.randn(1, 64, 64, 4, generator=g, device=dev())
+    b = a + 1e-3 * torch.randn(1, 64, 64, 4, generator=g, device=dev())
+    ar = a.clone().requires_grad_(True)
+    lo = torch.nn.functional.mse_loss(ar, b)
+    gr, = torch.autograd.grad(lo, ar)
+    loss = torch.zeros(1, device=dev())
+    d = torch.empty_like(a)
+    _lib.check(L.dh_mse_fwd_bwd(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(loss), _lib.ptr(d), _lib.stream_ptr()))
+    assert abs(loss.item() - lo.item()) < 1e-6 * lo.item() + 1e-12
+    assert torch.allclose(d, gr, rtol=1e-6, atol=0)
+
+
+def _null_oracle(rig, null_steps):
     from oracle import loop_ref as L
     img = make_image(512).to(dev())
-    (_, recon), init_noise, unc = rig.inv.invert(img, rig.disp.to(dev()), rig.prompt, num_inner_steps=5, max_timesteps=2)
     lat0 = rig.gd.vae.encode(img * 2 - 1)["latent_dist"].mean * 0.18215
+    rec = []
     o_lat, o_unc = L.null_text_inversion(rig.ref, L.DDIM(), lat0, rig.disp.to(dev()), rig.unc0, rig.cond,
-                                         num_inner_steps=5, null_steps=2)
-    assert init_noise.shape == (1, 4, 64, 64) and unc.shape == (2, 1, 77, 64)
+                                         num_inner_steps=5, null_steps=null_steps, record=rec)
+    return img, o_lat, o_unc, rec
+
+
+def test_null_inversion_matches_oracle(rig):
+    """StableNullInverter.invert over ALL 50 timesteps (TINY U-Net, 5 inner steps; reference
+    stable_null_inverter.py:112-122, 135-167) against the oracle loop.
+
+    What is compared and why the tolerances differ:
+      * the DDIM-inverted noise (50 forwards): rel-L2 < 2e-2 (fp16 engine forward);
+      * teacher-forced, per timestep (the product's inner loop started from the ORACLE's state of that timestep):
+        the loss of every inner step within 0.8 % (measured 0.16 %), the gradient d loss / d uncond of the first inner
+        step rel-L2 < 1.5e-2 (measured 2.6e-3; one engine backward through the text K|V projection with a 65536x-scaled
+        1e-6-sized cotangent), the same number of inner steps unless a loss sits within 3 % of the early-stop threshold;
+      * the Adam UPDATE itself is not held to the gradient's tolerance: step 1 of Adam is lr * g / (|g| + 1e-8) = +-lr
+        per element whatever |g| is, so the elements whose gradient is below the fp16 noise floor move by +-lr with an
+        arbitrary sign (two fp32 runs show it too: the reference's loop on the reference's own U-Net class vs on the
+        oracle's U-Net, 2e-6 apart, end 4.3e-2 apart in max |uncond| after 50 timesteps, tools/make_golden.py G7b).  It
+        is compared on the elements whose oracle gradient exceeds 10 % of the gradient's RMS (there: rel-L2 < 1e-2,
+        measured 1.5e-3) and, as a whole, by what it is for: the reconstruction loss the free-running product reaches
+        at each timestep stays within 2 % + 2e-6 of the oracle's (measured 0.02 %).
+    """
+    img, o_lat, o_unc, rec = _null_oracle(rig, 50)
+    (_, recon), init_noise, unc = rig.inv.invert(img, rig.disp.to(dev()), rig.prompt, num_inner_steps=5)
+    assert init_noise.shape == (1, 4, 64, 64) and unc.shape == (50, 1, 77, 64) and recon.shape == img.shape
     e = rel(init_noise, o_lat[-1])
     print("ddim inversion rel err", e)
     assert e < 2e-2
-    d_p, d_o = unc[0] - rig.unc0, o_unc[0] - rig.unc0
-    e2 = rel(d_p, d_o)
-    print("null-text update rel err", e2, "norm", d_o.norm().item())
-    assert e2 < 0.2
+    taken_free = list(rig.inv.inner_steps_taken)
+    # ---- teacher-forced inner loops ---------------------------------------------------------------------------
+    depth_nhwc = rig.gd.init_depth(rig.disp.to(dev())).permute(0, 2, 3, 1).contiguous()
+    worst = dict(loss=0.0, grad=0.0, upd=0.0)
+    with rig.gd.on_stream():
+        for i, r in enumerate(rec):
+            cur = r["cur"].permute(0, 2, 3, 1).contiguous()
+            target = r["target"].permute(0, 2, 3, 1).contiguous()
+            u = r["uncond"].clone().contiguous()
+            prec = {}
+            n = rig.inv.null_step(cur, u, rig.cond.contiguous(), depth_nhwc, i, target, 5, 1e-5, record=prec)
+            thr = 1e-5 + i * 2e-5
+            near = any(abs(l - thr) < 3e-2 * thr for l in r["loss"])
+            if not near:
+                assert n == len(r["loss"]), (i, n, r["loss"], prec["loss"])
+            for lp, lo in zip(prec["loss"], r["loss"]):
+                worst["loss"] = max(worst["loss"], abs(lp - lo) / (lo + 5e-7))
+                assert abs(lp - lo) < 8e-3 * lo + 1e-8, (i, lp, lo)           # measured 1.6e-3
+            if i == 49:
+                # t = 0: alpha_prev = final_alpha = alpha_0 = alpha_t, so d rec / d eps = 0 analytically: the oracle's
+                # autograd gradient is rounding noise (1e-12) and Adam turns it into +-lr steps; nothing to compare
+                assert float(prec["grad"][0].abs().max()) < 1e-9
+                continue
+            ge = rel(prec["grad"][0], r["grad"][0])
+            worst["grad"] = max(worst["grad"], ge)
+            assert ge < 1.5e-2, (i, ge)                                        # measured 2.6e-3
+            if n == len(r["loss"]):
+                big = r["grad"][0].abs() > 0.1 * r["grad"][0].pow(2).mean().sqrt()
+                du_p, du_o = (u - r["uncond"])[big], (r["uncond_out"] - r["uncond"])[big]
+                ue = rel(du_p, du_o)
+                worst["upd"] = max(worst["upd"], ue)
+                assert ue < 1e-2, (i, ue)                                      # measured 1.5e-3
+    print("teacher-forced worst errors", worst)
+    # ---- free-running: the optimisation reaches the oracle's reconstruction loss at every timestep --------------
+    final_p = []
+    with rig.gd.on_stream():
+        lat = rig.inv.last_ddim_latents
+        cur = lat[-1]
+        for i in range(50):
+            t = rig.gd.scheduler.timesteps[i]
+            a_t, a_p = rig.gd.scheduler.step_alphas(t)
+            eu, ec = rig.gd._cfg_eps(cur, depth_nhwc, t, unc[i], rig.cond)
+            cur = rig.inv._step(cur, eu, ec, 7.5, a_t, a_p)
+            final_p.append(torch.nn.functional.mse_loss(cur, lat[len(lat) - i - 2]).item())
+    from oracle import loop_ref as L
+    sched = L.DDIM()
+    depth64 = L.init_depth(rig.disp.to(dev()), (64, 64))
+    cur = o_lat[-1]
+    final_o = []
+    with torch.no_grad():
+        for i in range(50):
+            t = sched.timesteps[i]
+            cur = sched.step(L._eps_cfg(rig.ref, cur, depth64, t, o_unc[i], rig.cond), t, cur)
+            final_o.append(torch.nn.functional.mse_loss(cur, o_lat[len(o_lat) - i - 2]).item())
+    ratio = max(p / (o + 2e-6) for p, o in zip(final_p, final_o))
+    print("free-running reconstruction loss: product", final_p[::10], "oracle", final_o[::10], "worst ratio", ratio,
+          "inner steps product", taken_free[::5], "oracle", [len(r["loss"]) for r in rec][::5])
+    assert all(abs(p - o) < 2e-2 * o + 2e-6 for p, o in zip(final_p, final_o))
+
+
+def test_null_text_step_full_size_matches_oracle():
+    """One null-text timestep (5 inner Adam steps) at the full SD-2-depth size against the oracle's autograd: losses,
+    the text gradient of every inner step the two share, and the reconstruction loss after the update."""
+    from diffusionhandles_amd import conf as C
+    from diffusionhandles_amd.guided_stable_diffuser import GuidedStableDiffuser
+    from diffusionhandles_amd.stable_null_inverter import StableNullInverter
+    from diffusionhandles_amd.unet import HipUNet
+    from oracle import loop_ref as L
+    from oracle import unet_torch as U
+    ref = U.init_synthetic_(U.UNetTorch(U.SD2_DEPTH), seed=0).to(dev()).eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.half().float())
+            p.requires_grad_(False)
+    hip = HipUNet(dict(U.SD2_DEPTH, text_len=77), dtype=torch.float16, max_batch=2)
+    hip.load_state_dict(ref.state_dict())
+    conf = C.load_default().guided_diffuser
+    gd = GuidedStableDiffuser(conf, unet=hip).to(dev())
+    inv = StableNullInverter(gd)
+    g = torch.Generator(device=dev()).manual_seed(31)
+    cond = torch.randn(1, 77, 1024, generator=g, device=dev())
+    unc0 = torch.randn(1, 77, 1024, generator=g, device=dev())
+    cur = torch.randn(1, 4, 64, 64, generator=g, device=dev())
+    depth64 = torch.rand(1, 1, 64, 64, generator=g, device=dev()) * 2 - 1
+    i = 3
+    sched = L.DDIM()
+    t = sched.timesteps[i]
+    # a target the loop can move towards: the CFG step with a perturbed unconditional embedding
+    with torch.no_grad():
+        tgt_unc = unc0 + 0.05 * torch.randn(1, 77, 1024, generator=g, device=dev())
+        target = sched.step(L._eps_cfg(ref, cur, depth64, t, tgt_unc, cond), t, cur)
+    # oracle inner loop (the same statements as oracle.loop_ref.null_text_inversion's inner loop)
+    unc = unc0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([unc], lr=1e-2 * (1.0 - i / 100.0))
+    with torch.no_grad():
+        e_c = L._eps_single(ref, cur, depth64, t, cond)
+    o_loss, o_grad = [], []
+    for j in range(5):
+        e_u = L._eps_single(ref, cur, depth64, t, unc)
+        rec = sched.step(e_u + L.CFG_SCALE * (e_c - e_u), t, cur)
+        loss = torch.nn.functional.mse_loss(rec, target)
+        opt.zero_grad()
+        loss.backward()
+        o_loss.append(loss.item())
+        o_grad.append(unc.grad.detach().clone())
+        opt.step()
+    prec = {}
+    u = unc0.clone().contiguous()
+    with gd.on_stream():
+        n = inv.null_step(cur.permute(0, 2, 3, 1).contiguous(), u, cond.contiguous(), depth64.permute(0, 2, 3, 1).contiguous(),
+                          i, target.permute(0, 2, 3, 1).contiguous(), 5, 0.0, record=prec)
+    assert n == 5
+    print("full-size null step: losses product", prec["loss"], "oracle", o_loss)
+    e0 = rel(prec["grad"][0], o_grad[0])
+    print("first-step text gradient rel err", e0)
+    assert abs(prec["loss"][0] - o_loss[0]) < 2e-2 * o_loss[0]       # measured 0.9 %
+    assert e0 < 6e-2                                                 # measured 3.2e-2 (the engine's full-size backward tolerance)
+    for j in range(1, 5):
+        print("inner step", j, "text gradient rel err", rel(prec["grad"][j], o_grad[j]))
+    # later inner steps start from unconds that differ by the Adam sign noise of near-zero-gradient elements (see
+    # test_null_inversion_matches_oracle): the losses follow the oracle's within 10 %
+    for lp, lo in zip(prec["loss"][1:], o_loss[1:]):
+        assert abs(lp - lo) < 0.1 * lo, (prec["loss"], o_loss)
 
 
 def test_batched_edits_match_single_edits(rig):

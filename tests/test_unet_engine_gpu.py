@@ -148,3 +148,31 @@ def test_engine_truncated_forward_matches_full():
                 with pytest.raises(RuntimeError):
                     hip.backward([None, None, d1.new_zeros(full[2].shape)], None)
         torch.cuda.synchronize()
+
+
+def test_engine_graph_cache_keys_batch16():
+    """Graph cache keys give every field its own bit range: at B = 16 (and 17) the batch bits used to alias the
+    activation-mask bits of the backward key, so alternating two masks replayed the wrong graph.  Replay on a created
+    stream must equal the eager (null-stream) result for every (batch, mask) pair, in alternation."""
+    from oracle import unet_torch as U
+    cfg = dict(U.TINY, sample_size=16)
+    _, hip = build(cfg, torch.float16, 17)
+    g = torch.Generator(device=dev()).manual_seed(7)
+    side = torch.cuda.Stream()
+    cases = []
+    for B in (16, 17, 1):
+        x = torch.randn(B, 16, 16, 5, generator=g, device=dev())
+        text = torch.randn(B, 77, cfg["cross_attention_dim"], generator=g, device=dev())
+        d = [(torch.randn((B,) + s, generator=g, device=dev()) * 1e-2).to(torch.float16) for s in hip.act_shapes]
+        for mask in ([None, d[1], None], [None, d[1], d[2]], [d[0], None, None], [None, None, d[2]]):
+            hip.forward(x, 300.0, text, save_for_backward=True)
+            eager, _ = hip.backward(mask, None)
+            cases.append((x, text, mask, eager.clone()))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for rep in range(2):
+            for x, text, mask, eager in cases:
+                hip.forward(x, 300.0, text, save_for_backward=True)
+                got, _ = hip.backward(mask, None)
+                assert torch.equal(got, eager)
+    torch.cuda.synchronize()
