@@ -8,7 +8,18 @@ guidance energy + gradient, backward-to-latent, latent update} + the CFG U-Net f
 synthetic scene, seeded random weights of the exact architecture, the per-image identity
 (original activations, null-text list, initial noise) resident in HBM before the timed region.
 N > 1: one process per GPU, each an independent edit, no collective on the data path
-(weak scaling); torch.distributed is used only for the timing barrier and the MAX reduction.
+(weak scaling); torch.distributed is used only for the timing barriers and the MAX reductions.
+
+Next to the headline the same run reports (rank 0 unless stated; none of it inside the timed region):
+  roofline        dominant kernel (k_gemm_dma) by HIP events on its stream, + committed PMC traffic
+  hbm_kernels     guidance energy and batched re-projection, achieved GB/s
+  phases          BASELINE config 2 "with and without the per-image phase": null-text inversion (50 timesteps x <= 5
+                  inner Adam steps), initial inference, one whole edit (re-projection + 38 guided + 12 unguided steps +
+                  AutoencoderKL decode), edits/s with the identity cached and including it
+  batched_edits   BASELINE config 3: K = 8 edits of one image per U-Net batch
+  edits           BASELINE config 4's unit on every rank: 8 edits per GPU as one batch, whole-job edits/s (MAX over ranks)
+  res768_bf16     BASELINE config 5: 768x768, bf16 U-Net, f32 guidance energy / cotangent / latent update
+  cpu_baseline    the oracle on the host cores: U-Net step, and per piece z-buffer / cells / energy
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,8 +34,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STEP_TFLOP = 6.99          # algorithmic TFLOP of one guided-denoise step at 512^2
-MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+STEP_TFLOP = {512: 6.99, 768: 20.0}   # algorithmic TFLOP of one guided-denoise step
+MFMA_PEAK_TFLOPS = 2500.0              # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK = 8000.0
 
 
 def parse():
@@ -33,22 +45,27 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--res", type=int, default=512, help="image resolution of the headline (512 = BASELINE config 2)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps run with the HIP-event GEMM bracket")
-    ap.add_argument("--res", type=int, default=512, help="image resolution (512 = headline; 768 = BASELINE config 5)")
-    ap.add_argument("--no-time-edit", dest="time_edit", action="store_false", help="skip the whole-edit timing")
-    ap.add_argument("--batch-edits", type=int, default=0, help="also time K edits of one image in one U-Net batch (config 3)")
+    ap.add_argument("--batch-edits", type=int, default=8, help="K edits of one image per U-Net batch (config 3 / 4); 0 = skip")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phases", dest="phases", action="store_false", help="skip inversion / initial inference / whole-edit timing")
+    ap.add_argument("--no-res768", dest="res768", action="store_false", help="skip the 768x768 bf16 record (config 5)")
+    ap.add_argument("--no-time-edit", dest="phases", action="store_false", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 def cpu_baseline():
-    """The oracle (torch fp32 CPU restatement of the same U-Net, kind 'port') timed on this host's cores on a bounded
-    sample of the step (about 10-20 s of CPU work): one cold forward, one warm forward (B=1) and one warm
-    forward + backward-to-input (B=1, gradient of the two guided activations), at the full SD-2-depth size.  A guided
-    step is 3 x (forward + backward, B=1) + one CFG forward at B=2, timed as two B=1 forwards; the energy and the
-    elementwise updates are left out (they favour the CPU figure)."""
+    """The oracle (kind 'port') timed on this host's cores on a bounded sample (about 20 s of CPU work): the torch fp32
+    restatement of the full SD-2-depth U-Net (one cold + one warm forward, one forward + backward-to-input, B=1) scaled
+    to a guided step (3 x (forward + backward) + the CFG forward at B=2 as two B=1 forwards), and per piece of the edit:
+    z-buffered re-projection, correspondences -> cells, guidance energy + gradient (NumPy / torch-CPU oracles)."""
+    from oracle import depth_ref as D
+    from oracle import guidance_ref as G
     from oracle import unet_torch as U
-    threads = min(os.cpu_count() or 1, 32)      # more threads than this oversubscribes torch's CPU kernels
+    from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
+    host = os.cpu_count() or 1
+    threads = min(host, 32)      # more threads than this oversubscribes torch's CPU kernels
     torch.set_num_threads(threads)
     unet = U.UNetTorch(U.SD2_DEPTH).eval()      # default torch init: values do not matter for timing
     for p_ in unet.parameters():
@@ -70,13 +87,36 @@ def cpu_baseline():
         out = unet(xg, torch.tensor(940), encoder_hidden_states=cond, return_dict=False)
         (out[5].float().sum() + out[6].float().sum()).backward()
         t_fb = time.time() - t0
+        acts = [out[5][0].detach(), out[6][0].detach()]
     except Exception as exc:              # noqa: BLE001 - e.g. host memory: fall back to the FLOP-scaled forward
         note = f"; forward+backward not timed ({type(exc).__name__}), step scaled from the forward by 6.99/0.804 TFLOP"
-    step_s = 3.0 * t_fb + 2.0 * t_fwd if t_fb is not None else t_fwd * STEP_TFLOP / 0.804
+        acts = [torch.randn(640, 64, 64), torch.randn(320, 64, 64)]
+    del unet
+    step_s = 3.0 * t_fb + 2.0 * t_fwd if t_fb is not None else t_fwd * STEP_TFLOP[512] / 0.804
     fb = f", forward+backward-to-input B=1 = {t_fb:.2f}s" if t_fb is not None else ""
-    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": threads, "kind": "port",
+    pieces = {}
+    try:
+        depth, bg, mask = make_scene(512)
+        ang, tr = TRANSFORMS[2]
+        t0 = time.time()
+        _, corr = D.transform_depth_pc(depth, bg, mask, rot_angle=ang, rot_axis=[0, 1, 0], translation=tr)
+        pieces["reproject_s"] = round(time.time() - t0, 3)
+        t0 = time.time()
+        cells = G.cells_from_correspondences(corr.numpy(), 512, 0)
+        pieces["cells_s"] = round(time.time() - t0, 3)
+        t0 = time.time()
+        for a in acts:             # one energy evaluation of the t%3==2 phase: act1 and act2, foreground + background, with gradient
+            cur = (a + 0.01 * torch.randn(a.shape)).requires_grad_(True)
+            e = G.foreground_energy(cur, a, cells, 1, (64, 64)) + G.background_energy(cur, a, cells, 1, (64, 64), "global_avg")
+            torch.autograd.grad(e, cur)
+        pieces["energy_fwd_bwd_s"] = round(time.time() - t0, 3)
+    except Exception as exc:              # noqa: BLE001
+        pieces["error"] = f"{type(exc).__name__}: {exc}"
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": threads, "host_cores": host, "kind": "port",
             "sample": f"oracle torch-CPU fp32 full SD2-depth U-Net: forward B=1 = {t_fwd:.2f}s warm ({times[0]:.2f}s cold){fb}; "
-                      f"step = 3 x (fwd+bwd) + CFG forward at B=2 (2 x fwd) = {step_s:.1f}s{note}"}
+                      f"step = 3 x (fwd+bwd) + CFG forward at B=2 (2 x fwd) = {step_s:.1f}s{note}",
+            "pieces": dict(pieces, what="oracle on one 512x512 edit: z-buffered re-projection (NumPy), correspondences -> cells, "
+                                        "energy + gradient of act1 and act2 (torch-CPU autograd)")}
 
 
 def main():
@@ -103,34 +143,75 @@ def main():
 
     from diffusionhandles_amd import DiffusionHandles, _lib
     from diffusionhandles_amd import conf as C
-    from diffusionhandles_amd.depth_transform import normalize_depth, transform_depth
-    from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
+    from diffusionhandles_amd.depth_transform import normalize_depth, reproject_edits, transform_depth
+    from diffusionhandles_amd.synthetic import TRANSFORMS, make_image, make_scene
+    from diffusionhandles_amd.unet import SD2_DEPTH
 
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    K = max(0, args.batch_edits)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     conf = C.load_default()
-    from diffusionhandles_amd.unet import SD2_DEPTH
     lat = args.res // 8
-    ucfg = dict(SD2_DEPTH, sample_size=lat)
-    dh = DiffusionHandles(conf, dtype=dtype, unet_config=ucfg, max_batch=max(2, 2 * args.batch_edits)).to(dev)
+    # the AutoencoderKL / CLIP architectures with random weights ("sd"): the decode on an edit's critical path is a real one
+    dh = DiffusionHandles(conf, dtype=dtype, unet_config=dict(SD2_DEPTH, sample_size=lat), max_batch=max(2, 2 * K),
+                          vae="sd").to(dev)
     gd = dh.diffuser
     depth, bg_depth, mask = (t.to(dev) for t in make_scene(args.res))
     prompt = "a sphere on a plane"
     disparity = normalize_depth(1.0 / depth)
     T = conf.guided_diffuser.num_timesteps
+    gmax = conf.guided_diffuser.guidance_max_step
+    Y = torch.tensor([0.0, 1.0, 0.0])
+
+    # ---- the per-image phase (BASELINE config 2: "50 guided steps + null inversion"), timed on rank 0 --------------------
+    phases = None
     uncond = gd._encode([""])[None].expand(T, -1, -1, -1).contiguous()
     torch.manual_seed(conf.guided_diffuser.seed)
     noise = torch.randn(1, 4, lat, lat).to(dev)
-    # per-image identity, resident in HBM before the timed region
+    # untimed warm-up of the PyTorch-ROCm VAE (MIOpen picks / compiles its convolution kernels on the first call of
+    # every shape: tens of seconds that belong to no phase) and of the engine's graphs
+    with torch.no_grad():
+        gd.decode_latent_image(torch.zeros(1, 4, lat, lat, device=dev))
+        if K > 1:
+            gd.decode_latent_image(torch.zeros(K, 4, lat, lat, device=dev))
+    if rank == 0 and args.phases:
+        img = make_image(args.res).to(dev)
+        dh.inverter.invert(img, disparity, prompt, num_inner_steps=5, max_timesteps=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        null_text, inv_noise = dh.invert_input_image(img, depth, prompt)
+        torch.cuda.synchronize()
+        phases = {"inversion_s": round(time.perf_counter() - t0, 3),
+                  "inversion_inner_steps": int(sum(dh.inverter.inner_steps_taken)),
+                  "inversion_what": "StableNullInverter.invert: VAE encode, 50 DDIM-inversion forwards, 50 timesteps x (cond forward + "
+                                    "<= 5 x (forward + backward-to-text + Adam) + CFG forward B=2)"}
+        del null_text, inv_noise
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     acts, _, _, init_noise = gd.initial_inference(noise, disparity, uncond, prompt)
+    torch.cuda.synchronize()
+    if phases is not None:
+        phases["initial_inference_s"] = round(time.perf_counter() - t0, 3)
+
+    # ---- headline: guided-denoise steps of one edit per GPU ----------------------------------------------------------------
     ang, tr = TRANSFORMS[2 + rank % 4]
-    disp_e, corr = transform_depth(depth, bg_depth, mask, gd.get_depth_intrinsics(), rot_angle=ang,
-                                   rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor(tr))
+    disp_e, corr = transform_depth(depth, bg_depth, mask, gd.get_depth_intrinsics(), rot_angle=ang, rot_axis=Y,
+                                   translation=torch.tensor(tr))
     st = gd.prepare_guidance(disp_e, prompt, acts, corr)
     gd.scheduler.set_timesteps(T)
     timesteps = gd.scheduler.timesteps
     x0 = init_noise.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous()
-    gmax = conf.guided_diffuser.guidance_max_step
-
     state = {"x": x0, "i": 0}
 
     def one_step():
@@ -139,11 +220,6 @@ def main():
             state["x"] = x0
         state["x"] = gd.guided_step(st, state["x"], t_idx, timesteps[t_idx], uncond[t_idx])
         state["i"] += 1
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     with torch.no_grad(), gd.on_stream():
         for _ in range(args.warmup):
@@ -154,13 +230,10 @@ def main():
             one_step()
         barrier()
         elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(state["x"]).all(), "latents diverged"
 
-    # roofline of the dominant kernel (k_gemm: MFMA implicit GEMM), HIP events on its stream
+    # ---- roofline of the dominant kernel (k_gemm_dma: MFMA implicit GEMM), HIP events on its stream ------------------------
     import ctypes
     L = _lib.lib()
     roof = None
@@ -180,98 +253,116 @@ def main():
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, gfx950 x2 fetch
         # correction) of the same U-Net fwd+bwd launch mix; null when the workload differs from the measured one.
         traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_traffic.json")
-        if os.path.exists(pmc) and args.res == 512 and args.dtype == "fp16":
-            with open(pmc) as fh:
-                traffic = round(json.load(fh)["traffic_bytes_per_launch"])
-        roof = {"bound": "mfma", "kernel": "k_gemm (MFMA implicit GEMM: conv3x3 + linear, fwd + input-gradient)",
+        for name in ("r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc) and args.res == 512 and args.dtype == "fp16":
+                with open(pmc) as fh:
+                    traffic = round(json.load(fh)["traffic_bytes_per_launch"])
+                break
+        step_tf = STEP_TFLOP.get(args.res)
+        roof = {"bound": "mfma", "kernel": "k_gemm_dma (MFMA implicit GEMM: conv3x3 + linear, fwd + input-gradient)",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "bytes/launch (offline PMC)", "launches_per_step": int(n.value // max(1, args.profile_steps)),
                 "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
                 "flops_per_launch": round(fl.value / max(1, n.value) / 1e9, 3),
-                "step_tflop_algorithmic": STEP_TFLOP,
-                "step_frac_of_mfma_peak": round(world * args.steps / elapsed * STEP_TFLOP / MFMA_PEAK_TFLOPS / world, 4)}
+                "step_tflop_algorithmic": step_tf,
+                "step_frac_of_mfma_peak": round(args.steps / elapsed * step_tf / MFMA_PEAK_TFLOPS, 4) if step_tf else None,
+                "step_frac_note": "algorithmic TFLOP of the reference's step (the truncated optimisation forwards execute less)"}
 
-    batch_info = None
-    if rank == 0 and args.batch_edits > 1:
-        from diffusionhandles_amd.depth_transform import reproject_edits
-        K = args.batch_edits
-        tfs = [(TRANSFORMS[i % 8][0], torch.tensor([0.0, 1.0, 0.0]), torch.tensor(TRANSFORMS[i % 8][1])) for i in range(K)]
-        edits = reproject_edits(depth, bg_depth, mask, gd.get_depth_intrinsics(), tfs)
-        sts = [gd.prepare_guidance(d, prompt, acts, c) for d, c in edits]
-        xb = x0.expand(K, -1, -1, -1).contiguous()
-        with torch.no_grad(), gd.on_stream():
-            for i in range(2):
-                gd.guided_step_batch(sts, xb, i, timesteps[i], uncond[i])
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            nb = max(3, args.steps // 4)
-            for i in range(nb):
-                xb2 = gd.guided_step_batch(sts, xb, i % gmax, timesteps[i % gmax], uncond[i % gmax])
-            torch.cuda.synchronize()
-            tb = time.perf_counter() - tb
-        batch_info = {"edits_in_batch": K, "ms_per_batched_step": round(tb / nb * 1e3, 2),
-                      "edit_steps_per_s": round(K * nb / tb, 2),
-                      "frac_of_mfma_peak": round(K * nb / tb * STEP_TFLOP / MFMA_PEAK_TFLOPS, 4)}
+    # ---- batched edits: K transforms of one image in one U-Net batch (config 3), and config 4's unit on every rank -----------
+    batch_info, edits_info = None, None
+    if K > 1:
+        tfs = [(TRANSFORMS[(i + rank) % 8][0], Y, torch.tensor(TRANSFORMS[(i + rank) % 8][1])) for i in range(K)]
+        with torch.no_grad():
+            # batched guided steps (every rank runs them: they also capture the batch-K graphs the whole-edit timing replays)
+            edits = reproject_edits(depth, bg_depth, mask, gd.get_depth_intrinsics(), tfs)
+            sts = [gd.prepare_guidance(d, prompt, acts, c) for d, c in edits]
+            xb = x0.expand(K, -1, -1, -1).contiguous()
+            with gd.on_stream():
+                for i in range(3):
+                    gd.guided_step_batch(sts, xb, i, timesteps[i], uncond[i])
+                gd.guided_step_batch(sts, xb, gmax, timesteps[gmax], uncond[gmax])       # an unguided step: CFG pass only
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                nb = max(3, args.steps // 4)
+                for i in range(nb):
+                    gd.guided_step_batch(sts, xb, i % gmax, timesteps[i % gmax], uncond[i % gmax])
+                torch.cuda.synchronize()
+                tb = time.perf_counter() - tb
+            if rank == 0:
+                batch_info = {"edits_in_batch": K, "ms_per_batched_step": round(tb / nb * 1e3, 2),
+                              "edit_steps_per_s": round(K * nb / tb, 2),
+                              "frac_of_mfma_peak": round(K * nb / tb * STEP_TFLOP[512] / MFMA_PEAK_TFLOPS, 4) if args.res == 512 else None}
+            del sts, edits
+            # K whole edits per GPU as one batch (re-projection of K transforms, 50 batched steps, K decodes), every rank
+            barrier()
+            te = time.perf_counter()
+            imgs, _ = dh.transform_foreground_batch(depth, prompt, mask, bg_depth, uncond, init_noise, acts, tfs)
+            barrier()
+            te = max_over_ranks(time.perf_counter() - te)
+            assert torch.isfinite(imgs).all()
+            edits_info = {"edits_per_gpu": K, "edits_per_s": round(world * K / te, 4), "s_per_batch": round(te, 3),
+                          "what": f"{K} edits of one image per GPU as one batch: re-projection of {K} transforms, 38 guided + 12 "
+                                  "unguided batched steps, AutoencoderKL decode (random weights); identity cached; MAX over ranks"}
+            del imgs
 
-    # ---- secondary measurements (rank 0, after the timed region).  They never gate the headline line: a failure
-    # here is reported in place of the numbers.
-    def secondary():
-        # HBM-bound pieces of the path: guidance energy fwd+bwd and the batched K=8 reprojection,
-        # timed with events on the stream they are launched on; bytes are the algorithmic figures of BASELINE.md section 3
-        hbm = None
-        if rank == 0:
-            from diffusionhandles_amd.depth_transform import reproject_edits
-            HBM_PEAK = 8000.0
-
-            def timed(fn, n=20, graph=False):
-                for _ in range(3):
-                    fn()
-                if graph:       # replay through a captured graph: device time of the launches, no host gaps between them
-                    try:
-                        torch.cuda.synchronize()
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
-                            fn()
-                        fn = g.replay
+    # ---- secondary measurements (rank 0).  They never gate the headline line: a failure is reported in place of the numbers.
+    def hbm_records(gd_, st_, depth_, bg_, mask_, res):
+        def timed(fn, n=20, graph=False):
+            for _ in range(3):
+                fn()
+            if graph:       # replay through a captured graph: device time of the launches, no host gaps between them
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
                         fn()
-                    except Exception:
-                        pass
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(n):
+                    fn = g.replay
                     fn()
-                e1.record()
-                e1.synchronize()
-                return e0.elapsed_time(e1) / n * 1e-3
+                except Exception:
+                    pass
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / n * 1e-3
 
-            with torch.no_grad(), gd.on_stream():
-                hbm = []
-                cur = [o[1] for o in st.orig]                    # another timestep's activations stand in for "current"
-                for layers, tag in (((2,), "t%3==0: act2"), ((1,), "t%3==1: act1"), ((1, 2), "t%3==2: act1+act2")):
-                    fgw, bgw = st.schedule(2 if len(layers) == 2 else (0 if layers == (2,) else 1), 0)
-                    def run():
-                        for k in layers:
-                            gd._energy_grad(st, k, cur[k], 0, fgw[k], bgw[k])
-                    sec = timed(run, graph=True)
-                    nbytes = sum(3 * cur[k].numel() * cur[k].element_size() for k in layers)
-                    hbm.append({"kernel": f"guidance energy fwd+bwd ({tag})", "bound": "hbm", "bytes": nbytes,
-                                "us": round(sec * 1e6, 2), "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK,
-                                "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK, 4)})
-                K = 8
-                tfs8 = [(TRANSFORMS[i % 8][0], torch.tensor([0.0, 1.0, 0.0]), torch.tensor(TRANSFORMS[i % 8][1])) for i in range(K)]
-                sec = timed(lambda: reproject_edits(depth, bg_depth, mask, gd.get_depth_intrinsics(), tfs8), n=5)
-                per_edit = 9e6 * (args.res / 512.0) ** 2
-                hbm.append({"kernel": "batched K=8 unproject -> SE(3) -> z-buffer -> index maps (whole reproject_edits call, "
-                                      "host glue included)", "bound": "hbm", "bytes": int(K * per_edit),
-                            "us": round(sec * 1e6, 1), "achieved": round(K * per_edit / sec / 1e9, 2), "peak": HBM_PEAK,
-                            "unit": "GB/s", "frac": round(K * per_edit / sec / 1e9 / HBM_PEAK, 5)})
+        out = []
+        with torch.no_grad(), gd_.on_stream():
+            cur = [o[1] for o in st_.orig]                    # another timestep's activations stand in for "current"
+            for layers, tag in (((2,), "t%3==0: act2"), ((1,), "t%3==1: act1"), ((1, 2), "t%3==2: act1+act2")):
+                fgw, bgw = st_.schedule(2 if len(layers) == 2 else (0 if layers == (2,) else 1), 0)
 
-        # one whole edit (the other half of BASELINE.json's metric): transform_foreground = re-projection + 38 guided +
-        # 12 unguided steps + decode, with the per-image identity (inversion, original activations) already cached
-        edit_info = None
-        if rank == 0 and args.time_edit:
-            rot = dict(rot_angle=ang, rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor(tr))
+                def run():
+                    for k in layers:
+                        gd_._energy_grad(st_, k, cur[k], 0, fgw[k], bgw[k])
+                sec = timed(run, graph=True)
+                nbytes = sum(3 * cur[k].numel() * cur[k].element_size() for k in layers)
+                out.append({"kernel": f"guidance energy fwd+bwd ({tag}) at {res}x{res}", "bound": "hbm", "bytes": nbytes,
+                            "us": round(sec * 1e6, 2), "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK,
+                            "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK, 4)})
+            tfs8 = [(TRANSFORMS[i % 8][0], Y, torch.tensor(TRANSFORMS[i % 8][1])) for i in range(8)]
+            sec = timed(lambda: reproject_edits(depth_, bg_, mask_, gd_.get_depth_intrinsics(), tfs8), n=5)
+            per_edit = 9e6 * (res / 512.0) ** 2
+            out.append({"kernel": f"batched K=8 unproject -> SE(3) -> z-buffer -> index maps at {res}x{res} (whole reproject_edits "
+                                  "call, host glue included)", "bound": "hbm", "bytes": int(8 * per_edit),
+                        "us": round(sec * 1e6, 1), "achieved": round(8 * per_edit / sec / 1e9, 2), "peak": HBM_PEAK,
+                        "unit": "GB/s", "frac": round(8 * per_edit / sec / 1e9 / HBM_PEAK, 5)})
+        return out
+
+    hbm = None
+    if rank == 0:
+        try:
+            hbm = hbm_records(gd, st, depth, bg_depth, mask, args.res)
+        except Exception as exc:          # noqa: BLE001
+            hbm = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # one whole edit: transform_foreground = re-projection + 38 guided + 12 unguided steps + AutoencoderKL decode
+    if rank == 0 and phases is not None:
+        try:
+            rot = dict(rot_angle=ang, rot_axis=Y, translation=torch.tensor(tr))
             with torch.no_grad():
                 dh.transform_foreground(depth, prompt, mask, bg_depth, uncond, init_noise, acts, **rot)
                 torch.cuda.synchronize()
@@ -279,18 +370,31 @@ def main():
                 dh.transform_foreground(depth, prompt, mask, bg_depth, uncond, init_noise, acts, **rot)
                 torch.cuda.synchronize()
                 te = time.perf_counter() - te
-            edit_info = {"edits_per_s": round(1.0 / te, 4), "s_per_edit": round(te, 3),
-                         "what": "transform_foreground: z-buffer + index maps + 38 guided + 12 unguided steps + decode "
-                                 "(synthetic VAE stand-in), identity cached"}
+                lat_img = torch.randn(1, 4, lat, lat, device=dev)
+                gd.decode_latent_image(lat_img)
+                torch.cuda.synchronize()
+                td = time.perf_counter()
+                gd.decode_latent_image(lat_img)
+                torch.cuda.synchronize()
+                td = time.perf_counter() - td
+            per_image = phases["inversion_s"] + phases["initial_inference_s"]
+            phases.update({"edit_s": round(te, 3), "vae_decode_s": round(td, 4),
+                           "edits_per_s_identity_cached": round(1.0 / te, 4),
+                           "edits_per_s_with_inversion_and_initial_inference": round(1.0 / (te + per_image), 4),
+                           "edit_what": "transform_foreground: z-buffer + index maps + 38 guided + 12 unguided steps + AutoencoderKL "
+                                        "decode (the SD VAE architecture in PyTorch-ROCm fp32, random weights)"})
+        except Exception as exc:          # noqa: BLE001
+            phases["error"] = f"{type(exc).__name__}: {exc}"
 
-        return hbm, edit_info
-
-    hbm, edit_info = None, None
-    if rank == 0:
+    # ---- BASELINE config 5: 768x768, bf16 U-Net + f32 guidance (energy, cotangent seed, latent gradient and update in f32) ----
+    res768 = None
+    if rank == 0 and args.res768 and args.res == 512:
         try:
-            hbm, edit_info = secondary()
-        except Exception as exc:          # noqa: BLE001 - report, do not lose the headline measurement
-            hbm = {"error": f"{type(exc).__name__}: {exc}"}
+            del dh, gd, st, acts
+            torch.cuda.empty_cache()
+            res768 = bench_768(conf, dev, prompt, TRANSFORMS, Y, max(5, args.steps // 2))
+        except Exception as exc:          # noqa: BLE001
+            res768 = {"error": f"{type(exc).__name__}: {exc}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.res == 512:
@@ -306,15 +410,74 @@ def main():
             "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
-            "config": {"workload": f"single {args.res}x{args.res} edit per GPU, SD2-depth (865.7M params, seeded random weights), guided "
+            "config": {"workload": f"single {args.res}x{args.res} edit per GPU, SD2-depth (865.9M params, seeded random weights), guided "
                                    "phase: 3 x (fwd + energy + bwd-to-latent) + CFG fwd (B=2) + DDIM step",
                        "resolution": args.res, "edits_per_gpu": 1, "correspondences": int(corr.shape[0]),
                        "parallelism": "independent edits, one process per GPU, no collectives"},
-            "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu, "batched_edits": batch_info, "whole_edit": edit_info,
+            "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu, "phases": phases, "batched_edits": batch_info,
+            "edits": edits_info, "res768_bf16": res768,
         }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_768(conf, dev, prompt, TRANSFORMS, Y, steps):
+    """Guided-denoise steps/s of one 768x768 edit with the bf16 engine (96x96 latents), identity from initial_inference."""
+    from diffusionhandles_amd import DiffusionHandles
+    from diffusionhandles_amd.depth_transform import normalize_depth, transform_depth
+    from diffusionhandles_amd.synthetic import make_scene
+    from diffusionhandles_amd.unet import SD2_DEPTH
+    res, lat = 768, 96
+    dh = DiffusionHandles(conf, dtype=torch.bfloat16, unet_config=dict(SD2_DEPTH, sample_size=lat), max_batch=2).to(dev)
+    gd = dh.diffuser
+    depth, bg_depth, mask = (t.to(dev) for t in make_scene(res))
+    T, gmax = conf.guided_diffuser.num_timesteps, conf.guided_diffuser.guidance_max_step
+    uncond = gd._encode([""])[None].expand(T, -1, -1, -1).contiguous()
+    torch.manual_seed(conf.guided_diffuser.seed)
+    noise = torch.randn(1, 4, lat, lat).to(dev)
+    acts, _, _, init_noise = gd.initial_inference(noise, normalize_depth(1.0 / depth), uncond, prompt)
+    ang, tr = TRANSFORMS[2]
+    disp_e, corr = transform_depth(depth, bg_depth, mask, gd.get_depth_intrinsics(), rot_angle=ang, rot_axis=Y,
+                                   translation=torch.tensor(tr))
+    st = gd.prepare_guidance(disp_e, prompt, acts, corr)
+    gd.scheduler.set_timesteps(T)
+    ts = gd.scheduler.timesteps
+    x0 = init_noise.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous()
+    x = x0
+    with torch.no_grad(), gd.on_stream():
+        for i in range(3):
+            x = gd.guided_step(st, x, i, ts[i], uncond[i])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            t_idx = i % gmax
+            x = gd.guided_step(st, x0 if t_idx == 0 else x, t_idx, ts[t_idx], uncond[t_idx])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert torch.isfinite(x).all()
+        # the HBM-bound warp / energy at high resolution: achieved GB/s of one energy evaluation (act1 + act2, bf16)
+        cur = [o[1] for o in st.orig]
+        fgw, bgw = st.schedule(2, 0)
+        for _ in range(3):
+            for k in (1, 2):
+                gd._energy_grad(st, k, cur[k], 0, fgw[k], bgw[k])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            for k in (1, 2):
+                gd._energy_grad(st, k, cur[k], 0, fgw[k], bgw[k])
+        e1.record()
+        e1.synchronize()
+        sec = e0.elapsed_time(e1) / 20 * 1e-3
+    nbytes = sum(3 * cur[k].numel() * cur[k].element_size() for k in (1, 2))
+    return {"metric": "guided-denoise steps/sec at 768x768 (SD2-depth)", "value": round(steps / el, 3), "unit": "steps/s",
+            "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "dtype": "bf16",
+            "guidance": "energy, cotangent seed, latent gradient and latent update in f32; bf16 storage between the U-Net kernels, f32 accumulation",
+            "correspondences": int(corr.shape[0]),
+            "frac_of_mfma_peak": round(steps / el * STEP_TFLOP[768] / MFMA_PEAK_TFLOPS, 4),
+            "energy_hbm": {"bytes": nbytes, "us": round(sec * 1e6, 1), "achieved": round(nbytes / sec / 1e9, 1), "unit": "GB/s",
+                           "frac": round(nbytes / sec / 1e9 / HBM_PEAK, 4), "what": "energy + gradient of act1 and act2 at 96x96 cells (eager launches)"}}
 
 
 if __name__ == "__main__":

@@ -279,8 +279,9 @@ class GuidedStableDiffuser(GuidedDiffuser):
         activations = [a.permute(0, 3, 1, 2) for a in store]      # [T,C,h,w] views of channels-last storage
         return activations, x.permute(0, 3, 1, 2), uncond_embeddings, init_latents
 
-    def prepare_guidance(self, depth, prompt, activations_orig, correspondences, fg_weight=None, bg_weight=None):
-        """Everything of guided_inference that is constant over the denoising loop."""
+    def prepare_guidance(self, depth, prompt, activations_orig, correspondences, fg_weight=None, bg_weight=None, orig=None):
+        """Everything of guided_inference that is constant over the denoising loop.  `orig`: the channels-last copies of
+        the original activations of another guidance state of the SAME image (K edits of one image share them)."""
         from types import SimpleNamespace
         fg_weight = self.conf.fg_weight if fg_weight is None else fg_weight
         bg_weight = self.conf.bg_weight if bg_weight is None else bg_weight
@@ -291,7 +292,8 @@ class GuidedStableDiffuser(GuidedDiffuser):
         st.schedule = build_weight_schedule(fg_weight, bg_weight, self.conf.guidance_max_step,
                                             self.conf.guidance_schedule_type)
         # original activations as channels-last engine-dtype storage [T,h,w,C]
-        st.orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
+        st.orig = orig if orig is not None else \
+            [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
         st.size = (st.orig[2].shape[1], st.orig[2].shape[2])
         st.n_pairs = len(st.pc["original_x"])
         # default configuration: the energy runs through a per-edit plan (CSR + background flags built once)
@@ -389,8 +391,10 @@ class GuidedStableDiffuser(GuidedDiffuser):
             torch.manual_seed(self.conf.seed)
             self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
             timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
-            sts = [self.prepare_guidance(d, prompt, activations_orig, c, fg_weight, bg_weight)
-                   for d, c in zip(depths, correspondences_list)]
+            sts = []
+            for d, c in zip(depths, correspondences_list):
+                sts.append(self.prepare_guidance(d, prompt, activations_orig, c, fg_weight, bg_weight,
+                                                 orig=sts[0].orig if sts else None))
             x = _nhwc(latents.to(self.device, torch.float32)).expand(K, -1, -1, -1).contiguous()
             for t_idx, t in enumerate(timesteps):
                 x = self.guided_step_batch(sts, x, t_idx, t, uncond_embeddings[t_idx])

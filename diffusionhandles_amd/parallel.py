@@ -37,15 +37,55 @@ def gather_results(local_results, group=None):
     return out
 
 
-def run_edits(dh, image_identity, edits, depth, fg_mask, bg_depth, prompt):
-    """This rank's share of `edits` (list of dicts with rot_angle / rot_axis / translation) on one image
-    identity (null_text_emb, init_noise, activations); returns [(global_index, image, disparity)]."""
+def broadcast_identity(identity, src=0, device=None, group=None):
+    """One-shot hand-over of a per-image identity (null_text_emb, init_noise, activations[3]) from rank `src` to every
+    rank, so that only one rank pays inversion + initial inference when an image's edits are spread over GPUs (SURVEY
+    section 8e: 0.53 GB fp16 + 15.8 MB + 64 KB per image).  Off the per-edit path: one broadcast per tensor (RCCL on the
+    GPU, gloo on CPU tensors); ranks other than `src` pass identity=None.  Without a process group it is the identity."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return identity
+    rank = dist.get_rank(group)
+    meta = [None]
+    if rank == src:
+        null_text, noise, acts = identity
+        tensors = [null_text, noise] + list(acts)
+        meta[0] = [(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in tensors]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    out = []
+    for i, (shape, dt) in enumerate(meta[0]):
+        if rank == src:
+            t = tensors[i].contiguous()          # activations are channels-last views: the layout ranks agree on is [T,C,h,w] contiguous
+            if device is not None:
+                t = t.to(device)
+        else:
+            t = torch.empty(shape, dtype=getattr(torch, dt), device=device)
+        dist.broadcast(t, src=src, group=group)
+        out.append(t)
+    return out[0], out[1], out[2:]
+
+
+def run_edits(dh, image_identity, edits, depth, fg_mask, bg_depth, prompt, batch=8):
+    """This rank's share of `edits` (list of dicts with rot_angle / rot_axis / translation) on one image identity
+    (null_text_emb, init_noise, activations), executed `batch` edits at a time as ONE batched pass
+    (DiffusionHandles.transform_foreground_batch; BASELINE config 4: 64 edits, 8 per GPU).  batch <= 1 runs them one by
+    one through transform_foreground.  Returns [(global_index, image [3,H,W] cpu, disparity [1,1,H,W] cpu)]; no
+    collective is involved."""
     rank, world = rank_world()
     null_text, noise, acts = image_identity
+    mine = shard_edits(list(enumerate(edits)), rank, world)
     out = []
-    for gi, e in shard_edits(list(enumerate(edits)), rank, world):
-        img, disp = dh.transform_foreground(depth, prompt, fg_mask, bg_depth, null_text, noise, acts,
-                                            rot_angle=e.get("rot_angle"), rot_axis=e.get("rot_axis"),
-                                            translation=e.get("translation"))
-        out.append((gi, img.cpu(), disp.cpu()))
+    if batch <= 1:
+        for gi, e in mine:
+            img, disp = dh.transform_foreground(depth, prompt, fg_mask, bg_depth, null_text, noise, acts,
+                                                rot_angle=e.get("rot_angle"), rot_axis=e.get("rot_axis"),
+                                                translation=e.get("translation"))
+            out.append((gi, img[0].cpu(), disp.cpu()))
+        return out
+    for b0 in range(0, len(mine), batch):
+        chunk = mine[b0:b0 + batch]
+        tfs = [(e.get("rot_angle"), e.get("rot_axis"), e.get("translation")) for _, e in chunk]
+        imgs, disps = dh.transform_foreground_batch(depth, prompt, fg_mask, bg_depth, null_text, noise, acts, tfs)
+        for k, (gi, _) in enumerate(chunk):
+            out.append((gi, imgs[k].cpu(), disps[k].cpu()))
     return out

@@ -99,8 +99,11 @@ def guided_inference(unet, sched, latents, disparity, uncond_list, cond, acts_or
     bg_weight = conf.bg_weight if bg_weight is None else bg_weight
     torch.manual_seed(conf.seed)
     sched.set_timesteps(conf.num_timesteps)
-    cells = G.cells_from_correspondences(corr, disparity.shape[-1], conf.bg_erosion)
     s = unet.config.sample_size
+    # the reference hard-codes a 64 x 64 cell grid (guided_stable_diffuser.py:526-535: img_res // 64, masks of (64, 64)), which
+    # is its U-Net's latent size: it supports 512 x 512 only.  The grid here is the latent size, identical at 512 x 512 and
+    # the consistent choice elsewhere (768 x 768: 96 x 96 cells of 8 px, the resolution of the guided activations).
+    cells = G.cells_from_correspondences(corr, disparity.shape[-1], conf.bg_erosion, grid=s)
     depth64 = init_depth(disparity, (s, s))
     x = latents
     for i, t in enumerate(sched.timesteps):

@@ -52,3 +52,71 @@ def test_shard_edits_single_process():
     items = list(range(10))
     parts = [parallel.shard_edits(items, r, 4) for r in range(4)]
     assert sorted(sum(parts, [])) == items and parts[1] == [1, 5, 9]
+
+
+class _FakeHandles:
+    """Stands in for DiffusionHandles in the CPU test of the sharded driver: an 'edit' is a deterministic function of its
+    transform and of the identity, so a wrong shard, a wrong order or a stale identity shows in the gathered results."""
+
+    def __init__(self):
+        self.batches = []
+
+    def transform_foreground_batch(self, depth, prompt, fg_mask, bg_depth, null_text, noise, acts, transforms):
+        self.batches.append(len(transforms))
+        k = float(null_text.sum() + noise.sum() + sum(a.float().sum() for a in acts))
+        imgs = torch.stack([torch.full((3, 4, 4), float(a) + float(t.sum()) + k) for a, _, t in transforms])
+        return imgs, [torch.full((1, 1, 4, 4), float(a)) for a, _, _ in transforms]
+
+    def transform_foreground(self, depth, prompt, fg_mask, bg_depth, null_text, noise, acts, rot_angle=None, rot_axis=None,
+                             translation=None):
+        imgs, disps = self.transform_foreground_batch(depth, prompt, fg_mask, bg_depth, null_text, noise, acts,
+                                                      [(rot_angle, rot_axis, translation)])
+        return imgs[:1], disps[0]
+
+
+def _driver_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from diffusionhandles_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the identity exists on rank 0 only and is handed over once
+    identity = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(3)
+        acts = [torch.randn(5, 8, 2, 2, generator=g).half().permute(0, 2, 3, 1).permute(0, 3, 1, 2) for _ in range(3)]   # channels-last views
+        identity = (torch.randn(5, 1, 7, 4, generator=g), torch.randn(1, 4, 2, 2, generator=g), acts)
+    identity = parallel.broadcast_identity(identity, src=0)
+    assert identity[2][0].dtype == torch.float16 and identity[2][0].shape == (5, 8, 2, 2) and identity[2][0].is_contiguous()
+    edits = [dict(rot_angle=float(i), rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor([0.1 * i, 0.0, 0.0]))
+             for i in range(21)]
+    fake = _FakeHandles()
+    local = parallel.run_edits(fake, identity, edits, None, None, None, "p", batch=8)
+    single = parallel.run_edits(_FakeHandles(), identity, edits[:3], None, None, None, "p", batch=1)
+    allr = parallel.gather_results([(gi, float(im[0, 0, 0]), float(dp[0, 0, 0, 0])) for gi, im, dp in local])
+    k = float(identity[0].sum() + identity[1].sum() + sum(a.float().sum() for a in identity[2]))
+    q.put((rank, fake.batches, allr, k, [gi for gi, _, _ in single]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_driver_batches_and_identity():
+    """parallel.run_edits + broadcast_identity + gather_results over gloo, world 2: 21 edits -> rank 0 runs 11 (batches of
+    8 + 3), rank 1 runs 10 (8 + 2); every edit once, serial order restored, both ranks hold the same identity."""
+    world, port = 2, 29643
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [8, 3] and res[1][1] == [8, 2]
+    assert res[0][3] == res[1][3]                                     # same identity on both ranks
+    k = res[0][3]
+    for _, _, allr, _, single in res:
+        assert [gi for gi, _, _ in allr] == list(range(21))
+        for gi, v, d in allr:
+            assert abs(v - (gi + 0.1 * gi + k)) < 1e-3 and d == float(gi)
+    assert res[0][4] == [0, 2] and res[1][4] == [1]
