@@ -12,7 +12,11 @@ namespace dh {
 // 8 = copies / concat / split / pool
 #ifdef DH_TUNING
 static int ablate_mask() { static const int m = getenv("DH_ABLATE_SKIP") ? atoi(getenv("DH_ABLATE_SKIP")) : 0; return m; }
-#define DH_ABLATE(bit) do { if (ablate_mask() & (bit)) return; } while (0)
+// DH_ABLATE_EMPTY=1: the skipped launch is replaced by an EMPTY kernel (one wave, no memory access): what a kernel
+// boundary alone costs in situ
+__global__ void k_noop() {}
+static int ablate_empty() { static const int m = getenv("DH_ABLATE_EMPTY") ? atoi(getenv("DH_ABLATE_EMPTY")) : 0; return m; }
+#define DH_ABLATE(bit) do { if (ablate_mask() & (bit)) { if (ablate_empty()) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st); return; } } while (0)
 #else
 #define DH_ABLATE(bit) do { } while (0)
 #endif
