@@ -6,10 +6,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-timeout 600 python bench.py --batch-edits 8 2>/dev/null | tail -1 > $O/bench_n1.json
-timeout 600 python bench.py --res 768 --dtype bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_768_bf16.json
+timeout 900 python bench.py 2>/dev/null | tail -1 > $O/bench_n1.json
 cd /tmp; export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --no-time-edit --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_under_rocprof.json
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --no-phases --no-res768 --no-cpu-baseline --batch-edits 0 2>/dev/null | tail -1 > $O/bench_under_rocprof.json
 cd $R
 T=$(ls /tmp/prof_bench/*/*kernel_trace.csv | head -1)
 S=$(ls /tmp/prof_bench/*/*kernel_stats.csv | head -1)
