@@ -105,7 +105,8 @@ def test_conv3_forward_and_input_gradient(dtype, B, Cin, Cout, H, stride, up):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,HW,C,silu", [(1, 4096, 320, 1), (2, 1024, 960, 1), (1, 64, 2560, 1), (2, 256, 1280, 0), (1, 4096, 64, 1)])
+@pytest.mark.parametrize("B,HW,C,silu", [(1, 4096, 320, 1), (2, 1024, 960, 1), (1, 64, 2560, 1), (2, 256, 1280, 0), (1, 4096, 64, 1),
+                                          (1, 4096, 640, 1), (1, 9216, 320, 0), (3, 576, 1920, 1)])
 def test_groupnorm(dtype, B, HW, C, silu):
     g = torch.Generator(device=dev()).manual_seed(C + HW)
     x = (torch.randn(B, HW, C, generator=g, device=dev()) * 2 + 0.5).to(dtype)
