@@ -163,9 +163,10 @@ def main():
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     conf = C.load_default()
     lat = args.res // 8
-    # the AutoencoderKL / CLIP architectures with random weights ("sd"): the decode on an edit's critical path is a real one
+    # the SD AutoencoderKL architecture with random weights, its decoder on the engine's kernels ("sd-native"): the decode on
+    # an edit's critical path is a real one (the encoder, once per image, stays PyTorch-ROCm)
     dh = DiffusionHandles(conf, dtype=dtype, unet_config=dict(SD2_DEPTH, sample_size=lat), max_batch=max(2, 2 * K),
-                          vae="sd").to(dev)
+                          vae="sd-native").to(dev)
     gd = dh.diffuser
     depth, bg_depth, mask = (t.to(dev) for t in make_scene(args.res))
     prompt = "a sphere on a plane"
@@ -179,8 +180,8 @@ def main():
     uncond = gd._encode([""])[None].expand(T, -1, -1, -1).contiguous()
     torch.manual_seed(conf.guided_diffuser.seed)
     noise = torch.randn(1, 4, lat, lat).to(dev)
-    # untimed warm-up of the PyTorch-ROCm VAE (MIOpen picks / compiles its convolution kernels on the first call of
-    # every shape: tens of seconds that belong to no phase) and of the engine's graphs
+    # untimed warm-up of the decoder and of the engine's graphs (the PyTorch-ROCm encoder's first call lets MIOpen pick /
+    # compile its convolution kernels: seconds that belong to no phase; it runs inside the inversion warm-up below)
     with torch.no_grad():
         gd.decode_latent_image(torch.zeros(1, 4, lat, lat, device=dev))
         if K > 1:
@@ -303,7 +304,7 @@ def main():
             assert torch.isfinite(imgs).all()
             edits_info = {"edits_per_gpu": K, "edits_per_s": round(world * K / te, 4), "s_per_batch": round(te, 3),
                           "what": f"{K} edits of one image per GPU as one batch: re-projection of {K} transforms, 38 guided + 12 "
-                                  "unguided batched steps, AutoencoderKL decode (random weights); identity cached; MAX over ranks"}
+                                  "unguided batched steps, AutoencoderKL decode (native decoder, random weights); identity cached; MAX over ranks"}
             del imgs
 
     # ---- secondary measurements (rank 0).  They never gate the headline line: a failure is reported in place of the numbers.
@@ -382,7 +383,7 @@ def main():
                            "edits_per_s_identity_cached": round(1.0 / te, 4),
                            "edits_per_s_with_inversion_and_initial_inference": round(1.0 / (te + per_image), 4),
                            "edit_what": "transform_foreground: z-buffer + index maps + 38 guided + 12 unguided steps + AutoencoderKL "
-                                        "decode (the SD VAE architecture in PyTorch-ROCm fp32, random weights)"})
+                                        "decode (the SD VAE decoder on the engine's kernels, csrc/vae_engine.cpp, random weights)"})
         except Exception as exc:          # noqa: BLE001
             phases["error"] = f"{type(exc).__name__}: {exc}"
 

@@ -27,6 +27,11 @@ class UNetConfig(ctypes.Structure):
                 ("text_len", c_i), ("max_batch", c_i), ("dtype", c_i)]
 
 
+class VAEConfig(ctypes.Structure):
+    _fields_ = [("latent_channels", c_i), ("out_channels", c_i), ("block_out_channels", c_i * 4),
+                ("layers_per_block", c_i), ("norm_groups", c_i), ("latent_size", c_i), ("dtype", c_i)]
+
+
 # name -> (restype, argtypes); mirrors include/diffhandles_hip.h one to one
 SIGNATURES = {
     "dh_last_error": (ctypes.c_char_p, []),
@@ -64,6 +69,14 @@ SIGNATURES = {
     "dh_unet_forward": (c_i, [c_p, c_p, c_f, c_p, c_i, c_i, c_p, ctypes.POINTER(c_p), c_p]),
     "dh_unet_backward": (c_i, [c_p, ctypes.POINTER(c_p), c_p, c_p, c_p, c_p]),
     "dh_unet_stats": (c_i, [c_p, ctypes.POINTER(c_d), ctypes.POINTER(c_d), ctypes.POINTER(ctypes.c_int64)]),
+    "dh_vae_decoder_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
+    "dh_vae_decoder_destroy": (None, [c_p]),
+    "dh_vae_decoder_num_params": (c_i, [c_p]),
+    "dh_vae_decoder_param_info": (c_i, [c_p, c_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i),
+                                        ctypes.POINTER(ctypes.c_int64)]),
+    "dh_vae_decoder_load_param": (c_i, [c_p, c_i, c_p, c_p]),
+    "dh_vae_decoder_bytes": (c_sz, [c_p]),
+    "dh_vae_decoder_decode": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "dh_gemm_profile_begin": (c_i, []),
     "dh_gemm_profile_end": (c_i, [ctypes.POINTER(c_d), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(c_d)]),
     "dh_ddim_cfg_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_p]),

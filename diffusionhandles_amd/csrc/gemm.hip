@@ -792,7 +792,9 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   DH_KNOB(kKg2MinKt, "DH_KG2_MINKT", 4);            // K tiles per split from which the 128x64 tile splits K over two wave groups (16 -> 4: +1.4 % step)
   DH_KNOB(kManyBlocks, "DH_GEMM_MANY", 512);        // 128x128 grids from this size use two stages (two workgroups per CU)
   DH_KNOB(kMw128, "DH_GEMM_MW128", 1);              // min K tiles for eight waves on the 128x128 tile
+#ifdef DH_TUNING
   DH_KNOB(kWnt, "DH_W_NT", 0);                      // non-temporal weight DMA for GEMMs of at most this many row tiles (0 = never)
+#endif
   const bool lnf = k.ln_s != nullptr;
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
   const int ktiles = k.K / BK;

@@ -453,13 +453,13 @@ int build(dh_unet& u) {
 // 64x64-tile layout the GEMM streams (wt_index); otherwise plain row-major (the two tiny f32 convolutions).
 template <class D, bool TILED>
 __global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, long fwd_K, long row_off, D* bwd,
-                              long bwd_K, long col_off, int Nb) {
+                              long bwd_K, long col_off, int Nb, float scale = 1.f) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * C * taps) return;
   const int tap = (int)(idx % taps);
   const int cc = (int)((idx / taps) % C);
   const int nn = (int)(idx / ((size_t)taps * C));
-  const D v = from_f32<D>(src[idx]);
+  const D v = from_f32<D>(src[idx] * scale);
   const int fr = (int)row_off + nn, fk = tap * C + cc;
   const int bk = (taps - 1 - tap) * Nb + (int)col_off + nn;
   if (TILED) {
@@ -470,6 +470,25 @@ __global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, 
     if (bwd) bwd[(size_t)cc * bwd_K + bk] = v;
   }
 }
+
+}  // namespace
+namespace dh {
+// torch-layout f32 parameter -> engine weight storage (shared with the VAE decoder engine): rows [row_off, row_off + N) of
+// the forward matrix [.][taps * C] (and optionally the transposed / tap-flipped input-gradient matrix), tiled 16-bit when
+// dtype is DH_DTYPE_F16 / BF16, plain row-major f32 when dtype is DH_DTYPE_F32
+void launch_load_weight(int dtype, const float* src, int N, int C, int taps, void* fwd, long fwd_K, long row_off, void* bwd,
+                        long bwd_K, long col_off, int Nb, float scale, hipStream_t st) {
+  const size_t total = (size_t)N * C * taps;
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (dtype == DH_DTYPE_F32)
+    hipLaunchKernelGGL((k_load_weight<float, false>), dim3(nb), dim3(256), 0, st, src, N, C, taps, (float*)fwd, fwd_K, row_off, (float*)bwd, bwd_K, col_off, Nb, scale);
+  else if (dtype == DH_DTYPE_F16)
+    hipLaunchKernelGGL((k_load_weight<f16, true>), dim3(nb), dim3(256), 0, st, src, N, C, taps, (f16*)fwd, fwd_K, row_off, (f16*)bwd, bwd_K, col_off, Nb, scale);
+  else
+    hipLaunchKernelGGL((k_load_weight<bf16, true>), dim3(nb), dim3(256), 0, st, src, N, C, taps, (bf16*)fwd, fwd_K, row_off, (bf16*)bwd, bwd_K, col_off, Nb, scale);
+}
+}  // namespace dh
+namespace {
 
 // LayerNorm fold (one workgroup per output column n of a dense weight [N][K]): reads the unfolded 16-bit W[n][k] from the
 // input-gradient copy (rows k, columns n: it is never folded), writes W'[n][k] = round16(W[n][k] * gamma[k]) into the

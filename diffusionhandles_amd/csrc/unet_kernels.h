@@ -49,6 +49,10 @@ __host__ __device__ inline size_t wt_index(int n, int k, int K) {
   return ((size_t)(n >> 6) * (K >> 6) + (k >> 6)) * 4096 + (size_t)r * 64 + (size_t)((c ^ ((r >> 1) & 7)) << 3) + (k & 7);
 }
 
+// torch-layout f32 parameter [N][C][taps] -> weight storage (unet_engine.cpp): tiled 16-bit (dtype F16 / BF16) or plain f32
+void launch_load_weight(int dtype, const float* src, int N, int C, int taps, void* fwd, long fwd_K, long row_off, void* bwd,
+                        long bwd_K, long col_off, int Nb, float scale, hipStream_t st);
+
 // direct small convolutions (conv_in: Cin=5 -> C; conv_out: C -> 4) and their input-gradients
 void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* w, const float* bias, void* y,
                            int y_is_f32, int B, int H, int W, int Cin, int Cout, hipStream_t st);

@@ -135,7 +135,12 @@ class GuidedStableDiffuser(GuidedDiffuser):
             if isinstance(self.text_encoder, str):
                 self.text_encoder = build_text_encoder()
             if isinstance(self.vae, str):
+                # "sd": the SD VAE architecture in PyTorch-ROCm; "sd-native": the same with the decoder on the engine's kernels
+                native = self.vae == "sd-native"
                 self.vae = AutoencoderKL()
+                if native:
+                    from .vae import NativeDecodeVAE
+                    self.vae = NativeDecodeVAE(self.vae, self._unet_config["sample_size"], self.dtype)
             if self.tokenizer is None:
                 self.tokenizer = SyntheticTokenizer()
             if self.text_encoder is None:

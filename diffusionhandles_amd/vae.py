@@ -190,3 +190,108 @@ def build_text_encoder(pretrained_dir=None, config=None):
     if pretrained_dir is not None:
         return CLIPTextModel.from_pretrained(pretrained_dir)
     return CLIPTextModel(CLIPTextConfig(**dict(SD2_TEXT, **(config or {})))).eval()
+
+
+class HipVAEDecoder:
+    """The decoder half of `AutoencoderKL` on the native engine kernels (csrc/vae_engine.cpp): MFMA implicit-GEMM
+    convolutions, the engine's GroupNorm, the single 512-dim attention head as two GEMMs around a row softmax.
+    `decode(z)` has AutoencoderKL.decode's call surface (z [B,4,h,w] already divided by the scaling factor); the 1x1
+    `post_quant_conv` (a 4x4 matrix per latent pixel) stays a torch op.  Weights come from an AutoencoderKL state dict."""
+
+    def __init__(self, config=None, latent_size=64, dtype=torch.float16, device=None):
+        import ctypes
+        from . import _lib
+        _lib.require_gpu()
+        c = dict(SD_VAE, **(config or {}))
+        self.config = SimpleNamespace(**c)
+        self.dtype, self.latent_size = dtype, int(latent_size)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = _lib.VAEConfig()
+        cfg.latent_channels, cfg.out_channels = c["latent_channels"], c["out_channels"]
+        for i in range(4):
+            cfg.block_out_channels[i] = c["block_out_channels"][i]
+        cfg.layers_per_block, cfg.norm_groups = c["layers_per_block"], c["norm_num_groups"]
+        cfg.latent_size, cfg.dtype = self.latent_size, _lib.DTYPE_CODE[dtype]
+        self._L = _lib.lib()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dh_vae_decoder_create(ctypes.byref(cfg), ctypes.byref(h)), "dh_vae_decoder_create")
+        self._h = h
+        self._pq_w = self._pq_b = None
+        self._table = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.dh_vae_decoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def param_table(self):
+        import ctypes
+        from . import _lib
+        if self._table is None:
+            tab = []
+            for i in range(self._L.dh_vae_decoder_num_params(self._h)):
+                name, nd, shp = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+                _lib.check(self._L.dh_vae_decoder_param_info(self._h, i, ctypes.byref(name), ctypes.byref(nd), shp))
+                tab.append((name.value.decode(), tuple(int(shp[k]) for k in range(nd.value))))
+            self._table = tab
+        return self._table
+
+    def load_state_dict(self, sd):
+        """sd: an AutoencoderKL state dict (diffusers names); the `decoder.*` and `post_quant_conv.*` entries are used."""
+        from . import _lib
+        st = _lib.stream_ptr()
+        for i, (name, shape) in enumerate(self.param_table()):
+            t = sd[name].detach()
+            if t.dim() == 4 and len(shape) == 2:          # a Linear stored as a 1x1 convolution (older checkpoints)
+                t = t.reshape(shape)
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+            t = t.to(self.device, torch.float32).contiguous()
+            _lib.check(self._L.dh_vae_decoder_load_param(self._h, i, _lib.ptr(t), st), f"load {name}")
+        self._pq_w = sd["post_quant_conv.weight"].detach().to(self.device, torch.float32).reshape(
+            self.config.latent_channels, self.config.latent_channels).contiguous()
+        self._pq_b = sd["post_quant_conv.bias"].detach().to(self.device, torch.float32).contiguous()
+        torch.cuda.synchronize(self.device)
+        return self
+
+    def workspace_bytes(self):
+        return int(self._L.dh_vae_decoder_bytes(self._h))
+
+    @torch.no_grad()
+    def decode(self, z, return_dict=True):
+        from . import _lib
+        B, C, h, w = z.shape
+        if h != self.latent_size or w != self.latent_size:
+            raise ValueError(f"decoder built for {self.latent_size}x{self.latent_size} latents, got {h}x{w}")
+        zl = z.to(self.device, torch.float32).permute(0, 2, 3, 1)                       # channels-last
+        zl = (zl @ self._pq_w.t() + self._pq_b).contiguous()                           # post_quant_conv (1x1)
+        img = torch.empty((B, 8 * h, 8 * w, self.config.out_channels), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.dh_vae_decoder_decode(self._h, _lib.ptr(zl), B, _lib.ptr(img), _lib.stream_ptr()),
+                   "dh_vae_decoder_decode")
+        img = img.permute(0, 3, 1, 2)
+        return _Out(sample=img) if return_dict else (img,)
+
+
+class NativeDecodeVAE(nn.Module):
+    """AutoencoderKL whose `decode` runs on the native engine (`encode` stays PyTorch-ROCm: once per image)."""
+
+    def __init__(self, vae, latent_size=64, dtype=torch.float16):
+        super().__init__()
+        self.vae, self.config = vae, vae.config
+        self._latent_size, self._dtype, self._dec = latent_size, dtype, None
+
+    def to(self, device):
+        self.vae = self.vae.to(device)
+        if torch.device(device).type == "cuda":
+            self._dec = HipVAEDecoder(vars(self.vae.config), self._latent_size, self._dtype, device).load_state_dict(self.vae.state_dict())
+        return self
+
+    def encode(self, x, return_dict=True):
+        return self.vae.encode(x, return_dict)
+
+    def decode(self, z, return_dict=True):
+        return self._dec.decode(z, return_dict)

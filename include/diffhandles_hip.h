@@ -232,6 +232,31 @@ int dh_adam_step(float* p, const float* g, float* m, float* v, float lr, float b
 int dh_mse_fwd_bwd(const float* rec, const float* target, int n, float* loss_out, float* d_rec,
                    void* stream);
 
+/* --------------------------------------------------------------------------------------
+ * SD AutoencoderKL decoder on the engine's kernels: the decode that ends every edit
+ * (guided_stable_diffuser.py:481-483 decode_latent_image, :286; stable_null_inverter.py:105 latent2image).
+ * diffusers' AutoencoderKL is [ext]; parameter names are its state-dict names ("decoder.*").
+ * z: [B][h][w][latent_channels] f32 channels-last, ALREADY divided by the scaling factor and passed through
+ * post_quant_conv (a 4x4 matrix per pixel, host side); image: [B][8h][8w][out_channels] f32.  Forward only.
+ * ------------------------------------------------------------------------------------ */
+typedef struct dh_vae_decoder dh_vae_decoder;
+typedef struct dh_vae_config {
+  int latent_channels;        /* 4 */
+  int out_channels;           /* 3 */
+  int block_out_channels[4];  /* 128 256 512 512 (encoder order, as in the VAE's config.json) */
+  int layers_per_block;       /* 2 (the decoder runs layers_per_block + 1 resnets per up block) */
+  int norm_groups;            /* 32 */
+  int latent_size;            /* 64 (latent H = W; image = 8x) */
+  int dtype;                  /* DH_DTYPE_F16 or DH_DTYPE_BF16 */
+} dh_vae_config;
+int dh_vae_decoder_create(const dh_vae_config* cfg, dh_vae_decoder** out);
+void dh_vae_decoder_destroy(dh_vae_decoder* v);
+int dh_vae_decoder_num_params(const dh_vae_decoder* v);
+int dh_vae_decoder_param_info(const dh_vae_decoder* v, int i, const char** name, int* ndim, int64_t* shape4);
+int dh_vae_decoder_load_param(dh_vae_decoder* v, int i, const float* src, void* stream);   /* DEVICE f32, torch layout */
+size_t dh_vae_decoder_bytes(const dh_vae_decoder* v);
+int dh_vae_decoder_decode(dh_vae_decoder* v, const float* z, int batch, float* image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

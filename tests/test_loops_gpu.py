@@ -347,9 +347,12 @@ def test_scene_harness_end_to_end_on_the_reference_scene(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert [e["name"] for e in rep["edits"]] == ["edit_000", "edit_001"] and rep["resolution"] == 512
-    for f in ("recon.png", "edit_000.png", "edit_000_disparity.png", "edit_001.png", "edit_001_disparity.png", "report.json"):
+    for f in ("recon.png", "edit_000.png", "edit_000_disparity.png", "edit_001.png", "edit_001_disparity.png", "report.json",
+              "input.png", "mask.png", "depth.png", "bg_depth.png", "summary.html"):
         assert os.path.exists(os.path.join(out, f)), f
     img = S.read_png(os.path.join(out, "edit_001.png"))
     disp = S.read_png(os.path.join(out, "edit_001_disparity.png"))
     assert img.shape == (512, 512, 3) and disp.shape == (512, 512) and disp.max() == 255 and disp.min() < 64
     assert not os.path.exists(os.path.join(out, "identity.npz"))
+    html = open(os.path.join(out, "summary.html")).read()
+    assert html.count("<tr>") == 3 and "edit_001_disparity.png" in html            # header + one row per edit

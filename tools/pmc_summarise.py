@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""FETCH_SIZE / WRITE_SIZE per launch of the k_gemm_dma kernels from the two tools/pmc_passes.sh passes
+(gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}.tsv: kernel name, launches, counter sum in KiB) -> profiles-style JSON."""
+import json
+import sys
+
+out = {}
+by_kernel = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    n = v = 0.0
+    for line in open(f"{sys.argv[1]}/{c}.tsv"):
+        name, cnt, val = line.rstrip("\n").split("\t")
+        by_kernel.setdefault(name.split("(")[0][:60], {})[c] = (int(cnt), float(val))
+        if "k_gemm_dma" in name:
+            n += int(cnt)
+            v += float(val)
+    out[c] = (n, v)
+launches = out["FETCH_SIZE"][0]
+f = out["FETCH_SIZE"][1] / launches
+w = out["WRITE_SIZE"][1] / out["WRITE_SIZE"][0]
+print(json.dumps({
+    "kernel": "dh::k_gemm_dma (all instantiations)",
+    "workload": "SD-2-depth U-Net fwd+bwd, B=1, 64x64 latent, fp16 (tools/time_unet.py 1, 13 iterations)",
+    "launches": int(launches), "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w,
+    "fetch_correction": "x2 (gfx950 FETCH_SIZE under-count, MI355X_MICROARCH.md HBM section)",
+    "traffic_bytes_per_launch": (2 * f + w) * 1024,
+    "command": "tools/pmc_passes.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/time_unet.py 1 ; "
+               "same with --pmc WRITE_SIZE (separate passes); tools/pmc_summarise.py gpurun_out/pmc"}, indent=1))

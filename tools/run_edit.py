@@ -90,6 +90,23 @@ def main():
         write_png(os.path.join(args.out, f"{name}_disparity.png"), (disparity[0, 0] / disparity.max()).float().cpu().numpy())
         report["edits"].append(dict(name=name, seconds=round(dt, 3)))
     json.dump(report, open(os.path.join(args.out, "report.json"), "w"), indent=1)
+    # the results page of the reference's harness (test/generate_results_webpage.py: one row per edit with input, mask,
+    # depth, background depth, reconstruction, edit, edited disparity), written without a template engine
+    norm = lambda d: ((d - d.min()) / (d.max() - d.min() + 1e-12)).float().cpu().numpy()
+    write_png(os.path.join(args.out, "input.png"), img[0].permute(1, 2, 0).float().cpu().numpy())
+    write_png(os.path.join(args.out, "mask.png"), mask[0, 0].float().cpu().numpy())
+    write_png(os.path.join(args.out, "depth.png"), norm(1.0 / depth[0, 0]))
+    write_png(os.path.join(args.out, "bg_depth.png"), norm(1.0 / bg_depth[0, 0]))
+    cols = ["input", "mask", "depth", "bg_depth", "recon"]
+    rows = []
+    for e in report["edits"]:
+        cells = "".join(f'<td><img src="{c}.png" width="192"></td>' for c in cols)
+        cells += f'<td><img src="{e["name"]}.png" width="192"></td><td><img src="{e["name"]}_disparity.png" width="192"></td>'
+        rows.append(f'<tr><th>{e["name"]}<br>{e["seconds"]} s</th>{cells}</tr>')
+    head = "".join(f"<th>{c}</th>" for c in ["edit"] + cols + ["edited image", "edited disparity"])
+    with open(os.path.join(args.out, "summary.html"), "w") as f:
+        f.write(f"<!doctype html><html><head><meta charset='utf-8'><title>{prompt}</title></head><body><h3>{prompt} "
+                f"({res}x{res}, {args.mode})</h3><table border='1' cellspacing='0' cellpadding='4'><tr>{head}</tr>{''.join(rows)}</table></body></html>")
     print(json.dumps(report))
 
 

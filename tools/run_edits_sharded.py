@@ -66,7 +66,7 @@ def main():
     from diffusionhandles_amd.unet import SD2_DEPTH
     conf = C.load_default()
     dh = DiffusionHandles(conf, dtype=torch.float16, unet_config=dict(SD2_DEPTH, sample_size=args.res // 8),
-                          max_batch=max(2, 2 * args.batch), vae="sd").to(dev)
+                          max_batch=max(2, 2 * args.batch), vae="sd-native").to(dev)
     if args.scene:
         sc = load_scene(args.scene, args.res)
         img, depth, bg_depth, mask, prompt = sc["img"], sc["depth"], sc["bg_depth"], sc["fg_mask"], sc["prompt"]
@@ -83,7 +83,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():       # untimed: MIOpen picks / compiles the VAE's convolution kernels on the first call of a shape
+    with torch.no_grad():       # untimed warm-up of the decoder
         lat = args.res // 8
         dh.diffuser.decode_latent_image(torch.zeros(min(args.batch, -(-len(edits) // world)), 4, lat, lat, device=dev))
     # ---- per-image identity: once per image ------------------------------------------------------------------------
