@@ -356,3 +356,26 @@ def test_scene_harness_end_to_end_on_the_reference_scene(tmp_path):
     assert not os.path.exists(os.path.join(out, "identity.npz"))
     html = open(os.path.join(out, "summary.html")).read()
     assert html.count("<tr>") == 3 and "edit_001_disparity.png" in html            # header + one row per edit
+
+
+def test_sharded_edit_driver_on_one_gpu(tmp_path):
+    """tools/run_edits_sharded.py (BASELINE config 4's driver) on the one GPU of the box: 5 edits in batches of 2 (so a
+    ragged last batch), identity from initial inference, images written, report with the whole-job edits/s."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from diffusionhandles_amd import scene_io as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "edits")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_edits_sharded.py"), "--edits", "5", "--batch", "2",
+                        "--out", out], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["edits"] == 5 and rep["n_gpus"] == 1 and rep["batch"] == 2 and rep["edits_per_s"] > 0
+    for i in range(5):
+        img = S.read_png(os.path.join(out, f"edit_{i:03d}.png"))
+        assert img.shape == (512, 512, 3)
+        assert S.read_png(os.path.join(out, f"edit_{i:03d}_disparity.png")).shape == (512, 512)
+    assert json.load(open(os.path.join(out, "report.json")))["edits"] == 5
