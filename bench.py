@@ -272,7 +272,8 @@ def main():
 
     # ---- batched edits: K transforms of one image in one U-Net batch (config 3), and config 4's unit on every rank -----------
     batch_info, edits_info = None, None
-    if K > 1:
+    def batched_section():
+        nonlocal batch_info, edits_info
         tfs = [(TRANSFORMS[(i + rank) % 8][0], Y, torch.tensor(TRANSFORMS[(i + rank) % 8][1])) for i in range(K)]
         with torch.no_grad():
             # batched guided steps (every rank runs them: they also capture the batch-K graphs the whole-edit timing replays)
@@ -306,6 +307,15 @@ def main():
                           "what": f"{K} edits of one image per GPU as one batch: re-projection of {K} transforms, 38 guided + 12 "
                                   "unguided batched steps, AutoencoderKL decode (native decoder, random weights); identity cached; MAX over ranks"}
             del imgs
+
+    if K > 1:
+        if world > 1:
+            batched_section()          # every rank meets the same barriers: an exception must end the job, not leave ranks waiting
+        else:
+            try:
+                batched_section()
+            except Exception as exc:          # noqa: BLE001 - never lose the headline line to a secondary measurement
+                edits_info = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- secondary measurements (rank 0).  They never gate the headline line: a failure is reported in place of the numbers.
     def hbm_records(gd_, st_, depth_, bg_, mask_, res):

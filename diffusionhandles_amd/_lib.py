@@ -68,6 +68,7 @@ SIGNATURES = {
     "dh_unet_workspace_bytes": (c_sz, [c_p]),
     "dh_unet_forward": (c_i, [c_p, c_p, c_f, c_p, c_i, c_i, c_p, ctypes.POINTER(c_p), c_p]),
     "dh_unet_backward": (c_i, [c_p, ctypes.POINTER(c_p), c_p, c_p, c_p, c_p]),
+    "dh_unet_set_text_key": (c_i, [c_p, ctypes.c_ulonglong]),
     "dh_unet_stats": (c_i, [c_p, ctypes.POINTER(c_d), ctypes.POINTER(c_d), ctypes.POINTER(ctypes.c_int64)]),
     "dh_vae_decoder_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
     "dh_vae_decoder_destroy": (None, [c_p]),

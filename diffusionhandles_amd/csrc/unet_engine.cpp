@@ -99,6 +99,13 @@ struct dh_unet {
   int temb_ops = 0, temb_rows = 0;
   float temb_t = 0.f;
   hipStream_t temb_stream = nullptr;   // the stream the cached projections were produced on (another stream = miss)
+  // the K|V projections of the text (one GEMM over all cross-attention layers) depend on the text embedding only: the
+  // caller names the embedding with a key (dh_unet_set_text_key); a forward that finds the projections of the same key,
+  // batch and stream in place skips the text conversion and that GEMM (the three optimisation passes of a guided step share
+  // the prompt embedding; the CFG pass, whose text differs, overwrites the buffer)
+  uint64_t text_key = 0, kv_key = 0;
+  int kv_rows = 0;
+  hipStream_t kv_stream = nullptr;
   long temb_f32_off = -1;
   int temb_total = 0, kv_total = 0;
   // staging buffers (fixed addresses so a captured graph can be replayed) and graph cache
@@ -610,7 +617,7 @@ extern "C" int dh_unet_param_info(const dh_unet* u, int i, const char** name, in
 }
 
 extern "C" int dh_unet_load_param(dh_unet* u, int i, const float* src, void* stream) {
-  if (u) { u->temb_rows = 0; u->fold_dirty = true; }     // cached time-embedding projections / folded LayerNorm weights belong to the old parameters
+  if (u) { u->temb_rows = 0; u->fold_dirty = true; u->kv_key = 0; }     // cached time-embedding projections / folded LayerNorm weights belong to the old parameters
   DH_REQUIRE(u && src && i >= 0 && i < (int)u->params.size(), "bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const ParamInfo& p = u->params[i];
@@ -673,14 +680,15 @@ static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
   }
 }
 
-static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, hipStream_t st) {
+static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit, hipStream_t st) {
   const int dt = u->dtype;
   const dh_unet_config& c = u->cfg;
   u->flops_fwd = 0;
   int gn_have = 0;       // the op just executed left the GroupNorm slice statistics of its output in u->small
-  launch_f32_to_t(dt, u->in_text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
+  if (!kv_hit) launch_f32_to_t(dt, u->in_text, u->aptr(u->t_text), (size_t)B * c.text_len * c.cross_attention_dim, st);
   for (int oi = first_op; oi < n_ops; ++oi) {
     const Op& o = u->ops[oi];
+    if (kv_hit && oi == u->temb_ops) continue;        // the hoisted text K|V projection (the op right after the time-embedding chain)
     switch (o.type) {
       case OP_TIMESTEP:
         launch_timestep_embedding(dt, u->t_dev, c.block_out_channels[0], B, u->aptr(o.out), st);
@@ -769,9 +777,9 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, hipStream_t 
 
 // run `body` through a cached hipGraph (captured on first use of `key`) or eagerly
 // graph cache keys: batch in bits 0-11 (max_batch < 2^12 by dh_unet_create), the tape length in 12-27, the
-// backward's activation mask in 28-30, its flags in 31-33, time-embedding hit in 34, forward / backward in 35
-static uint64_t graph_key_fwd(int B, int n_ops, bool temb_hit) {
-  return (uint64_t)B | ((uint64_t)n_ops << 12) | ((uint64_t)(temb_hit ? 1 : 0) << 34);
+// backward's activation mask in 28-30, its flags in 31-33, time-embedding hit in 34, forward / backward in 35, text K|V hit in 36
+static uint64_t graph_key_fwd(int B, int n_ops, bool temb_hit, bool kv_hit) {
+  return (uint64_t)B | ((uint64_t)n_ops << 12) | ((uint64_t)(temb_hit ? 1 : 0) << 34) | ((uint64_t)(kv_hit ? 1 : 0) << 36);
 }
 static uint64_t graph_key_bwd(int B, unsigned mask, bool eps, bool sample, bool text) {
   return (uint64_t)B | ((uint64_t)(mask & 7u) << 28) | ((uint64_t)(eps ? 1 : 0) << 31) | ((uint64_t)(sample ? 1 : 0) << 32) |
@@ -821,11 +829,13 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   }
   if (u->fold_dirty) fold_layernorms(u, st);
   const bool temb_hit = u->temb_rows >= B && u->temb_t == timestep && u->temb_stream == st;
+  const bool kv_hit = u->text_key != 0 && u->text_key == u->kv_key && u->kv_rows == B && u->kv_stream == st;
   const int first_op = temb_hit ? u->temb_ops : 0;
-  int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit), st, &u->flops_fwd,
-                       [&]() { forward_ops(u, B, n_ops, first_op, st); });
-  if (rc != DH_OK) { u->temb_rows = 0; return rc; }      // nothing cached after a failed capture / launch
+  int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit, kv_hit), st, &u->flops_fwd,
+                       [&]() { forward_ops(u, B, n_ops, first_op, kv_hit, st); });
+  if (rc != DH_OK) { u->temb_rows = 0; u->kv_key = 0; return rc; }      // nothing cached after a failed capture / launch
   if (!temb_hit) { u->temb_t = timestep; u->temb_rows = B; u->temb_stream = st; }
+  if (!kv_hit) { u->kv_key = u->text_key; u->kv_rows = B; u->kv_stream = st; }   // key 0: the buffer now holds an unnamed text
   if (eps_out) DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
   if (act_out) {
     for (int i = 0; i < 3; ++i)
@@ -1052,6 +1062,12 @@ extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_e
   if (d_sample) DH_CHECK_HIP(hipMemcpyAsync(d_sample, u->out_dsample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
   if (d_text) DH_CHECK_HIP(hipMemcpyAsync(d_text, u->out_dtext, nt * 4, hipMemcpyDeviceToDevice, st));
   DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_unet_set_text_key(dh_unet* u, unsigned long long key) {
+  DH_REQUIRE(u, "null engine");
+  u->text_key = key;
   return DH_OK;
 }
 

@@ -90,6 +90,8 @@ def _nhwc(x):
 
 
 class GuidedStableDiffuser(GuidedDiffuser):
+    _text_keys = 0
+
     def __init__(self, conf, unet=None, vae=None, text_encoder=None, tokenizer=None, dtype=torch.float16,
                  unet_config=None, max_batch=2, synthetic_seed=0):
         super().__init__(conf=conf)
@@ -294,6 +296,8 @@ class GuidedStableDiffuser(GuidedDiffuser):
         st.pc = self.process_correspondences(correspondences, img_res=depth.shape[-1], bg_erosion=self.conf.bg_erosion)
         st.depth_nhwc = _nhwc(self.init_depth(depth.to(self.device, torch.float32))) if self.conf.use_depth else None
         st.cond = self._encode([prompt]).contiguous()
+        GuidedStableDiffuser._text_keys += 1
+        st.cond_key = GuidedStableDiffuser._text_keys          # names st.cond for the engine's text K|V cache
         st.schedule = build_weight_schedule(fg_weight, bg_weight, self.conf.guidance_max_step,
                                             self.conf.guidance_schedule_type)
         # original activations as channels-last engine-dtype storage [T,h,w,C]
@@ -328,7 +332,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
             active = [k for k in range(3) if (fgw[k] != 0.0 and st.n_pairs > 0) or bgw[k] != 0.0]
             if active:
                 _, acts = self.unet.forward(self._unet_input(x, st.depth_nhwc), float(t), st.cond, save_for_backward=True,
-                                            want_acts=active, want_eps=False)
+                                            want_acts=active, want_eps=False, text_key=st.cond_key)
                 d_acts = [None, None, None]
                 for k in active:
                     d_acts[k] = self._energy_grad(st, k, acts[k][0], t_idx, fgw[k], bgw[k])[None]
@@ -363,7 +367,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
             if active:
                 sample = torch.cat([x, depth], dim=-1).contiguous() if self.conf.use_depth else x
                 _, acts = self.unet.forward(sample, float(t), cond, save_for_backward=True, want_acts=active,
-                                            want_eps=False)
+                                            want_eps=False, text_key=sts[0].cond_key)
                 d_acts = [None, None, None]
                 for k in active:
                     g_all = torch.empty_like(acts[k])

@@ -118,11 +118,13 @@ class HipUNet:
         return int(self._L.dh_unet_workspace_bytes(self._h))
 
     # ---- compute ------------------------------------------------------------------------
-    def forward(self, sample_nhwc, timestep, text, save_for_backward=False, want_acts=True, want_eps=True):
+    def forward(self, sample_nhwc, timestep, text, save_for_backward=False, want_acts=True, want_eps=True, text_key=0):
         """sample_nhwc [B,H,W,Cin] f32, text [B,L,D] f32 (device, contiguous).
         Returns eps [B,H,W,Cout] f32 and a list of 3 channels-last activations [B,h,w,C].
         want_acts may be a collection of activation indices; with want_eps=False the engine stops after
-        the last requested activation (eps is None, the other activations are None)."""
+        the last requested activation (eps is None, the other activations are None).
+        text_key != 0 names the content of `text`: consecutive forwards with the same key and batch reuse the text K|V
+        projections (the caller changes the key when the embedding changes)."""
         B = sample_nhwc.shape[0]
         s = self.sample_size
         eps = torch.empty((B, s, s, self.cfg["out_channels"]), dtype=torch.float32, device=self.device) \
@@ -134,6 +136,7 @@ class HipUNet:
             acts = [torch.empty((B,) + shp, dtype=self.dtype, device=self.device) if i in idx else None
                     for i, shp in enumerate(self.act_shapes)]
             arr = (ctypes.c_void_p * 3)(*[a.data_ptr() if a is not None else None for a in acts])
+        _lib.check(self._L.dh_unet_set_text_key(self._h, int(text_key)), "dh_unet_set_text_key")
         _lib.check(self._L.dh_unet_forward(self._h, _lib.ptr(sample_nhwc), float(timestep), _lib.ptr(text), B,
                                            1 if save_for_backward else 0, _lib.ptr(eps), arr, _lib.stream_ptr()),
                    "dh_unet_forward")

@@ -212,6 +212,11 @@ int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* 
 int dh_gemm_profile_begin(void);
 int dh_gemm_profile_end(double* ms_total, int64_t* launches, double* flops);
 /* per-kernel-class accumulated launch counts / algorithmic flops of the last forward */
+/* Names the text embedding of the following dh_unet_forward calls (0 = unnamed, the default).  The K|V projections of every
+ * cross-attention layer depend on the text only; a forward that finds those of the same key, batch and stream already in the
+ * engine skips recomputing them.  The caller must change the key whenever the text tensor's content changes
+ * (guided_stable_diffuser.py:404-410: the prompt embedding is constant over the optimisation passes of an edit). */
+int dh_unet_set_text_key(dh_unet* u, unsigned long long key);
 int dh_unet_stats(const dh_unet* u, double* flops_fwd, double* flops_bwd, int64_t* launches);
 
 /* --------------------------------------------------------------------------------------

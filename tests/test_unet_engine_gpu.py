@@ -176,3 +176,32 @@ def test_engine_graph_cache_keys_batch16():
                 got, _ = hip.backward(mask, None)
                 assert torch.equal(got, eager)
     torch.cuda.synchronize()
+
+
+def test_engine_text_kv_cache_by_key():
+    """dh_unet_set_text_key: forwards that name the same text reuse the hoisted K|V projections (bit-identical to
+    recomputing them); a new key, another batch size or an unnamed forward in between recomputes."""
+    from oracle import unet_torch as U
+    cfg = dict(U.TINY, sample_size=16)
+    _, hip = build(cfg, torch.float16, 2)
+    g = torch.Generator(device=dev()).manual_seed(17)
+    x = torch.randn(1, 16, 16, 5, generator=g, device=dev())
+    x2 = torch.randn(1, 16, 16, 5, generator=g, device=dev())
+    ta = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g, device=dev())
+    tb = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g, device=dev())
+    with torch.cuda.stream(torch.cuda.Stream()):
+        ref_a = hip.forward(x, 100.0, ta)[0].clone()
+        ref_a2 = hip.forward(x2, 100.0, ta)[0].clone()
+        ref_b = hip.forward(x, 100.0, tb)[0].clone()
+        assert torch.equal(hip.forward(x, 100.0, ta, text_key=5)[0], ref_a)           # miss: computes and names the projections
+        assert torch.equal(hip.forward(x2, 100.0, ta, text_key=5)[0], ref_a2)         # hit
+        assert torch.equal(hip.forward(x, 100.0, tb, text_key=6)[0], ref_b)           # new key: recomputed
+        assert torch.equal(hip.forward(x, 100.0, ta)[0], ref_a)                       # unnamed forward overwrites the buffer ...
+        assert torch.equal(hip.forward(x, 100.0, tb, text_key=6)[0], ref_b)           # ... so key 6 is recomputed, not stale
+        d = (torch.randn((1,) + hip.act_shapes[2], generator=g, device=dev()) * 1e-2).to(torch.float16)
+        hip.forward(x, 100.0, tb, save_for_backward=True, text_key=6)                 # hit, then a backward to the text through it
+        ds_hit, dt_hit = hip.backward([None, None, d], None, True, True)
+        hip.forward(x, 100.0, tb, save_for_backward=True)
+        ds_ref, dt_ref = hip.backward([None, None, d], None, True, True)
+        assert torch.equal(ds_hit, ds_ref) and torch.equal(dt_hit, dt_ref)
+    torch.cuda.synchronize()

@@ -43,5 +43,10 @@ if os.environ.get('DH_SHAPES') == 'abl':
     shapes = [(4096, 640, 5760, (1, 64, 640)), (256, 1280, 11520, (1, 16, 1280)), (8192, 1280, 11520, (8, 32, 1280))]
 if os.environ.get('DH_SHAPES') == 'b1':
     shapes = [(4096, 320, 2880, (1, 64, 320)), (4096, 640, 5760, (1, 64, 640)), (4096, 320, 1280, None), (1024, 640, 5760, (1, 32, 640)), (4096, 1280, 320, None)]
+if os.environ.get('DH_SHAPES') == 'b8':     # the batched-edits mode (8 images per pass)
+    shapes = [(32768, 320, 2880, (8, 64, 320)), (32768, 320, 5760, (8, 64, 640)), (8192, 640, 5760, (8, 32, 640)),
+              (8192, 640, 11520, (8, 32, 1280)), (2048, 1280, 11520, (8, 16, 1280)), (512, 1280, 11520, (8, 8, 1280)),
+              (32768, 320, 320, None), (32768, 960, 320, None), (32768, 2560, 320, None), (32768, 320, 1280, None),
+              (8192, 5120, 640, None), (8192, 640, 2560, None), (2048, 1280, 1280, None), (2048, 10240, 1280, None)]
 for s in shapes:
     run(*s)
