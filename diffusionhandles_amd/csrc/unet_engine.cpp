@@ -113,6 +113,7 @@ struct dh_unet {
   std::map<uint64_t, hipGraphExec_t> graphs;      // 64-bit keys: every field has its own bit range (graph_key_*)
   std::map<uint64_t, double> graph_flops;
   bool use_graphs = true;
+  long ones_off = -1, zeros_off = -1;   // f32 vectors of the widest LayerNorm: gamma = 1 / beta = 0 for the unfolded large-batch path
   bool fold_dirty = true;           // a parameter was (re)loaded: W * gamma and the s / t vectors of the folded LayerNorms are stale
   // run state
   int saved_batch = 0;
@@ -446,6 +447,10 @@ int build(dh_unet& u) {
     const Op& nx = u.ops[i + 1];
     if (nx.type == OP_GN && nx.in0 == o.out && (o.type == OP_GEMM || o.type == OP_CONCAT)) o.gn_next = (int)(i + 1);
   }
+  { int cmax = 0;
+    for (const Op& o : u.ops) if (o.type == OP_LN) cmax = std::max(cmax, u.tens[o.in0].C);
+    u.ones_off = (long)u.pf_elems; u.pf_elems += align_up((size_t)cmax, 64);
+    u.zeros_off = (long)u.pf_elems; u.pf_elems += align_up((size_t)cmax, 64); }
   // scratch: split-K partial slabs, upsample-backward temporary, small f32 vectors
   size_t biggest = 0;
   for (const Ten& t : u.tens) biggest = std::max(biggest, (size_t)t.rows * t.C * c.max_batch);
@@ -521,7 +526,31 @@ __global__ void __launch_bounds__(256) k_fold_ln(const D* bwd, int bwd_K, const 
 }
 
 // (re)compute the folded weights and vectors of every LayerNorm-consuming GEMM; runs on `st` before the pass that needs them
+__global__ void k_fill_f32(float* p, int n, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// The fold pays where a pass is launch-bound (same-box A/B of the forward pass at 64x64 latents: B = 1 and 2 -2 %, B = 4
+// +0.5 %, B = 8 +-0): with many rows the LayerNorm kernel is cheap next to what the row sums cost inside the GEMM's K loop.
+// Above this many rows of the widest level the pass runs the LayerNorm as a kernel again -- with gamma = 1, beta = 0,
+// because gamma and beta live in the folded weights and in ln_t.
+static bool use_ln_fold(const dh_unet* u, int B) {
+#ifdef DH_TUNING
+  static const long lim = getenv("DH_LN_FOLD_MAXROWS") ? atol(getenv("DH_LN_FOLD_MAXROWS")) : 12288;
+#else
+  constexpr long lim = 12288;
+#endif
+  return (long)B * u->cfg.sample_size * u->cfg.sample_size <= lim;
+}
+
 static void fold_layernorms(dh_unet* u, hipStream_t st) {
+  { int cmax = 0;
+    for (const Op& o : u->ops) if (o.type == OP_LN) cmax = std::max(cmax, u->tens[o.in0].C);
+    if (cmax > 0) {
+      hipLaunchKernelGGL(k_fill_f32, dim3(cdiv(cmax, 256)), dim3(256), 0, st, u->pf + u->ones_off, cmax, 1.f);
+      hipLaunchKernelGGL(k_fill_f32, dim3(cdiv(cmax, 256)), dim3(256), 0, st, u->pf + u->zeros_off, cmax, 0.f);
+    } }
   for (const Op& g : u->ops) {
     if (g.type != OP_GEMM || g.ln_fold < 0) continue;
     const Op& l = u->ops[g.ln_fold];
@@ -672,11 +701,15 @@ static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
   g.C = u->aptr(o.out); g.ldc = to.C;
   g.act_silu = o.act_silu;
   g.partial = u->partial; g.partial_elems = u->partial_elems;
-  if (o.ln_fold >= 0) {          // A = the LayerNorm's INPUT; the normalisation happens in the epilogue (bias is inside ln_t)
+  if (o.ln_fold >= 0) {
     const Op& l = u->ops[o.ln_fold];
-    g.A = u->aptr(l.in0); g.lda = u->tens[l.in0].C;
-    g.bias = nullptr;
-    g.ln_s = u->pf + o.ln_s_off; g.ln_t = u->pf + o.ln_t_off; g.ln_stats = u->f32a + l.stats_off; g.ln_eps = l.eps;
+    if (use_ln_fold(u, B)) {     // A = the LayerNorm's INPUT; the normalisation happens in the epilogue (bias is inside ln_t)
+      g.A = u->aptr(l.in0); g.lda = u->tens[l.in0].C;
+      g.bias = nullptr;
+      g.ln_s = u->pf + o.ln_s_off; g.ln_t = u->pf + o.ln_t_off; g.ln_stats = u->f32a + l.stats_off; g.ln_eps = l.eps;
+    } else {
+      g.bias = u->pf + o.ln_t_off;      // A = the plain-normalised tensor (OP_LN ran with gamma 1, beta 0); W * gamma and t hold the affine part
+    }
   }
 }
 
@@ -730,9 +763,11 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit,
         break;
       }
       case OP_LN: {
-        if (o.folded) break;           // normalised inside the GEMM that follows (fill_gemm)
+        if (o.folded && use_ln_fold(u, B)) break;           // normalised inside the GEMM that follows (fill_gemm)
         const Ten& t = u->tens[o.in0];
-        launch_layernorm_fwd(dt, u->aptr(o.in0), u->pf + o.gamma_off, u->pf + o.beta_off, u->aptr(o.out),
+        // (a folded LayerNorm on the large-batch path normalises without the affine part: it sits in the GEMM's weights)
+        launch_layernorm_fwd(dt, u->aptr(o.in0), u->pf + (o.folded ? u->ones_off : o.gamma_off),
+                             u->pf + (o.folded ? u->zeros_off : o.beta_off), u->aptr(o.out),
                              u->f32a + o.stats_off, B * t.rows, t.C, o.eps, st);
         break;
       }

@@ -52,6 +52,7 @@ class HipUNet:
         ch, s = self.cfg["block_out_channels"], c.sample_size
         self.act_shapes = [(s // 2, s // 2, ch[2]), (s, s, ch[1]), (s, s, ch[0])]   # (h, w, C) of act0..2
         self._saved_batch = 0
+        self._text_key = 0
 
     def __del__(self):
         try:
@@ -136,7 +137,9 @@ class HipUNet:
             acts = [torch.empty((B,) + shp, dtype=self.dtype, device=self.device) if i in idx else None
                     for i, shp in enumerate(self.act_shapes)]
             arr = (ctypes.c_void_p * 3)(*[a.data_ptr() if a is not None else None for a in acts])
-        _lib.check(self._L.dh_unet_set_text_key(self._h, int(text_key)), "dh_unet_set_text_key")
+        if int(text_key) != self._text_key:           # (0 = unnamed text, the engine's default)
+            _lib.check(self._L.dh_unet_set_text_key(self._h, int(text_key)), "dh_unet_set_text_key")
+            self._text_key = int(text_key)
         _lib.check(self._L.dh_unet_forward(self._h, _lib.ptr(sample_nhwc), float(timestep), _lib.ptr(text), B,
                                            1 if save_for_backward else 0, _lib.ptr(eps), arr, _lib.stream_ptr()),
                    "dh_unet_forward")
