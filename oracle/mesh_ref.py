@@ -4,7 +4,9 @@ CPU restatement of depth_transform_mode='mesh' (reference depth_transform.py:91-
 :30-71, transform_points :438-458, renderer outputs 'world_position' + 'flat_vertex_color' of
 pytorch3d_renderer.py:541-941).
 
-PARITY UNPINNED: the reference draws with pytorch3d (git HEAD, pyproject.toml:35), which is neither in
+GEOMETRY PINNED (g13, tools/make_golden_mesh.py): the vertices, the two counter-clockwise triangles per pixel quad and the
+float32 Rodrigues motion of the masked vertices equal the reference's own depth_to_mesh / transform_points (pure torch).
+RASTERISATION PARITY UNPINNED: the reference draws with pytorch3d (git HEAD, pyproject.toml:35), which is neither in
 /root/reference nor installed, and the reference holds no test or golden vector for this mode.  This
 file restates pytorch3d's published naive rasterisation rule (NDC +X left/+Y up, pixel-centre sampling,
 blur_radius coverage, perspective-correct clipped barycentrics, |area| <= 1e-8 skipped, area < 0 culled,
