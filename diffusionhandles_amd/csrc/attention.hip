@@ -140,12 +140,7 @@ __device__ __forceinline__ void store_rows_t(T* base, long ld, long row, int col
       for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(acc[dt][4 * g + i] * mul);
       w[g] = *reinterpret_cast<uint2*>(o);
     }
-    const uint2 sa = hi ? w[0] : w[1], sb = hi ? w[2] : w[3];
-    uint2 ra, rb;
-    ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
-    rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
-    const uint4 ca = hi ? make_uint4(ra.x, ra.y, w[1].x, w[1].y) : make_uint4(w[0].x, w[0].y, ra.x, ra.y);
-    const uint4 cb = hi ? make_uint4(rb.x, rb.y, w[3].x, w[3].y) : make_uint4(w[2].x, w[2].y, rb.x, rb.y);
+    const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
     T* out = base + row * ld + col0 + dt * 32 + 8 * hi;
     *reinterpret_cast<uint4*>(out) = ca;
     *reinterpret_cast<uint4*>(out + 16) = cb;
@@ -217,7 +212,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = fast_exp2((m_run - m_new) * CEXP);
     const float mc = m_new * CEXP;
@@ -230,7 +225,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
         s[t2][r] = p;
         rs += p;
       }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = xor32_sum(rs);
     l_run = l_run * alpha + rs;
     m_run = m_new;
 #pragma unroll
@@ -336,7 +331,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
 #pragma unroll
       for (int i = 0; i < 8; ++i) del_q += to_f32<T>(ov[i]) * to_f32<T>(dv[i]);
     }
-    del_q += __shfl_xor(del_q, 32, 64);
+    del_q = xor32_sum(del_q);
     if (delta && qok && ks == 0 && hi == 0) delta[((long)b * H + h) * Nq + qrow] = del_q;      // NULL: already there
   }
   const float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;

@@ -91,6 +91,56 @@ __device__ __forceinline__ T wave_max(T v) {
   }
   return v;
 }
+
+// f32 cross-lane steps on the VALU instead of ds_bpermute (an LDS round trip of >100 cycles per step, six dependent
+// ones per wave reduction): DPP quad permutes / mirrors inside a row of 16 lanes, v_permlane16_swap / v_permlane32_swap
+// (gfx950) across rows and wave halves.  x_swap(v, v) returns {v with its odd rows (upper half) replaced by the even rows
+// (lower half), v with the even rows replaced by the odd ones}: their sum is the pairwise total, identical in both lanes.
+typedef unsigned lane_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
+struct LanePair { float a, b; };
+__device__ __forceinline__ LanePair half_pair(float v) {          // {value of the lower-half lane, of the upper-half lane} of (l, l ^ 32)
+  const lane_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ LanePair row_pair(float v) {           // the same for (l, l ^ 16)
+  const lane_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ float xor32_sum(float v) { const LanePair p = half_pair(v); return p.a + p.b; }
+__device__ __forceinline__ float xor32_max(float v) { const LanePair p = half_pair(v); return fmaxf(p.a, p.b); }
+// sum over aligned groups of 8 lanes, in every lane of the group
+__device__ __forceinline__ float oct_sum(float v) {
+  v += dpp_f32<DPP_QUAD_XOR1>(v);
+  v += dpp_f32<DPP_QUAD_XOR2>(v);
+  v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = oct_sum(v);
+  v += dpp_f32<DPP_ROW_MIRROR>(v);
+  { const LanePair p = row_pair(v); v = p.a + p.b; }
+  return xor32_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+  v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+  { const LanePair p = row_pair(v); v = fmaxf(p.a, p.b); }
+  return xor32_max(v);
+}
+// lanes l and l ^ 32 each hold two 8-byte values (a, b); afterwards the lower lane holds {its a, the upper lane's a} and
+// the upper lane {the lower lane's b, its b}: the 16-byte chunks of the wide epilogue stores
+__device__ __forceinline__ uint4 half_exchange(uint2 a, uint2 b) {
+  const lane_u2 x = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+  const lane_u2 y = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+  return make_uint4(x[0], y[0], x[1], y[1]);
+}
 // block sum with a fixed tree (deterministic); sm must hold blockDim.x/64 elements.
 template <class T>
 __device__ __forceinline__ T block_sum(T v, T* sm) {

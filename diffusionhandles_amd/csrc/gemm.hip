@@ -30,6 +30,9 @@ struct GemmProf {
   double flops = 0;
 };
 static GemmProf g_prof;
+#ifdef DH_TUNING
+static unsigned long long* g_gemm_ts = nullptr;      // device buffer of 8 stamps (dh_dbg_gemm_timeline)
+#endif
 bool gemm_profiling_on() { return g_prof.on; }
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
@@ -62,6 +65,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   int wide_store;   // 16-byte epilogue stores (N % 32 == 0, C and ldc 16-byte aligned)
 #ifdef DH_TUNING
   int w_nt;         // non-temporal weight DMA (measured: no gain at <= 2 row tiles, a loss beyond; tuning builds only)
+  unsigned long long* ts;   // in-kernel timeline of workgroup (0,0,0), lane 0 of wave 0: s_memtime at the phase boundaries
   int lnf_abl;      // timing-only ablation of the folded LayerNorm: 1 = no sums in the K loop, 2 = no exchange, 4 = no epilogue transform
 #endif
   // LayerNorm folded into this GEMM (LNF instantiations): A is the LayerNorm INPUT x, W holds W * gamma, and
@@ -161,8 +165,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
 #ifdef DH_TUNING
 #define LNF_ABL(bit) && !(p.lnf_abl & (bit))
+#define LEAN_ABL && !(p.lnf_abl & 8)
+#define DH_STAMP(i) do { if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) p.ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define LNF_ABL(bit)
+#define LEAN_ABL
+#define DH_STAMP(i) do { } while (0)
 #endif
 
 // sum and sum of squares of the 8 16-bit values of an MFMA operand fragment (f32 accumulate, v_dot2c)
@@ -212,6 +220,7 @@ template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, in
 __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) {
   static_assert((WG == 1) + (KG == 1) + (MW == 1) >= 2, "one kind of wave grouping per instantiation");
   static_assert(!LNF || (WG == 1 && MODE == GM_DENSE), "the folded LayerNorm needs every k-step of a row in one wave group");
+  DH_STAMP(0);
   constexpr int NWV = 4 * MW;                               // waves that share one staged tile
   constexpr int TM = BM / 64 / MW, TN = BN / 64;
   constexpr int NPA = BM / 32 / WG / MW, NPB = BN / 32 / WG / MW;     // 1-KiB pieces per wave per stage
@@ -345,6 +354,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
   for (int s = 0; s < ST - 1; ++s)
     if (s < ntiles) issue(s, s);
+  DH_STAMP(1);
 
   // the residual tile is fetched now and added in the epilogue: its cold load flies under the K loop instead of
   // sitting at the tail of the kernel (these loads are younger than the prologue DMAs and older than every later one,
@@ -394,10 +404,12 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 
   constexpr int KK = BK / 16 / WG;                // k-steps of a tile multiplied by this wave group
   const int kk0 = grp * KK;
+  DH_STAMP(2);
   for (int kt = 0; kt < loop_tiles; ++kt) {
     // tile kt has landed once at most (ST-2) later tiles' loads are still outstanding
     if (ntiles - 1 - kt >= ST - 2) wait_vmcnt<NP * (ST - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) DH_STAMP(3);
     if (KG > 1 && kt >= ntiles) continue;           // a group with a shorter K range only keeps the barrier count
     const bool more = ABL != 2 && kt + ST - 1 < ntiles;
     const int nkt = kt + ST - 1, nstage = nkt % ST;
@@ -436,6 +448,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
     if (more) next_tile();
   }
+  DH_STAMP(4);
 
   if (LNF LNF_ABL(2)) {
     // exchange the row sums with the partner wave (wave ^ 1: same rows, the other k-steps) through the idle rings
@@ -497,7 +510,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     const float inv_k = 1.f / (float)p.K;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const float a = ln1[i] + __shfl_xor(ln1[i], 32, 64), q = ln2[i] + __shfl_xor(ln2[i], 32, 64);
+      const float a = xor32_sum(ln1[i]), q = xor32_sum(ln2[i]);
       const float mean = a * inv_k;
       float var = q * inv_k - mean * mean;
       var = var > 0.f ? var : 0.f;
@@ -521,6 +534,46 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
   }
 
+  DH_STAMP(5);
+  // the common epilogue as straight-line code: bias and residual already sit in registers (prefetched under the K loop), no
+  // per-image vector, no SiLU.  The general path below carries a fallback load and a ~90-instruction SiLU block per 4-column
+  // group behind uniform branches; jumping over them costs an instruction-cache line fetch per hop in a kernel whose
+  // epilogue runs once, on one wave per SIMD.
+  if (PRE && p.splits == 1 && p.wide_store && p.pre_r && !p.rowvec && !p.act_silu LEAN_ABL) {
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    const bool hb = p.bias != nullptr, hr = p.R != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      if (m >= p.M) continue;
+      T* orow = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n0 + wn * (BN / 2) + 8 * hi;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (n0 + wn * (BN / 2) + j * 32 >= p.N) continue;
+        uint2 w[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+          if (hb) { v0 += bpre[j][g].x; v1 += bpre[j][g].y; v2 += bpre[j][g].z; v3 += bpre[j][g].w; }
+          if (hr) {
+            const T4 rv = __builtin_bit_cast(T4, rpre[i][j][g]);
+            v0 += to_f32<T>(rv[0]); v1 += to_f32<T>(rv[1]); v2 += to_f32<T>(rv[2]); v3 += to_f32<T>(rv[3]);
+          }
+          T4 o;
+          o[0] = from_f32<T>(v0); o[1] = from_f32<T>(v1); o[2] = from_f32<T>(v2); o[3] = from_f32<T>(v3);
+          w[g] = __builtin_bit_cast(uint2, o);
+        }
+        const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
+        *reinterpret_cast<uint4*>(orow + j * 32) = ca;
+        *reinterpret_cast<uint4*>(orow + j * 32 + 16) = cb;
+      }
+    }
+    DH_STAMP(6);
+#ifdef DH_TUNING
+    if (p.ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DH_STAMP(7); }
+#endif
+    return;
+  }
   // 16-bit results: the two lanes of a row (lane, lane ^ 32) own alternating 4-column groups; they swap two groups so
   // that each stores two 16-byte chunks instead of four 8-byte ones (half the write transactions, whole 32-byte sectors
   // per lane pair)
@@ -538,17 +591,16 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         for (int g = 0; g < 4; ++g)
           w[g] = epilogue_pack<T>(p, m, nb + 8 * g + 4 * hi, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
                                   acc[i][j][4 * g + 3], pre_r, rpre[i][j][g], pre_b, bpre[j][g]);
-        const uint2 sa = hi ? w[0] : w[1], sb = hi ? w[2] : w[3];
-        uint2 ra, rb;
-        ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
-        rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
-        const uint4 ca = hi ? make_uint4(ra.x, ra.y, w[1].x, w[1].y) : make_uint4(w[0].x, w[0].y, ra.x, ra.y);
-        const uint4 cb = hi ? make_uint4(rb.x, rb.y, w[3].x, w[3].y) : make_uint4(w[2].x, w[2].y, rb.x, rb.y);
+        const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
         T* out = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 8 * hi;
         *reinterpret_cast<uint4*>(out) = ca;
         *reinterpret_cast<uint4*>(out + 16) = cb;
       }
     }
+    DH_STAMP(6);
+#ifdef DH_TUNING
+    if (p.ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DH_STAMP(7); }
+#endif
     return;
   }
 
@@ -827,6 +879,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   k.w_nt = kWnt > 0 && tm <= kWnt;
   static const int kLnfAbl = getenv("DH_LNF_ABL") ? atoi(getenv("DH_LNF_ABL")) : 0;
   k.lnf_abl = kLnfAbl;
+  k.ts = g_gemm_ts;
 #endif
   dim3 grid(tm, tn, splits);
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -901,6 +954,11 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace dh
+
+#ifdef DH_TUNING
+// tuning builds: the next GEMM launches stamp the timeline of their first workgroup into `ts` (8 x u64, device memory)
+extern "C" int dh_dbg_gemm_timeline(unsigned long long* ts) { dh::g_gemm_ts = ts; return DH_OK; }
+#endif
 
 extern "C" int dh_gemm_profile_begin(void) {
   dh::g_prof.on = true;

@@ -288,14 +288,12 @@ __device__ __forceinline__ void gn_combine(const float* part, int b, int G, int 
   float n = 0.f, sm = 0.f;
 #pragma unroll
   for (int k = 0; k < GN_COMBINE_K; ++k) { n += cn[k]; sm += cn[k] * cm[k]; }
-#pragma unroll
-  for (int o = 4; o > 0; o >>= 1) { n += __shfl_xor(n, o, 64); sm += __shfl_xor(sm, o, 64); }
+  n = oct_sum(n); sm = oct_sum(sm);
   const float mean = sm / n;
   float m2 = 0.f;
 #pragma unroll
   for (int k = 0; k < GN_COMBINE_K; ++k) { const float d = cm[k] - mean; m2 += cq[k] + cn[k] * d * d; }
-#pragma unroll
-  for (int o = 4; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+  m2 = oct_sum(m2);
   if (act && sub == 0) {
     const float rstd = rsqrtf(m2 / n + eps);
     sm_stats[g] = make_float2(mean, rstd);
@@ -430,8 +428,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
     float a = 0.f, c = 0.f;
 #pragma unroll
     for (int k = 0; k < GN_COMBINE_K; ++k) { a += v[k].x; c += v[k].y; }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+    a = oct_sum(a); c = oct_sum(c);
     const float inv = 1.f / ((float)HW * (float)cpg);
     if (act && sub == 0) sm_st[g] = make_float4(st.x, st.y, a * inv, c * inv);
   }

@@ -42,8 +42,7 @@ __global__ void __launch_bounds__(256) k_softmax_rows(T* s, int rows, int cols) 
 #pragma unroll
     for (int i = 0; i < 8; ++i) mx = fmaxf(mx, to_f32<T>(v[i]));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  mx = wave_max(mx);
   float sum = 0.f;
   for (int c = lane * 8; c < cols; c += 512) {
     const uint4 raw = *reinterpret_cast<const uint4*>(p + c);
