@@ -50,6 +50,9 @@ __device__ __forceinline__ v16f zero16() {
   return z;
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#ifndef DH_ATTN_ABL
+#define DH_ATTN_ABL 0      // timing-only ablations of the forward loop (tools/attn_ablate.sh): never set in the product build
+#endif
 
 // 4 register fragments (k = d) of row `row` of a [rows][ld] matrix at column col0: B-operand layout
 template <class T>
@@ -183,20 +186,25 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
   for (int it = 0; it < tps; ++it) {
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;        // uniform per wave group; barriers are block-wide
-    __syncthreads();
-    if (act) {
+    if (DH_ATTN_ABL != 3) __syncthreads();
+    if (act && (DH_ATTN_ABL != 6 || it == 0)) {
       commit_tile<GT>(rk, sK, tid);
       commit_tile<GT>(rv, sV, tid);
     }
-    __syncthreads();
+    if (DH_ATTN_ABL != 3) __syncthreads();
     if (!act) continue;
-    if (t_begin + it + 1 < t_end) {            // next tile's loads fly under this tile's MFMAs
+    if (t_begin + it + 1 < t_end && DH_ATTN_ABL != 2 && DH_ATTN_ABL != 6) {            // next tile's loads fly under this tile's MFMAs
       fetch_tile<T, GT>(kp, ldk, k0 + 64, Nk, rk, tid);
       fetch_tile<T, GT>(vp, ldk, k0 + 64, Nk, rv, tid);
     }
     v16f s[2];
+    if (DH_ATTN_ABL == 5) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[0][r] = __uint_as_float(qf[r & 3].x) * (float)(it + r); s[1][r] = __uint_as_float(qf[r & 3].y) * (float)(it - r); }
+    } else {
     s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
     s[1] = tile_times_frags<T>(sK, 32, ln, hi, qf);
+    }
     if (k0 + 64 > Nk) {            // ragged last tile: mask the keys past Nk
       // (the empty asm keeps this a real branch: flattened into selects it cost 32 compares + 32 selects + the key
       // index arithmetic in EVERY tile of a loop that is bound by its softmax VALU work)
@@ -221,7 +229,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(__builtin_fmaf(s[t2][r], CEXP, -mc));
+        const float p = DH_ATTN_ABL == 1 ? __builtin_fmaf(s[t2][r], CEXP, -mc) : fast_exp2(__builtin_fmaf(s[t2][r], CEXP, -mc));
         s[t2][r] = p;
         rs += p;
       }
@@ -238,8 +246,10 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
       for (int st = 0; st < 2; ++st) {
         const uint4 pf = pack8<T>(s[t2], st);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt) {
+          if (DH_ATTN_ABL == 4) { oacc[dt][st] += __uint_as_float(pf.x) + __uint_as_float(pf.y) + __uint_as_float(pf.z) + __uint_as_float(pf.w); continue; }
           oacc[dt] = Mma<T>::run(tr_frag(vt, dt * 32, t2 * 32 + 16 * st), pf, oacc[dt]);
+        }
       }
   }
   if (KS > 1) {
