@@ -77,3 +77,8 @@ extern "C" int dh_dbg_pool2x2(int dtype, const void* src, void* dst, int B, int 
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+extern "C" int dh_dbg_lane_ops(const float* in, float* out, unsigned* ex, void* stream) {
+  launch_lane_ops_probe(in, out, ex, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}

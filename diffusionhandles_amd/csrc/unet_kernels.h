@@ -89,6 +89,9 @@ void launch_copy_cols(int dtype, const void* src, long lds, void* dst, long ldd,
 // src [rows][colsA + colsB] split into dstA (=|+=) and dstB (=|+=) in one launch (concat backward)
 void launch_split_cols(int dtype, const void* src, long lds, void* dstA, long ldA, int colsA, int accA, void* dstB, long ldB,
                        int colsB, int accB, int rows, hipStream_t st);
+// test hook: the cross-lane helpers of common.h on one wave (out[0..63] wave_sum, [64..] wave_max, [128..] oct_sum,
+// [192..] xor32_sum, [256..] xor32_max; ex[lane] = half_exchange of (a = {4 lane, 4 lane + 1}, b = {4 lane + 2, 4 lane + 3}))
+void launch_lane_ops_probe(const float* in, float* out, unsigned* ex, hipStream_t st);
 void launch_pool2x2_sum(int dtype, const void* src, void* dst, int B, int h, int w, int C, int accumulate,
                         hipStream_t st);                     // dst[b][y][x] (=|+=) sum of the 2x2 block of src
 void launch_f32_to_t(int dtype, const float* src, void* dst, size_t n, hipStream_t st);

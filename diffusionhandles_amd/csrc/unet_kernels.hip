@@ -931,4 +931,19 @@ void launch_timestep_embedding(int dtype, const float* t, int dim, int B, void* 
   else hipLaunchKernelGGL((k_timestep<bf16>), dim3(cdiv(B * dim, 256)), dim3(256), 0, st, t, dim, B, (bf16*)out);
 }
 
+__global__ void k_lane_ops_probe(const float* in, float* out, unsigned* ex) {
+  const int lane = threadIdx.x;
+  const float v = in[lane];
+  out[lane] = wave_sum(v);
+  out[64 + lane] = wave_max(v);
+  out[128 + lane] = oct_sum(v);
+  out[192 + lane] = xor32_sum(v);
+  out[256 + lane] = xor32_max(v);
+  const uint4 e = half_exchange(make_uint2(4u * lane, 4u * lane + 1), make_uint2(4u * lane + 2, 4u * lane + 3));
+  ex[4 * lane] = e.x; ex[4 * lane + 1] = e.y; ex[4 * lane + 2] = e.z; ex[4 * lane + 3] = e.w;
+}
+void launch_lane_ops_probe(const float* in, float* out, unsigned* ex, hipStream_t st) {
+  hipLaunchKernelGGL(k_lane_ops_probe, dim3(1), dim3(64), 0, st, in, out, ex);
+}
+
 }  // namespace dh

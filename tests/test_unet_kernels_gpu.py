@@ -186,3 +186,31 @@ def test_attention_forward_backward(dtype, B, H, Nq, Nk):
     close(lse, lse_ref, 1e-3, 2e-3, "attn lse")
     for got, r, nm in ((dq, gq, "dq"), (dk, gk, "dk"), (dv, gv, "dv")):
         close(got, r, 2 * tol, 2 * tol * max(1.0, r.abs().max().item()) * 0.2, "attn " + nm)
+
+
+def test_cross_lane_helpers():
+    """common.h's VALU cross-lane steps (DPP / v_permlane16_swap / v_permlane32_swap): every lane of the wave (aligned octet,
+    lane pair l / l^32) holds the total; the 16-byte exchange of the wide epilogue stores hands the right halves over."""
+    torch.manual_seed(5)
+    for trial in range(4):
+        x = torch.randn(64, device=dev()) * (10.0 ** trial)
+        out = torch.zeros(320, device=dev())
+        ex = torch.zeros(256, dtype=torch.int32, device=dev())
+        L().check(L().lib().dh_dbg_lane_ops(P(x), P(out), P(ex), L().stream_ptr()), "lane ops")
+        torch.cuda.synchronize()
+        xs = x.double().cpu()
+        o = out.cpu()
+        tot = xs.sum().item()
+        assert torch.all(o[:64] == o[0]) and abs(o[0].item() - tot) <= 1e-5 * xs.abs().sum().item()
+        assert torch.all(o[64:128] == x.max().item())
+        for g in range(8):
+            seg = o[128 + 8 * g:136 + 8 * g]
+            assert torch.all(seg == seg[0]) and abs(seg[0].item() - xs[8 * g:8 * g + 8].sum().item()) <= 1e-5 * xs.abs().sum().item()
+        xc = x.cpu()
+        assert torch.equal(o[192:224], xc[:32] + xc[32:]) and torch.equal(o[224:256], xc[:32] + xc[32:])
+        assert torch.equal(o[256:288], torch.maximum(xc[:32], xc[32:])) and torch.equal(o[288:320], torch.maximum(xc[:32], xc[32:]))
+        e = ex.cpu().view(64, 4)
+        for lane in range(32):      # lower lane: {its a, the upper lane's a}; upper lane: {the lower lane's b, its b}
+            up = lane + 32
+            assert e[lane].tolist() == [4 * lane, 4 * lane + 1, 4 * up, 4 * up + 1]
+            assert e[up].tolist() == [4 * lane + 2, 4 * lane + 3, 4 * up + 2, 4 * up + 3]
