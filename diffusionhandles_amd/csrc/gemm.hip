@@ -903,6 +903,10 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   if (kAbl == 1 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 1>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 2 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_CONV_S1, 2>), grid, dim3(256), 0, st, k); }
   else if (kAbl == 3 && BM == 128 && BN == 128) { hipLaunchKernelGGL((k_gemm_dma<T, 128, 128, 4, GM_DENSE, 1>), grid, dim3(256), 0, st, k); }
+  else if (kAbl == 1 && mw2 && gm == GM_CONV_S1) { hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_CONV_S1, 1, 1, 1, 2>), grid, dim3(512), 0, st, k); }
+  else if (kAbl == 2 && mw2 && gm == GM_CONV_S1) { hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_CONV_S1, 2, 1, 1, 2>), grid, dim3(512), 0, st, k); }
+  else if (kAbl == 1 && mw2 && gm == GM_DENSE && !lnf) { hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_DENSE, 1, 1, 1, 2>), grid, dim3(512), 0, st, k); }
+  else if (kAbl == 2 && mw2 && gm == GM_DENSE && !lnf) { hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_DENSE, 2, 1, 1, 2>), grid, dim3(512), 0, st, k); }
   else
 #endif
   if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k);
