@@ -27,5 +27,8 @@ def run(B, H, Nq, Nk, iters=20, bwd=True):
         res.append(e0.elapsed_time(e1) * 1e3 / iters)
     f = 4.0 * B * H * Nq * Nk * 64
     print(f"B={B} H={H:2d} Nq={Nq:5d} Nk={Nk:5d}: fwd {res[0]:7.1f} us ({f/res[0]/1e6:6.1f} TF/s)   fwd+delta+dq+dkv {res[1]:7.1f} us ({3.5*f/(res[1])/1e6:6.1f} TF/s)")
-for cfg in [(1, 5, 4096, 4096), (2, 5, 4096, 4096), (1, 10, 1024, 1024), (1, 20, 256, 256), (1, 5, 4096, 77), (1, 10, 1024, 77), (1, 5, 9216, 9216)]:
+CFGS = [(1, 5, 4096, 4096), (2, 5, 4096, 4096), (1, 10, 1024, 1024), (1, 20, 256, 256), (1, 5, 4096, 77), (1, 10, 1024, 77), (1, 5, 9216, 9216)]
+if os.environ.get("DH_ATTN_CFGS") == "b8":      # the batched-edits mode
+    CFGS = [(8, 5, 4096, 4096), (8, 10, 1024, 1024), (8, 20, 256, 256), (8, 5, 4096, 77), (8, 10, 1024, 77)]
+for cfg in CFGS:
     run(*cfg)

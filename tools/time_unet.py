@@ -5,9 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusionhandles_amd.unet import HipUNet
 
-dt = torch.float16
+from diffusionhandles_amd.unet import SD2_DEPTH
+dt = torch.bfloat16 if os.environ.get("DH_DTYPE") == "bf16" else torch.float16
+LAT = int(os.environ.get("DH_LATENT", "64"))           # 96 = the 768x768 configuration
 BATCHES = tuple(int(b) for b in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 2)
-u = HipUNet(dtype=dt, max_batch=max(BATCHES))
+u = HipUNet(dict(SD2_DEPTH, sample_size=LAT), dtype=dt, max_batch=max(BATCHES))
 u.init_synthetic(0)
 print("weights GB", u.weight_bytes() / 1e9, "workspace GB", u.workspace_bytes() / 1e9)
 dev = u.device
@@ -15,7 +17,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 side = torch.cuda.Stream()
 torch.cuda.set_stream(side)
 for B in BATCHES:
-    x = torch.randn(B, 64, 64, 5, generator=g, device=dev)
+    x = torch.randn(B, LAT, LAT, 5, generator=g, device=dev)
     txt = torch.randn(B, 77, 1024, generator=g, device=dev)
     da = [None, torch.randn((B,) + u.act_shapes[1], generator=g, device=dev).to(dt) * 1e-2,
           torch.randn((B,) + u.act_shapes[2], generator=g, device=dev).to(dt) * 1e-2]
