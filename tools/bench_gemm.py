@@ -48,5 +48,8 @@ if os.environ.get('DH_SHAPES') == 'b8':     # the batched-edits mode (8 images p
               (8192, 640, 11520, (8, 32, 1280)), (2048, 1280, 11520, (8, 16, 1280)), (512, 1280, 11520, (8, 8, 1280)),
               (32768, 320, 320, None), (32768, 960, 320, None), (32768, 2560, 320, None), (32768, 320, 1280, None),
               (8192, 5120, 640, None), (8192, 640, 2560, None), (2048, 1280, 1280, None), (2048, 10240, 1280, None)]
+if os.environ.get('DH_SHAPES') == 'lin':    # the long-K linears that split K over workgroups + a plain reduce launch
+    shapes = [(256, 1280, 5120, None), (256, 1280, 10240, None), (1024, 640, 2560, None), (1024, 640, 5120, None), (64, 1280, 5120, None),
+              (64, 1280, 10240, None), (256, 10240, 1280, None), (1024, 5120, 640, None), (4096, 320, 2560, None)]
 for s in shapes:
     run(*s)
