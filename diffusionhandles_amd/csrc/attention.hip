@@ -157,15 +157,16 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // keys [ks, ks+1) * ceil(tiles / KS) and the groups' (m, l, O) are merged through LDS at the end.  A single
 // image has only Nq/128 * H query tiles (160 at 64x64 latents, 5 heads): splitting the keys inside the block
 // puts KS waves on every SIMD instead of one, so one wave's softmax VALU work hides under another's MFMAs.
-template <class T, int KS, int QW>
+template <class T, int KS, int QW, bool DB>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
                                                        float* lse, int H, int Nq, int Nk) {
-  // DB (key-split blocks, i.e. long loops): the K/V tiles are double-buffered per wave group -- tile it+1, fetched one
-  // iteration ago, is committed to the other buffer after tile it has been multiplied, so ONE block-wide barrier per key
-  // tile orders both "tile it is visible" and "everyone has left tile it-1" (N = 4096: 49.8 -> 45.3 us).  Short loops
-  // (KS = 1: at most 7 tiles, the 77-key cross-attention) keep the single buffer: there the second buffer's extra
-  // prologue step costs more than the barrier it saves (guided step -0.7 % when every shape was double-buffered).
-  constexpr bool DB = KS >= 2;
+  // DB (key-split blocks of grids that fit the chip once or twice): the K/V tiles are double-buffered per wave group --
+  // tile it+1, fetched one iteration ago, is committed to the other buffer after tile it has been multiplied, so ONE
+  // block-wide barrier per key tile orders both "tile it is visible" and "everyone has left tile it-1" (N = 4096, B = 1:
+  // 49.8 -> 45.3 us).  Short loops (KS = 1: at most 7 tiles, the 77-key cross-attention) keep the single buffer: there the
+  // second buffer's extra prologue step costs more than the barrier it saves (guided step -0.7 % when every shape was
+  // double-buffered); so do big grids (batch 8: 1280 blocks), where 147 KB of LDS leaves one block per CU instead of two
+  // (310 -> 352 us).
   constexpr int NBUF = DB ? 2 : 1;
   __shared__ __attribute__((aligned(16))) unsigned short smem[KS * NBUF * 2 * TILE];
   constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
@@ -635,8 +636,16 @@ static int attn_row_waves(int rows, int hb, int loop_rows) {
 template <class T, int KS, int QW>
 static void attn_fwd_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
                             long ldo, float* lse, int H, int Nq, int Nk) {
-  hipLaunchKernelGGL((k_attn_fwd<T, KS, QW>), dim3(cdiv(Nq, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
-                     (const T*)k, (const T*)v, ldk, (T*)o, ldo, lse, H, Nq, Nk);
+  const dim3 grid(cdiv(Nq, 32 * QW), H, B);
+  if constexpr (KS >= 2 && KS * QW < 16) {      // (the 16-wave block has no registers to spare for the second fetch)
+    if ((long)grid.x * grid.y * grid.z <= 512) {
+      hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, true>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
+                         ldk, (T*)o, ldo, lse, H, Nq, Nk);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, false>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
+                     ldk, (T*)o, ldo, lse, H, Nq, Nk);
 }
 template <class T, int KS, int QW>
 static void attn_dq_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
