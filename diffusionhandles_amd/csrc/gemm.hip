@@ -79,6 +79,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   int splits, k_per_split;
   float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
   const void* gnb_x; long gnb_ldx; const float *gnb_gamma, *gnb_beta, *gnb_stats; int gnb_silu;   // backward statistics
+  const void* lnb_x; const float *lnb_gamma, *lnb_stats; const void* lnb_add; void* lnb_dx;        // LayerNorm backward on the reduce (host side only)
 };
 
 constexpr int BK = 64;
@@ -849,7 +850,7 @@ static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK
 #endif
 
 template <class T>
-static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn_done) {
+static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn_done, int* lnb_done, int dtype) {
   DH_KNOB(kSplitTiles, "DH_SPLITK_TILES", 200);     // split K only under this many output tiles ...
   DH_KNOB(kSplitMinK, "DH_SPLITK_MINKT", 32);       // ... and from this many K tiles (24 -> 32: +1 % on the guided step)
   DH_KNOB(kSplitTarget, "DH_SPLITK_TARGET", 256);   // workgroups aimed at
@@ -943,6 +944,10 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
       if (k.gnb_x) hipLaunchKernelGGL((k_splitk_reduce_gn<T, true>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
       else hipLaunchKernelGGL((k_splitk_reduce_gn<T, false>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
       if (gn_done) *gn_done = 1;
+    } else if (k.lnb_x && lnb_done && !k.bias && !k.rowvec && !k.R && !k.act_silu && k.N % 8 == 0 && k.ldc == k.N) {
+      // the rows are the dy of a LayerNorm: reduce + LayerNorm backward in one launch (dy itself is not written)
+      launch_splitk_reduce_ln_bwd(dtype, k.partial, splits, k.lnb_x, k.lnb_gamma, k.lnb_stats, k.lnb_add, k.lnb_dx, k.M, k.N, st);
+      *lnb_done = 1;
     } else {
       const size_t groups = (size_t)k.M * k.N / 4;
       hipLaunchKernelGGL((k_splitk_reduce<T>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, k);
@@ -967,9 +972,11 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   k.gn_part = a.gn_part; k.gn_HW = a.gn_HW; k.gn_G = a.gn_G; k.gn_S = 0;
   k.gnb_x = a.gnb_x; k.gnb_ldx = a.gnb_ldx; k.gnb_gamma = a.gnb_gamma; k.gnb_beta = a.gnb_beta; k.gnb_stats = a.gnb_stats;
   k.gnb_silu = a.gnb_silu;
+  k.lnb_x = a.lnb_x; k.lnb_gamma = a.lnb_gamma; k.lnb_stats = a.lnb_stats; k.lnb_add = a.lnb_add; k.lnb_dx = a.lnb_dx;
   if (a.gn_done) *a.gn_done = 0;
-  if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st, a.gn_done);
-  else gemm_dispatch<bf16>(k, a.partial_elems, st, a.gn_done);
+  if (a.lnb_done) *a.lnb_done = 0;
+  if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st, a.gn_done, a.lnb_done, dtype);
+  else gemm_dispatch<bf16>(k, a.partial_elems, st, a.gn_done, a.lnb_done, dtype);
   return 2.0 * (double)a.M * (double)a.N * (double)a.K;
 }
 

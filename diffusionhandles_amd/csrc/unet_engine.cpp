@@ -916,6 +916,7 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
   Bwd bw{u, B, dt, st, d_text != nullptr};
   bool text_grad_written = false;
   int gnb_have = 0, gnb_for = -1;       // the split-K reduce just run left the backward statistics of GroupNorm op gnb_for
+  int lnb_have = 0, lnb_for = -1;       // the split-K reduce just run applied the backward of LayerNorm op lnb_for
   for (int oi = (int)u->ops.size() - 1; oi >= 0; --oi) {
     const Op& o = u->ops[oi];
     switch (o.type) {
@@ -956,6 +957,17 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
           g.M = B * to.rows; g.N = w.K; g.K = w.N;
           g.C = u->gptr(o.in0) + o.in_col; g.ldc = ti.C;
           if (u->gready[o.in0]) { g.R = g.C; g.ldr = ti.C; }
+          lnb_have = 0;
+          if (oi > 0 && u->ops[oi - 1].type == OP_LN && u->ops[oi - 1].out == o.in0 && !u->gready[o.in0] && o.in_col == 0 &&
+              w.K == ti.C) {
+            // the gradient being written is dy of the LayerNorm that is processed next and this GEMM is its only consumer:
+            // a split-K reduce applies that LayerNorm's backward to the summed rows directly
+            const Op& ln = u->ops[oi - 1];
+            g.lnb_x = u->aptr(ln.in0); g.lnb_gamma = u->pf + ln.gamma_off; g.lnb_stats = u->f32a + ln.stats_off;
+            g.lnb_add = u->gready[ln.in0] ? u->gptr(ln.in0) : nullptr; g.lnb_dx = u->gptr(ln.in0);
+            g.lnb_done = &lnb_have;
+            lnb_for = oi - 1;
+          }
           u->flops_bwd += launch_gemm(dt, g, st);
           u->gready[o.in0] = 1;
         } else if (o.up) {
@@ -1005,6 +1017,11 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
       }
       case OP_LN: {
         if (!u->gready[o.out]) break;
+        if (lnb_have && lnb_for == oi) {      // done by the split-K reduce of the GEMM in front of it
+          lnb_have = 0;
+          u->gready[o.in0] = 1;
+          break;
+        }
         const Ten& t = u->tens[o.in0];
         launch_layernorm_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->pf + o.gamma_off, u->f32a + o.stats_off,
                              u->gready[o.in0] ? u->gptr(o.in0) : nullptr, u->gptr(o.in0), B * t.rows, t.C, st);

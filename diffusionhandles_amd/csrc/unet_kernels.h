@@ -36,7 +36,16 @@ struct GemmArgs {
   // LayerNorm folded into the GEMM (dense, no split-K): A = the LayerNorm input, W = W * gamma (load-time fold),
   // ln_s[n] = sum_k W'[n][k], ln_t[n] = sum_k beta[k] W[n][k] + bias[n]; the row statistics are written to ln_stats [M][2]
   const float* ln_s = nullptr; const float* ln_t = nullptr; float* ln_stats = nullptr; float ln_eps = 1e-5f;
+  // lnb_x != NULL: the output (dense, full rows of width N, nothing accumulated into it) is the gradient dy of a LayerNorm
+  // whose INPUT is lnb_x.  When the launch goes through the split-K reduce, that kernel applies the LayerNorm backward to
+  // the summed rows and writes lnb_dx (+ lnb_add) instead of C; *lnb_done is set to 1 and the caller skips the LayerNorm op.
+  const void* lnb_x = nullptr; const float *lnb_gamma = nullptr, *lnb_stats = nullptr; const void* lnb_add = nullptr;
+  void* lnb_dx = nullptr; int* lnb_done = nullptr;
 };
+// split-K reduce + LayerNorm backward in one pass over the slabs (f32 [splits][rows][C]); dy is rounded to the storage type
+// before it is used, exactly as the reduce + k_ln_bwd pair does
+void launch_splitk_reduce_ln_bwd(int dtype, const float* partial, int splits, const void* x, const float* gamma,
+                                 const float* stats, const void* add, void* dx, int rows, int C, hipStream_t st);
 // D[m][n] = sum_k A(m,k) W[n][k] (+bias, +rowvec, silu, +R); returns algorithmic flops
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 bool gemm_profiling_on();   // HIP-event bracket active (bench roofline pass): graphs are bypassed

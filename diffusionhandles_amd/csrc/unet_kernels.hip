@@ -701,6 +701,123 @@ __global__ void __launch_bounds__(256, NCH == 1 ? 8 : (NCH <= 3 ? 4 : 1)) k_ln_b
   }
 }
 
+// The same backward with dy = the sum of `splits` f32 slabs [splits][rows][C] of a split-K input-gradient GEMM (no bias, no
+// residual): the reduce launch and the LayerNorm backward launch in one kernel, dy never goes to memory.  The sum is
+// rounded to the storage type first, so the result equals the two-kernel path bit for bit.
+template <class T, int NCH>
+__global__ void __launch_bounds__(256, NCH == 1 ? 4 : (NCH <= 3 ? 2 : 1)) k_splitk_reduce_ln_bwd(const float* part, int splits, const T* x, const float* gamma,
+                                                                       const float* stats, const T* add, T* dx, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C / 8;
+  const size_t base = (size_t)row * C, slab = (size_t)rows * C;
+  uint4 rx[NCH];
+  float d[NCH][8];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) rx[k] = *reinterpret_cast<const uint4*>(x + base + ch * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[k][i] = 0.f;
+  }
+  // the slabs in split order (the order of k_splitk_reduce), four splits' loads in flight per chunk
+  int z = 0;
+  for (; z + 4 <= splits; z += 4) {
+    float4 v[NCH][4][2];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int ch = lane + 64 * k;
+      if (ch < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* p = part + (size_t)(z + j) * slab + base + ch * 8;
+          v[k][j][0] = *reinterpret_cast<const float4*>(p);
+          v[k][j][1] = *reinterpret_cast<const float4*>(p + 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int ch = lane + 64 * k;
+      if (ch < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          d[k][0] += v[k][j][0].x; d[k][1] += v[k][j][0].y; d[k][2] += v[k][j][0].z; d[k][3] += v[k][j][0].w;
+          d[k][4] += v[k][j][1].x; d[k][5] += v[k][j][1].y; d[k][6] += v[k][j][1].z; d[k][7] += v[k][j][1].w;
+        }
+      }
+    }
+  }
+  for (; z < splits; ++z) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int ch = lane + 64 * k;
+      if (ch < nch) {
+        const float* p = part + (size_t)z * slab + base + ch * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
+        d[k][0] += a0.x; d[k][1] += a0.y; d[k][2] += a0.z; d[k][3] += a0.w;
+        d[k][4] += a1.x; d[k][5] += a1.y; d[k][6] += a1.z; d[k][7] += a1.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[k][i] = to_f32<T>(from_f32<T>(d[k][i]));
+  const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const T* xv = reinterpret_cast<const T*>(&rx[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
+        d[k][i] *= g[i];
+        s1 += d[k][i];
+        s2 += d[k][i] * xh;
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      uint4 ra = make_uint4(0, 0, 0, 0);
+      if (add) ra = *reinterpret_cast<const uint4*>(add + base + ch * 8);
+      const T* xv = reinterpret_cast<const T*>(&rx[k]);
+      const T* av = reinterpret_cast<const T*>(&ra);
+      T o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (to_f32<T>(xv[i]) - mean) * rstd;
+        float r = rstd * (d[k][i] - s1 - xh * s2);
+        if (add) r += to_f32<T>(av[i]);
+        o[i] = from_f32<T>(r);
+      }
+      *reinterpret_cast<uint4*>(dx + base + ch * 8) = *reinterpret_cast<uint4*>(o);
+    }
+  }
+}
+void launch_splitk_reduce_ln_bwd(int dtype, const float* partial, int splits, const void* x, const float* gamma,
+                                 const float* stats, const void* add, void* dx, int rows, int C, hipStream_t st) {
+#define DH_RLN(TT, N) hipLaunchKernelGGL((k_splitk_reduce_ln_bwd<TT, N>), dim3(cdiv(rows, 4)), dim3(256), 0, st, partial, splits, (const TT*)x, gamma, stats, (const TT*)add, (TT*)dx, rows, C)
+  const int n = C <= 512 ? 1 : (C <= 1024 ? 2 : (C <= 1536 ? 3 : LN_MAXCH));
+  if (dtype == DH_DTYPE_F16) {
+    if (n == 1) DH_RLN(f16, 1); else if (n == 2) DH_RLN(f16, 2); else if (n == 3) DH_RLN(f16, 3); else DH_RLN(f16, LN_MAXCH);
+  } else {
+    if (n == 1) DH_RLN(bf16, 1); else if (n == 2) DH_RLN(bf16, 2); else if (n == 3) DH_RLN(bf16, 3); else DH_RLN(bf16, LN_MAXCH);
+  }
+#undef DH_RLN
+}
+
 void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           int rows, int C, float eps, hipStream_t st) {
   DH_ABLATE(1);
