@@ -614,14 +614,18 @@ __global__ void k_attn_dkv_reduce(const float* qpart, int qchunks, int rows_pad,
 //     (640 at N=4096, H=5): the row tile is chosen so that the blocks cover the 256 CUs as evenly as possible
 //     (128-row tiles = 160 blocks leave 96 CUs idle, 96-row tiles = 215 blocks).
 static int attn_key_split(int tiles, int max_ks) {
-  static const int force = getenv("DH_ATTN_KS") ? atoi(getenv("DH_ATTN_KS")) : 0;
   int ks = tiles >= 16 ? 4 : tiles >= 8 ? 2 : 1;
+#ifdef DH_TUNING
+  static const int force = getenv("DH_ATTN_KS") ? atoi(getenv("DH_ATTN_KS")) : 0;
   if (force == 1 || force == 2 || force == 4) ks = force;
+#endif
   return ks < max_ks ? ks : max_ks;
 }
 static int attn_row_waves(int rows, int hb, int loop_rows) {
+#ifdef DH_TUNING
   static const int force = getenv("DH_ATTN_QW") ? atoi(getenv("DH_ATTN_QW")) : 0;
   if (force >= 1 && force <= 4) return force;
+#endif
   const int min_qw = loop_rows > 1024 ? 2 : 1;        // a 32-row block would stream the whole K/V per 32 rows
   int best = 4;
   long best_cost = -1;

@@ -657,7 +657,11 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
   hipLaunchKernelGGL(k_normalize, dim3(cdiv(R2, 256), K), dim3(256), 0, st, R2, disparity, w.minmax, bounds, raw_mask,
                      clean_mask, w.inpaint);
   compact(w.inpaint, R2, K, R2, w.unk, R2, counts + 2, 4, w.block_counts, st);
+#ifdef DH_TUNING
   static const bool cg_lds = !(getenv("DH_CG_LDS") && atoi(getenv("DH_CG_LDS")) == 0);
+#else
+  constexpr bool cg_lds = true;
+#endif
   if (cg_lds)
     hipLaunchKernelGGL(k_cg_fill_lds, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3,
                        w.owner, 20000, 1e-24, counts, (const float*)nullptr, w.vx, w.vr, w.vp, w.vq);

@@ -162,8 +162,11 @@ __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z))
 // slices per image: 32 for one or two images (the statistics kernels then launch 256 workgroups, one per CU), 16 for
 // bigger batches, where the batch dimension already fills the chip and the apply kernels' combine costs more
 static int gn_slice_cap(int B) {
+#ifdef DH_TUNING
   static const int v = getenv("DH_GN_SLICES") ? atoi(getenv("DH_GN_SLICES")) : 0;
-  return v > 0 ? (v > 64 ? 64 : v) : (B <= 2 ? 32 : 16);      // <= 64: gn_combine holds 8 slices per lane
+  if (v > 0) return v > 64 ? 64 : v;                          // <= 64: gn_combine holds 8 slices per lane
+#endif
+  return B <= 2 ? 32 : 16;
 }
 int gn_slices(int HW, int B) { const int cap = gn_slice_cap(B); int s = HW / 4; return s < 1 ? 1 : (s > cap ? cap : s); }
 
