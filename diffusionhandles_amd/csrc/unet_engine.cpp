@@ -917,6 +917,7 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
   bool text_grad_written = false;
   int gnb_have = 0, gnb_for = -1;       // the split-K reduce just run left the backward statistics of GroupNorm op gnb_for
   int lnb_have = 0, lnb_for = -1;       // the split-K reduce just run applied the backward of LayerNorm op lnb_for
+  int cat_done = -1;                    // the GroupNorm backward just run wrote the gradient of concatenation op cat_done to its sources
   for (int oi = (int)u->ops.size() - 1; oi >= 0; --oi) {
     const Op& o = u->ops[oi];
     switch (o.type) {
@@ -1008,11 +1009,24 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
       case OP_GN: {
         if (!u->gready[o.out]) break;
         const Ten& t = u->tens[o.in0];
+        GnBwdSplit split;
+        if (oi > 0 && u->ops[oi - 1].type == OP_CONCAT && u->ops[oi - 1].out == o.in0) {
+          // x is the concatenation made by the op in front: this GroupNorm is the last writer of its gradient, so the two
+          // halves go straight to the concatenated tensors' gradients (no k_split_cols pass) when nothing was accumulated
+          // there yet
+          const Op& cat = u->ops[oi - 1];
+          const int ca = u->tens[cat.in0].C;
+          if (!u->gready[cat.in0] && !u->gready[cat.in1] && ca % 8 == 0 && ca + u->tens[cat.in1].C == t.C) {
+            split.out0 = u->gptr(cat.in0); split.out1 = u->gptr(cat.in1); split.split_c = ca;
+            cat_done = oi - 1;
+          }
+        }
         launch_groupnorm_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->pf + o.gamma_off, u->pf + o.beta_off,
                              u->f32a + o.stats_off, u->gptr(o.in0), u->small, B, t.rows, t.C, o.groups, o.silu,
-                             u->gready[o.in0] ? 1 : 0, st, gnb_have && gnb_for == oi);
+                             u->gready[o.in0] ? 1 : 0, st, gnb_have && gnb_for == oi, split);
         gnb_have = 0;
         u->gready[o.in0] = 1;
+        if (split.out0) { u->gready[u->ops[oi - 1].in0] = 1; u->gready[u->ops[oi - 1].in1] = 1; }
         break;
       }
       case OP_LN: {
@@ -1068,6 +1082,7 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
       }
       case OP_CONCAT: {
         if (!u->gready[o.out]) break;
+        if (cat_done == oi) { cat_done = -1; break; }     // written by the GroupNorm backward behind it
         const Ten &a = u->tens[o.in0], &b2 = u->tens[o.in1], &t = u->tens[o.out];
         launch_split_cols(dt, u->gptr(o.out), t.C, u->gptr(o.in0), a.C, a.C, u->gready[o.in0] ? 1 : 0, u->gptr(o.in1), b2.C,
                           b2.C, u->gready[o.in1] ? 1 : 0, B * t.rows, st);

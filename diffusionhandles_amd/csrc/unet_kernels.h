@@ -80,9 +80,12 @@ constexpr int GN_GB = 4;        // groups per statistics workgroup
 void launch_concat_gn(int dtype, const void* a, int Ca, const void* b, int Cb, void* out, float* gn_part, int B, int HW,
                       int G, hipStream_t st);
 // dx (=|+=) d gn-act / d x
+// (the gradient of a concatenation written in place of the concatenated gradient: columns [0, split_c) of every row go to
+// split0 (row stride split_c), the rest to split1 (row stride C - split_c); `accumulate` still reads the addend from dx)
+struct GnBwdSplit { void* out0 = nullptr; void* out1 = nullptr; int split_c = 0; };
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
-                          int accumulate, hipStream_t st, int have_partials = 0);
+                          int accumulate, hipStream_t st, int have_partials = 0, GnBwdSplit split = GnBwdSplit());
 // LayerNorm over C per row; stats [rows][2]
 void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           int rows, int C, float eps, hipStream_t st);

@@ -397,7 +397,8 @@ void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const fl
 template <class T, bool WIDE>
 __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, const float* gamma, const float* beta,
                                                       const float* stats, const float* part, T* dx, int HW, int C, int G,
-                                                      int S, int silu, int accumulate, int iters) {
+                                                      int S, int silu, int accumulate, int iters, T* split0, T* split1,
+                                                      int split_c) {
   __shared__ float4 sm_st[64];     // mean, rstd, mean(dxhat), mean(dxhat*xhat)
   const int b = blockIdx.y, cpg = C / G;
   const float inv_cpg = 1.f / (float)cpg;
@@ -472,7 +473,10 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
       if (accumulate) r += to_f32<T>(ov[i]);
       o[i] = from_f32<T>(r);
     }
-    *reinterpret_cast<uint4*>(dx + row * C + c0) = __builtin_bit_cast(uint4, o);
+    // (split0 != NULL: x is a concatenation and the gradient goes straight to its two sources; split_c % 8 == 0)
+    T* dst = !split0 ? dx + row * C + c0
+                     : (c0 < split_c ? split0 + row * split_c + c0 : split1 + row * (C - split_c) + (c0 - split_c));
+    *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, o);
     if (!nlive) return;
     idx = nidx; row = nrow; c0 = nc0; rx = nrx; rd = nrd; ro = nro;
 #pragma unroll
@@ -482,7 +486,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(const T* x, const T* dy, c
 
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
-                          int accumulate, hipStream_t st, int have_partials) {
+                          int accumulate, hipStream_t st, int have_partials, GnBwdSplit split) {
   DH_ABLATE(2);
   const int S = gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
@@ -490,12 +494,12 @@ void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float*
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);
   if (dtype == DH_DTYPE_F16) {
     if (!have_partials) hipLaunchKernelGGL((k_gn_partial<f16, true>), g1, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
-    if (C / G >= 8) hipLaunchKernelGGL((k_gn_bwd_apply<f16, true>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate, iters);
-    else hipLaunchKernelGGL((k_gn_bwd_apply<f16, false>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate, iters);
+    if (C / G >= 8) hipLaunchKernelGGL((k_gn_bwd_apply<f16, true>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate, iters, (f16*)split.out0, (f16*)split.out1, split.split_c);
+    else hipLaunchKernelGGL((k_gn_bwd_apply<f16, false>), g2, dim3(256), 0, st, (const f16*)x, (const f16*)dy, gamma, beta, stats, scratch, (f16*)dx, HW, C, G, S, silu, accumulate, iters, (f16*)split.out0, (f16*)split.out1, split.split_c);
   } else {
     if (!have_partials) hipLaunchKernelGGL((k_gn_partial<bf16, true>), g1, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, HW, C, G, S, silu);
-    if (C / G >= 8) hipLaunchKernelGGL((k_gn_bwd_apply<bf16, true>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate, iters);
-    else hipLaunchKernelGGL((k_gn_bwd_apply<bf16, false>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate, iters);
+    if (C / G >= 8) hipLaunchKernelGGL((k_gn_bwd_apply<bf16, true>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate, iters, (bf16*)split.out0, (bf16*)split.out1, split.split_c);
+    else hipLaunchKernelGGL((k_gn_bwd_apply<bf16, false>), g2, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, scratch, (bf16*)dx, HW, C, G, S, silu, accumulate, iters, (bf16*)split.out0, (bf16*)split.out1, split.split_c);
   }
 }
 
