@@ -876,7 +876,10 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   const bool n320 = kN320 > 0 && k.N == 320 && BM == 128 && BN == 64 && cdiv(k.M, 128) >= kN320;
   if (n320) BN = 320;
   // grids that fill the machine: 256x128 tiles, eight waves (see MW)
-  const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && (long)cdiv(k.M, 256) * cdiv(k.N, 128) >= kMwBlocks;
+  // (not when M <= 256 leaves a single row of 256-row tiles on fewer than half of the CUs: two rows of 128x128 eight-wave
+  // tiles put twice the workgroups on the same K loop -- M = 256, N = 10240, K = 1280: 22.4 -> 15.5 us)
+  const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && (long)cdiv(k.M, 256) * cdiv(k.N, 128) >= kMwBlocks &&
+                   !(k.M <= 256 && k.M > 128 && cdiv(k.N, 128) < 128);
   if (mw2) { BM = 256; BN = 128; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
