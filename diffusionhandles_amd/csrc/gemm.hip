@@ -878,8 +878,13 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   // grids that fill the machine: 256x128 tiles, eight waves (see MW)
   // (not when M <= 256 leaves a single row of 256-row tiles on fewer than half of the CUs: two rows of 128x128 eight-wave
   // tiles put twice the workgroups on the same K loop -- M = 256, N = 10240, K = 1280: 22.4 -> 15.5 us)
-  const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && (long)cdiv(k.M, 256) * cdiv(k.N, 128) >= kMwBlocks &&
-                   !(k.M <= 256 && k.M > 128 && cdiv(k.N, 128) < 128);
+  // and in general not for short K loops on fewer than half of the CUs (per-shape sweep, tools/sweep_gemm_shapes.py:
+  // M = 1024, N = 2560, K = 640: 16.6 -> 12.8 us; M = 512, N = 5120, K = 1280: 25.2 -> 20.2 us as 128x128 tiles); long K
+  // loops keep the big tile, they split K over workgroups anyway
+  DH_KNOB(kMwShortK, "DH_GEMM_MW_SHORTK", 128);
+  const long tiles256 = (long)cdiv(k.M, 256) * cdiv(k.N, 128);
+  const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && tiles256 >= kMwBlocks &&
+                   !(k.M <= 256 && k.M > 128 && cdiv(k.N, 128) < 128) && (tiles256 >= kMwShortK || ktiles >= kSplitMinK);
   if (mw2) { BM = 256; BN = 128; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
@@ -891,6 +896,28 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
     if ((size_t)splits > fit) splits = (int)fit;
     if (splits < 1) splits = 1;
   }
+#ifdef DH_TUNING
+  // per-shape policy search (tools/sweep_gemm_shapes.py): DH_GEMM_LOG=1 prints every dispatch, DH_FORCE_TILE / DH_FORCE_SPLITS override
+  // the choice (1 = 64x64, 2 = 128x64 two K groups, 3 = 128x64, 4 = 128x128 eight waves, 5 = 128x128, 6 = 256x128 eight waves)
+  static const int kLog = getenv("DH_GEMM_LOG") ? atoi(getenv("DH_GEMM_LOG")) : 0;
+  const int kForceTile = getenv("DH_FORCE_TILE") ? atoi(getenv("DH_FORCE_TILE")) : 0;          // (re-read per dispatch: one process sweeps)
+  const int kForceSplits = getenv("DH_FORCE_SPLITS") ? atoi(getenv("DH_FORCE_SPLITS")) : 0;
+  int force_tile = 0;
+  if (kForceTile) {
+    const int fbm = kForceTile == 1 ? 64 : (kForceTile == 6 ? 256 : 128), fbn = (kForceTile <= 3) ? 64 : 128;
+    if (k.N % fbn == 0 || fbn == 64) { BM = fbm; BN = fbn; force_tile = kForceTile; }
+  }
+  if (kForceSplits && k.partial && !lnf) {
+    splits = kForceSplits;
+    if (splits > ktiles / 2) splits = ktiles / 2 > 0 ? ktiles / 2 : 1;
+    const size_t fit = partial_elems / ((size_t)k.M * k.N);
+    if ((size_t)splits > fit) splits = (int)fit;
+    if (splits < 1) splits = 1;
+  }
+  if (kLog) fprintf(stderr, "GEMMLOG M=%d N=%d K=%d mode=%d lnf=%d gn=%d gnb=%d bias=%d R=%d rowvec=%d | BM=%d BN=%d splits=%d\n", k.M, k.N, k.K,
+                    k.mode == A_DENSE ? 0 : (k.mode == A_CONV3 && k.stride == 1 && k.up == 0 ? 1 : 2), (int)lnf, k.gn_part != nullptr,
+                    k.gnb_x != nullptr, k.bias != nullptr, k.R != nullptr, k.rowvec != nullptr, BM, BN, splits);
+#endif
   const int tiles_per_split = cdiv(ktiles, splits);
   splits = cdiv(ktiles, tiles_per_split);
   k.splits = splits;
@@ -901,7 +928,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   k.lnf_abl = kLnfAbl;
   k.ts = g_gemm_ts;
 #endif
+#ifdef DH_TUNING
+  dim3 grid(force_tile ? cdiv(k.M, BM) : tm, force_tile ? cdiv(k.N, BN) : tn, splits);
+#else
   dim3 grid(tm, tn, splits);
+#endif
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof.on) {
     if (g_prof.used + 2 > g_prof.ev.size()) {
@@ -927,6 +958,12 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (kAbl == 2 && mw2 && gm == GM_CONV_S1) { hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_CONV_S1, 2, 1, 1, 2>), grid, dim3(512), 0, st, k); }
   else if (kAbl == 1 && mw2 && gm == GM_DENSE && !lnf) { hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_DENSE, 1, 1, 1, 2>), grid, dim3(512), 0, st, k); }
   else if (kAbl == 2 && mw2 && gm == GM_DENSE && !lnf) { hipLaunchKernelGGL((k_gemm_dma<T, 256, 128, 3, GM_DENSE, 2, 1, 1, 2>), grid, dim3(512), 0, st, k); }
+  else if (force_tile == 1) launch_tile<T, 64, 64, 4, 1, 1, 1>(gm, lnf, grid, st, k);
+  else if (force_tile == 2) launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k);
+  else if (force_tile == 3) launch_tile<T, 128, 64, 5, 1, 1, 1>(gm, lnf, grid, st, k);
+  else if (force_tile == 4) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k);
+  else if (force_tile == 5) launch_tile<T, 128, 128, 4, 1, 1, 1>(gm, lnf, grid, st, k);
+  else if (force_tile == 6) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k);
   else
 #endif
   if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k);

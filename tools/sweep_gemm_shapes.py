@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Per-shape search of the GEMM tile / split-K policy (tuning build: DH_FORCE_TILE / DH_FORCE_SPLITS are re-read per dispatch).
+
+  run   : DIFFHANDLES_LIB=tools/bin/libdiffhandles_hip_tuning.so rocprofv3 --kernel-trace --output-format csv -d DIR -- \
+              python3 tools/sweep_gemm_shapes.py run gpurun_out/r2_gemmlog.txt gpurun_out/sweep_manifest.json
+          every (shape, tile, splits) candidate is launched REPS times, each behind a 1 GiB streaming pass that evicts L2 and the
+          Infinity Cache (the weights of a layer are HBM-cold in the step)
+  parse : python3 tools/sweep_gemm_shapes.py parse manifest.json kernel_trace.csv   -> per shape: policy choice vs best candidate
+"""
+import collections, csv, ctypes, json, os, re, sys
+
+REPS = 4
+TILES = {0: "policy", 1: "64x64", 2: "128x64 kg2", 3: "128x64", 4: "128x128 mw2", 5: "128x128", 6: "256x128 mw2"}
+
+
+def shapes_from_log(path):
+    c = collections.Counter()
+    for l in open(path):
+        m = re.search(r"GEMMLOG M=(\d+) N=(\d+) K=(\d+) mode=(\d) lnf=(\d) gn=(\d) gnb=(\d)(?: count=(\d+))?", l)
+        if m:
+            c[tuple(int(x) for x in m.groups()[:5])] += int(m.group(8) or 1)            # (M, N, K, mode, lnf)
+    return c
+
+
+def candidates(M, N, K, mode, lnf):
+    kt = K // 64
+    out = [(0, 0)]
+    for tile in (1, 2, 3, 4, 5, 6):
+        bm = 64 if tile == 1 else (256 if tile == 6 else 128)
+        bn = 64 if tile <= 3 else 128
+        if N % bn and bn == 128:
+            continue
+        if bm == 256 and M <= 128:
+            continue
+        for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+            if sp > 1 and (lnf or kt // sp < 4):
+                continue
+            tiles = -(-M // bm) * -(-N // bn)
+            if tiles * sp > 1024:
+                continue
+            out.append((tile, sp))
+    return out
+
+
+def run(log, manifest):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    from diffusionhandles_amd import _lib
+    os.environ["DH_DBG_PRETILED"] = "1"
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    part = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    junk = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    shapes = shapes_from_log(log)
+    plan = []
+    for (M, N, K, mode, lnf), cnt in sorted(shapes.items()):
+        if lnf:
+            continue                                                  # the debug hook has no folded-LayerNorm inputs; its tiles follow the dense rule
+        dt = torch.float16
+        if mode == 1:
+            Cin = K // 9
+            H = int(round((M if M <= 4096 else M // 2) ** 0.5)); B = M // (H * H)
+            A = torch.randn(B * H * H, Cin, device=dev).to(dt); lda = Cin; geo = (H, H, Cin, H, H, 1, 0); gm = 1
+        elif mode == 2:
+            continue                                                  # stride-2 / upsampling convolutions: a handful of launches
+        else:
+            A = torch.randn(M, K, device=dev).to(dt); lda = K; geo = (0, 0, 0, 0, 0, 1, 0); gm = 0
+        W = torch.randn(N, K, device=dev).to(dt)
+        bias = torch.randn(N, device=dev)
+        C = torch.empty(M, N, dtype=dt, device=dev)
+        for tile, sp in candidates(M, N, K, mode, lnf):
+            os.environ["DH_FORCE_TILE"] = str(tile)
+            os.environ["DH_FORCE_SPLITS"] = str(sp)
+            ok = 0
+            for _ in range(REPS):
+                junk.add_(1.0)
+                rc = L.dh_dbg_gemm(0, P(A), lda, P(W), M, N, K, gm, *geo, P(bias), P(None), 0, 1, P(None), N, P(C), N, 0, P(part),
+                                   part.numel(), _lib.stream_ptr())
+                ok += rc == 0
+            if ok == REPS:
+                plan.append(dict(M=M, N=N, K=K, mode=mode, count=cnt, tile=tile, splits=sp))
+            else:
+                assert ok == 0, "a candidate launched only some of its repetitions"
+        torch.cuda.synchronize()
+    json.dump(dict(reps=REPS, plan=plan), open(manifest, "w"))
+    print("candidates", len(plan))
+
+
+def parse(manifest, trace):
+    man = json.load(open(manifest))
+    rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+    # sequence: [evict (torch add)] [k_gemm_dma] [optional k_splitk_reduce*] per repetition
+    groups, cur = [], None
+    for r in rows:
+        n = r["Kernel_Name"]
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        if "k_gemm_dma" in n:
+            cur = [d, 0.0]; groups.append(cur)
+        elif "k_splitk_reduce" in n and cur is not None:
+            cur[1] += d
+        elif "k_tile_weights" in n:
+            pass
+        else:
+            cur = None if "k_gemm_dma" not in n and "splitk" not in n else cur
+    reps = man["reps"]
+    assert len(groups) == reps * len(man["plan"]), (len(groups), reps * len(man["plan"]))
+    by = collections.defaultdict(list)
+    for i, c in enumerate(man["plan"]):
+        g = groups[i * reps:(i + 1) * reps]
+        t = sorted(a + b for a, b in g)[len(g) // 2]                  # median of GEMM + reduce
+        by[(c["M"], c["N"], c["K"], c["mode"], c["count"])].append((t, c["tile"], c["splits"]))
+    tot_pol = tot_best = 0.0
+    for key, cands in sorted(by.items(), key=lambda kv: -kv[0][4]):
+        pol = [c for c in cands if c[1] == 0][0]
+        best = min(c for c in cands if c[1] != 0)
+        tot_pol += pol[0] * key[4]; tot_best += min(best[0], pol[0]) * key[4]
+        flag = "  <<<" if best[0] < 0.9 * pol[0] else ""
+        print(f"M={key[0]:5d} N={key[1]:5d} K={key[2]:6d} mode={key[3]} x{key[4]:3d}: policy {pol[0]:7.1f} us   best {best[0]:7.1f} us "
+              f"({TILES[best[1]]}, splits {best[2]}){flag}")
+    print(f"weighted total: policy {tot_pol:.0f} us, per-shape best {tot_best:.0f} us ({100 * (1 - tot_best / tot_pol):.1f} % less)")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(sys.argv[2], sys.argv[3])
+    else:
+        parse(sys.argv[2], sys.argv[3])
