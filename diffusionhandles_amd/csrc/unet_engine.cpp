@@ -852,8 +852,6 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   const dh_unet_config& c = u->cfg;
   const size_t ns = (size_t)B * c.sample_size * c.sample_size;
   DH_CHECK_HIP(hipMemcpyAsync(u->in_sample, sample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
-  DH_CHECK_HIP(hipMemcpyAsync(u->in_text, text, (size_t)B * c.text_len * c.cross_attention_dim * 4, hipMemcpyDeviceToDevice, st));
-  launch_set_scalar(u->t_dev, timestep, st);
   // without eps_out the tape stops after the last requested activation (the tail's only consumer is eps)
   int n_ops = (int)u->ops.size();
   if (!eps_out) {
@@ -866,6 +864,10 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   const bool temb_hit = u->temb_rows >= B && u->temb_t == timestep && u->temb_stream == st;
   const bool kv_hit = u->text_key != 0 && u->text_key == u->kv_key && u->kv_rows == B && u->kv_stream == st;
   const int first_op = temb_hit ? u->temb_ops : 0;
+  // the text and the timestep are only read by the ops a cache hit skips (K|V projection of the text; time embedding)
+  if (!kv_hit)
+    DH_CHECK_HIP(hipMemcpyAsync(u->in_text, text, (size_t)B * c.text_len * c.cross_attention_dim * 4, hipMemcpyDeviceToDevice, st));
+  if (!temb_hit) launch_set_scalar(u->t_dev, timestep, st);
   int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit, kv_hit), st, &u->flops_fwd,
                        [&]() { forward_ops(u, B, n_ops, first_op, kv_hit, st); });
   if (rc != DH_OK) { u->temb_rows = 0; u->kv_key = 0; return rc; }      // nothing cached after a failed capture / launch
