@@ -7,6 +7,10 @@
 struct Big { float v[60]; int n; float* out; };
 
 __global__ void k_triv(float* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1.f; }
+// no kernel arguments at all: what the argument fetch (s_load of the kernarg segment, cold in every kernel) adds to a launch
+__device__ float g_sink[64];
+__global__ void k_noarg() { if (threadIdx.x == 0 && blockIdx.x == 0) g_sink[0] += 1.f; }
+__global__ void k_empty() {}
 template <int I> __global__ void k_var(float* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[I] += (float)I; }
 __global__ void k_big(const Big b) { if (threadIdx.x == 0 && blockIdx.x == 0) b.out[0] += b.v[b.n]; }
 // streaming: y = x + 1 over n floats (dependent chain through memory)
@@ -80,6 +84,8 @@ int main() {
     const int N = 2000;
     run("trivial <<<1,64>>>", st, N, graph, [&](int) { hipLaunchKernelGGL(k_triv, dim3(1), dim3(64), 0, st, p); });
     run("trivial <<<256,256>>>", st, N, graph, [&](int) { hipLaunchKernelGGL(k_triv, dim3(256), dim3(256), 0, st, p); });
+    run("no-argument kernel, same work <<<256,256>>>", st, N, graph, [&](int) { hipLaunchKernelGGL(k_noarg, dim3(256), dim3(256), 0, st); });
+    run("empty kernel (s_endpgm) <<<256,256>>>", st, N, graph, [&](int) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st); });
     run("trivial <<<2048,256>>>", st, N, graph, [&](int) { hipLaunchKernelGGL(k_triv, dim3(2048), dim3(256), 0, st, p); });
     run("8 different trivial kernels alternating <<<256,256>>>", st, N, graph, [&](int i) {
       switch (i & 7) {
