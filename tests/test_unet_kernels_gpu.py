@@ -161,7 +161,7 @@ def test_geglu(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 5, 1024, 1024), (2, 2, 256, 256), (1, 20, 64, 64), (2, 5, 1024, 77), (1, 10, 200, 77), (1, 5, 4096, 77), (1, 2, 4096, 4096)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 5, 1024, 1024), (2, 2, 256, 256), (1, 20, 64, 64), (2, 5, 1024, 77), (1, 10, 200, 77), (1, 5, 4096, 77), (1, 2, 4096, 4096), (1, 3, 1000, 1000), (1, 2, 1100, 600)])
 def test_attention_forward_backward(dtype, B, H, Nq, Nk):
     g = torch.Generator(device=dev()).manual_seed(Nq + Nk + H)
     C = H * 64
