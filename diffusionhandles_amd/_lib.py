@@ -78,6 +78,8 @@ SIGNATURES = {
     "dh_vae_decoder_load_param": (c_i, [c_p, c_i, c_p, c_p]),
     "dh_vae_decoder_bytes": (c_sz, [c_p]),
     "dh_vae_decoder_decode": (c_i, [c_p, c_p, c_i, c_p, c_p]),
+    "dh_vae_encoder_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
+    "dh_vae_encoder_encode": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "dh_gemm_profile_begin": (c_i, []),
     "dh_gemm_profile_end": (c_i, [ctypes.POINTER(c_d), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(c_d)]),
     "dh_ddim_cfg_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_p]),

@@ -58,7 +58,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   const void* A; long lda;
   const void* W;
   int M, N, K;
-  int mode, Hin, Win, Cin, Hout, Wout, stride, up;
+  int mode, Hin, Win, Cin, Hout, Wout, stride, up, pad;
   const float* bias;
   const float* rowvec; int rowvec_ld; int rows_per_batch; float inv_rows_per_batch;
   const void* R; long ldr;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         bool ok = a_ok[j];
         int sy, sx;
         if (p.mode == A_CONV3) {
-          const int iy = a_oy[j] * p.stride + ky - 1, ix = a_ox[j] * p.stride + kx - 1;
+          const int iy = a_oy[j] * p.stride + ky - p.pad, ix = a_ox[j] * p.stride + kx - p.pad;
           ok = ok && iy >= 0 && ix >= 0 && iy < (p.Hin << p.up) && ix < (p.Win << p.up);
           sy = iy >> p.up; sx = ix >> p.up;
         } else {
@@ -947,7 +947,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   }
   int gm = GM_GENERIC;
   if (k.mode == A_DENSE) gm = GM_DENSE;
-  else if (k.mode == A_CONV3 && k.stride == 1 && k.up == 0) gm = GM_CONV_S1;
+  else if (k.mode == A_CONV3 && k.stride == 1 && k.up == 0 && k.pad == 1) gm = GM_CONV_S1;
 #ifdef DH_TUNING
   // ablations of the K loop (timing only): 1 = no LDS reads / MFMA, 2 = no DMA in the loop, 3 = 1 on the dense kernel
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
@@ -1000,7 +1000,7 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   GemmK k;
   k.A = a.A; k.lda = a.lda; k.W = a.W; k.M = a.M; k.N = a.N; k.K = a.K;
   k.mode = a.mode; k.Hin = a.Hin; k.Win = a.Win; k.Cin = a.Cin; k.Hout = a.Hout; k.Wout = a.Wout;
-  k.stride = a.stride; k.up = a.up;
+  k.stride = a.stride; k.up = a.up; k.pad = a.pad;
   k.bias = a.bias; k.rowvec = a.rowvec; k.rowvec_ld = a.rowvec_ld;
   k.rows_per_batch = a.rows_per_batch > 0 ? a.rows_per_batch : 1;
   k.inv_rows_per_batch = 1.f / (float)k.rows_per_batch;

@@ -20,6 +20,8 @@ struct GemmArgs {
   int Hin = 0, Win = 0, Cin = 0;           // source tensor spatial size, channels per tap
   int Hout = 0, Wout = 0;                  // output spatial size (M = B*Hout*Wout)
   int stride = 1, up = 0;
+  int pad = 1;                             // A_CONV3: zero padding on the top / left (1 = the usual 'same' 3x3; 0 with stride 2 = the
+                                           // VAE encoder's down-sampler, which pads bottom / right only)
   const float* bias = nullptr;             // [N]
   const float* rowvec = nullptr; int rowvec_ld = 0; int rows_per_batch = 1;
   const void* R = nullptr; long ldr = 0;   // residual added after everything else

@@ -69,7 +69,7 @@ struct VParam { std::string name; int ndim; int64_t shape[4]; int wt; int row_of
 struct VOpRec {
   int type, in0, out, res = -1, wt = -1;
   long bias = -1, gamma = -1, beta = -1;
-  int Hin = 0, Cin = 0, Hout = 0, up = 0, silu = 0;
+  int Hin = 0, Cin = 0, Hout = 0, up = 0, silu = 0, stride = 1, pad = 1;
   float eps = 1e-6f;
   size_t stats = 0;
 };
@@ -89,6 +89,7 @@ struct dh_vae_decoder {
   float *pf = nullptr, *f32a = nullptr, *small = nullptr, *partial = nullptr;
   size_t partial_elems = 0;
   int t_out = -1;
+  bool encoder = false;       // the tape is AutoencoderKL.encoder (image in, 2 * latent_channels moments out)
 };
 
 namespace {
@@ -134,10 +135,11 @@ struct VB {
     v.ops.push_back(o);
     return o.out;
   }
-  int conv3(int x, const std::string& pre, int Cout, int up, int res) {
+  int conv3(int x, const std::string& pre, int Cout, int up, int res, int stride = 1, int pad = 1) {
     const VTen t = v.tens[x];
     VOpRec o;
-    o.type = V_CONV; o.in0 = x; o.res = res; o.Hin = t.H; o.Cin = t.C; o.up = up; o.Hout = t.H << up;
+    o.type = V_CONV; o.in0 = x; o.res = res; o.Hin = t.H; o.Cin = t.C; o.up = up; o.stride = stride; o.pad = pad;
+    o.Hout = stride == 2 ? t.H / 2 : t.H << up;
     o.wt = weight(Cout, 9 * t.C, 9, false);
     bind(pre + ".weight", o.wt, Cout, 0, t.C, 9);
     o.bias = pf32(pre + ".bias", Cout);
@@ -162,6 +164,35 @@ struct VB {
     }
     return conv3(h, pre + ".conv2", Cout, 0, sc);
   }
+  // single-head self-attention over the H*H tokens with a residual connection (the VAE mid block)
+  int attention(int x, const std::string& pre) {
+    const int Ctop = v.tens[x].C, S = v.tens[x].H;
+    int t = gn(x, pre + ".group_norm", false);
+    VOpRec q;
+    q.type = V_LINEAR; q.in0 = t; q.wt = weight(3 * Ctop, Ctop, 1, false);
+    const float sc = 1.f / sqrtf((float)Ctop);            // the softmax scale is folded into the q projection
+    bind(pre + ".to_q.weight", q.wt, Ctop, 0, Ctop, 1, sc);
+    bind(pre + ".to_k.weight", q.wt, Ctop, Ctop, Ctop, 1);
+    bind(pre + ".to_v.weight", q.wt, Ctop, 2 * Ctop, Ctop, 1);
+    q.bias = (long)v.pf_elems; v.pf_elems += align_up((size_t)3 * Ctop, 64);
+    pf32_at(pre + ".to_q.bias", Ctop, q.bias, sc);
+    pf32_at(pre + ".to_k.bias", Ctop, q.bias + Ctop, 1.f);
+    pf32_at(pre + ".to_v.bias", Ctop, q.bias + 2 * Ctop, 1.f);
+    q.out = tensor(S, 3 * Ctop);
+    v.ops.push_back(q);
+    VOpRec a;
+    a.type = V_ATTN; a.in0 = q.out; a.out = tensor(S, Ctop);
+    v.ops.push_back(a);
+    VOpRec o;
+    o.type = V_LINEAR; o.in0 = a.out; o.res = x; o.wt = weight(Ctop, Ctop, 1, false);
+    bind(pre + ".to_out.0.weight", o.wt, Ctop, 0, Ctop, 1);
+    o.bias = pf32(pre + ".to_out.0.bias", Ctop);
+    o.out = tensor(S, Ctop);
+    v.ops.push_back(o);
+    v.scores_elems = (size_t)S * S * S * S;
+    v.tiled_elems = (size_t)S * S * Ctop;
+    return o.out;
+  }
 };
 
 int build(dh_vae_decoder& v) {
@@ -178,33 +209,7 @@ int build(dh_vae_decoder& v) {
     o.bias = b.pf32("decoder.conv_in.bias", Ctop);
     v.ops.push_back(o); }
   x = b.resnet(x, "decoder.mid_block.resnets.0", Ctop);
-  { // single-head self-attention over the S*S tokens, residual connection
-    const std::string pre = "decoder.mid_block.attentions.0";
-    int t = b.gn(x, pre + ".group_norm", false);
-    VOpRec q;
-    q.type = V_LINEAR; q.in0 = t; q.wt = b.weight(3 * Ctop, Ctop, 1, false);
-    const float sc = 1.f / sqrtf((float)Ctop);            // the softmax scale is folded into the q projection
-    b.bind(pre + ".to_q.weight", q.wt, Ctop, 0, Ctop, 1, sc);
-    b.bind(pre + ".to_k.weight", q.wt, Ctop, Ctop, Ctop, 1);
-    b.bind(pre + ".to_v.weight", q.wt, Ctop, 2 * Ctop, Ctop, 1);
-    q.bias = (long)v.pf_elems; v.pf_elems += align_up((size_t)3 * Ctop, 64);
-    b.pf32_at(pre + ".to_q.bias", Ctop, q.bias, sc);
-    b.pf32_at(pre + ".to_k.bias", Ctop, q.bias + Ctop, 1.f);
-    b.pf32_at(pre + ".to_v.bias", Ctop, q.bias + 2 * Ctop, 1.f);
-    q.out = b.tensor(S, 3 * Ctop);
-    v.ops.push_back(q);
-    VOpRec a;
-    a.type = V_ATTN; a.in0 = q.out; a.out = b.tensor(S, Ctop);
-    v.ops.push_back(a);
-    VOpRec o;
-    o.type = V_LINEAR; o.in0 = a.out; o.res = x; o.wt = b.weight(Ctop, Ctop, 1, false);
-    b.bind(pre + ".to_out.0.weight", o.wt, Ctop, 0, Ctop, 1);
-    o.bias = b.pf32(pre + ".to_out.0.bias", Ctop);
-    o.out = b.tensor(S, Ctop);
-    v.ops.push_back(o);
-    x = o.out;
-    v.scores_elems = (size_t)S * S * S * S;
-    v.tiled_elems = (size_t)S * S * Ctop; }
+  x = b.attention(x, "decoder.mid_block.attentions.0");
   x = b.resnet(x, "decoder.mid_block.resnets.1", Ctop);
   for (int i = 0; i < L; ++i) {
     const int co = ch[L - 1 - i];
@@ -226,9 +231,47 @@ int build(dh_vae_decoder& v) {
   v.small_elems = (size_t)64 * 4096 + 4096;
   return DH_OK;
 }
+
+// AutoencoderKL.encoder: conv_in, four down blocks (two ResNets each, a stride-2 convolution padded bottom / right behind
+// the first three), the mid block, GroupNorm + SiLU + conv_out to 2 * latent_channels moments
+int build_encoder(dh_vae_decoder& v) {
+  const dh_vae_config& c = v.cfg;
+  VB b(v);
+  const int* ch = c.block_out_channels;        // 128 256 512 512
+  const int L = 4, R = 8 * c.latent_size;
+  v.encoder = true;
+  int x = b.tensor(R, ch[0]);
+  { VOpRec o;
+    o.type = V_CONV_IN; o.out = x; o.Hin = R; o.Cin = c.out_channels;
+    o.wt = b.weight(ch[0], 9 * c.out_channels, 9, true);
+    b.bind("encoder.conv_in.weight", o.wt, ch[0], 0, c.out_channels, 9);
+    o.bias = b.pf32("encoder.conv_in.bias", ch[0]);
+    v.ops.push_back(o); }
+  for (int i = 0; i < L; ++i) {
+    const std::string pre = "encoder.down_blocks." + std::to_string(i);
+    for (int j = 0; j < c.layers_per_block; ++j) x = b.resnet(x, pre + ".resnets." + std::to_string(j), ch[i]);
+    if (i < L - 1) x = b.conv3(x, pre + ".downsamplers.0.conv", ch[i], 0, -1, 2, 0);
+  }
+  x = b.resnet(x, "encoder.mid_block.resnets.0", ch[L - 1]);
+  x = b.attention(x, "encoder.mid_block.attentions.0");
+  x = b.resnet(x, "encoder.mid_block.resnets.1", ch[L - 1]);
+  x = b.gn(x, "encoder.conv_norm_out", true);
+  { VOpRec o;
+    o.type = V_CONV_OUT; o.in0 = x; o.Hin = v.tens[x].H; o.Cin = v.tens[x].C;
+    o.wt = b.weight(2 * c.latent_channels, 9 * o.Cin, 9, true);
+    b.bind("encoder.conv_out.weight", o.wt, 2 * c.latent_channels, 0, o.Cin, 9);
+    o.bias = b.pf32("encoder.conv_out.bias", 2 * c.latent_channels);
+    v.ops.push_back(o); }
+  v.t_out = x;
+  size_t biggest = 0;
+  for (const VTen& t : v.tens) biggest = std::max(biggest, (size_t)t.H * t.H * t.C);
+  v.partial_elems = std::max<size_t>((size_t)16 << 20, biggest);
+  v.small_elems = (size_t)64 * 4096 + 4096;
+  return DH_OK;
+}
 }  // namespace
 
-extern "C" int dh_vae_decoder_create(const dh_vae_config* cfg, dh_vae_decoder** out) {
+static int vae_create(const dh_vae_config* cfg, dh_vae_decoder** out, bool encoder) {
   DH_REQUIRE(cfg && out, "null pointer");
   DH_REQUIRE(cfg->dtype == DH_DTYPE_F16 || cfg->dtype == DH_DTYPE_BF16, "dtype must be f16 or bf16");
   DH_REQUIRE(cfg->latent_size >= 8 && cfg->latent_size % 8 == 0, "latent size must be a multiple of 8");
@@ -241,7 +284,7 @@ extern "C" int dh_vae_decoder_create(const dh_vae_config* cfg, dh_vae_decoder** 
   dh_vae_decoder* v = new dh_vae_decoder();
   v->cfg = *cfg;
   v->dtype = cfg->dtype;
-  int rc = build(*v);
+  int rc = encoder ? build_encoder(*v) : build(*v);
   if (rc != DH_OK) { delete v; return rc; }
   auto fail = [&](hipError_t e, const char* what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -261,6 +304,12 @@ extern "C" int dh_vae_decoder_create(const dh_vae_config* cfg, dh_vae_decoder** 
   (void)hipMemset(v->pf, 0, v->pf_elems * 4);
   *out = v;
   return DH_OK;
+}
+
+extern "C" int dh_vae_decoder_create(const dh_vae_config* cfg, dh_vae_decoder** out) { return vae_create(cfg, out, false); }
+extern "C" int dh_vae_encoder_create(const dh_vae_config* cfg, dh_vae_decoder** out) {
+  DH_REQUIRE(cfg && 2 * cfg->latent_channels <= 8, "the moments (2 * latent_channels) must fit the few-output convolution (<= 8)");
+  return vae_create(cfg, out, true);
 }
 
 extern "C" void dh_vae_decoder_destroy(dh_vae_decoder* v) {
@@ -307,16 +356,19 @@ extern "C" size_t dh_vae_decoder_bytes(const dh_vae_decoder* v) {
   return v ? (v->w16_elems + v->act_elems + v->scores_elems + v->tiled_elems) * 2 + (v->pf_elems + v->f32_elems + v->small_elems + v->partial_elems) * 4 : 0;
 }
 
-extern "C" int dh_vae_decoder_decode(dh_vae_decoder* v, const float* z, int batch, float* image, void* stream) {
-  DH_REQUIRE(v && z && image && batch >= 1, "bad arguments");
+// one image at a time through the tape: `z` is the tape's input (decoder: latents [S][S][latent_channels]; encoder: the image
+// [8S][8S][out_channels]) and `image` its output (decoder: the image; encoder: the moments [S][S][2 * latent_channels]), f32 NHWC
+static int vae_run(dh_vae_decoder* v, const float* z, int batch, float* image, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int dt = v->dtype;
   const dh_vae_config& c = v->cfg;
   const int S = c.latent_size, R = 8 * S;
+  const size_t in_elems = v->encoder ? (size_t)R * R * c.out_channels : (size_t)S * S * c.latent_channels;
+  const size_t out_elems = v->encoder ? (size_t)S * S * 2 * c.latent_channels : (size_t)R * R * c.out_channels;
   auto aptr = [&](int t) { return v->act + v->tens[t].off; };
   for (int b = 0; b < batch; ++b) {
-    const float* zb = z + (size_t)b * S * S * c.latent_channels;
-    float* ib = image + (size_t)b * R * R * c.out_channels;
+    const float* zb = z + (size_t)b * in_elems;
+    float* ib = image + (size_t)b * out_elems;
     for (const VOpRec& o : v->ops) {
       switch (o.type) {
         case V_CONV_IN: {
@@ -336,7 +388,8 @@ extern "C" int dh_vae_decoder_decode(dh_vae_decoder* v, const float* z, int batc
           g.A = aptr(o.in0); g.lda = ti.C; g.W = v->w16 + w.off;
           g.M = to.H * to.H; g.N = w.N; g.K = w.K;
           if (o.type == V_CONV) {
-            g.mode = A_CONV3; g.Hin = o.Hin; g.Win = o.Hin; g.Cin = o.Cin; g.Hout = o.Hout; g.Wout = o.Hout; g.stride = 1; g.up = o.up;
+            g.mode = A_CONV3; g.Hin = o.Hin; g.Win = o.Hin; g.Cin = o.Cin; g.Hout = o.Hout; g.Wout = o.Hout; g.stride = o.stride; g.up = o.up;
+            g.pad = o.pad;
           }
           g.bias = v->pf + o.bias;
           if (o.res >= 0) { g.R = aptr(o.res); g.ldr = v->tens[o.res].C; }
@@ -376,4 +429,16 @@ extern "C" int dh_vae_decoder_decode(dh_vae_decoder* v, const float* z, int batc
   }
   DH_LAUNCH_CHECK();
   return DH_OK;
+}
+
+extern "C" int dh_vae_decoder_decode(dh_vae_decoder* v, const float* z, int batch, float* image, void* stream) {
+  DH_REQUIRE(v && z && image && batch >= 1, "bad arguments");
+  DH_REQUIRE(!v->encoder, "this handle is an encoder (dh_vae_encoder_create)");
+  return vae_run(v, z, batch, image, stream);
+}
+
+extern "C" int dh_vae_encoder_encode(dh_vae_decoder* v, const float* image, int batch, float* moments, void* stream) {
+  DH_REQUIRE(v && image && moments && batch >= 1, "bad arguments");
+  DH_REQUIRE(v->encoder, "this handle is a decoder (dh_vae_decoder_create)");
+  return vae_run(v, image, batch, moments, stream);
 }

@@ -198,6 +198,8 @@ class HipVAEDecoder:
     `decode(z)` has AutoencoderKL.decode's call surface (z [B,4,h,w] already divided by the scaling factor); the 1x1
     `post_quant_conv` (a 4x4 matrix per latent pixel) stays a torch op.  Weights come from an AutoencoderKL state dict."""
 
+    _CREATE = "dh_vae_decoder_create"
+
     def __init__(self, config=None, latent_size=64, dtype=torch.float16, device=None):
         import ctypes
         from . import _lib
@@ -215,7 +217,7 @@ class HipVAEDecoder:
         self._L = _lib.lib()
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self._L.dh_vae_decoder_create(ctypes.byref(cfg), ctypes.byref(h)), "dh_vae_decoder_create")
+            _lib.check(getattr(self._L, self._CREATE)(ctypes.byref(cfg), ctypes.byref(h)), self._CREATE)
         self._h = h
         self._pq_w = self._pq_b = None
         self._table = None
@@ -276,22 +278,69 @@ class HipVAEDecoder:
         return _Out(sample=img) if return_dict else (img,)
 
 
+class HipVAEEncoder(HipVAEDecoder):
+    """The encoder half of `AutoencoderKL` on the same kernels (csrc/vae_engine.cpp, `dh_vae_encoder_*`): `encode(x)` has
+    AutoencoderKL.encode's call surface (x [B,3,H,W] in [-1, 1]) and returns the latent distribution; the 1x1 `quant_conv`
+    (an 8x8 matrix per latent pixel) stays a torch op.  Weights: the `encoder.*` / `quant_conv.*` entries of the state dict."""
+
+    _CREATE = "dh_vae_encoder_create"
+
+    def load_state_dict(self, sd):
+        from . import _lib
+        st = _lib.stream_ptr()
+        for i, (name, shape) in enumerate(self.param_table()):
+            t = sd[name].detach()
+            if t.dim() == 4 and len(shape) == 2:
+                t = t.reshape(shape)
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+            t = t.to(self.device, torch.float32).contiguous()
+            _lib.check(self._L.dh_vae_decoder_load_param(self._h, i, _lib.ptr(t), st), f"load {name}")
+        m = 2 * self.config.latent_channels
+        self._q_w = sd["quant_conv.weight"].detach().to(self.device, torch.float32).reshape(m, m).contiguous()
+        self._q_b = sd["quant_conv.bias"].detach().to(self.device, torch.float32).contiguous()
+        torch.cuda.synchronize(self.device)
+        return self
+
+    def decode(self, z, return_dict=True):
+        raise NotImplementedError("this is the encoder half")
+
+    @torch.no_grad()
+    def encode(self, x, return_dict=True):
+        from . import _lib
+        B, C, H, W = x.shape
+        if H != 8 * self.latent_size or W != 8 * self.latent_size:
+            raise ValueError(f"encoder built for {8 * self.latent_size}x{8 * self.latent_size} images, got {H}x{W}")
+        xl = x.to(self.device, torch.float32).permute(0, 2, 3, 1).contiguous()          # channels-last
+        m = 2 * self.config.latent_channels
+        mom = torch.empty((B, self.latent_size, self.latent_size, m), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.dh_vae_encoder_encode(self._h, _lib.ptr(xl), B, _lib.ptr(mom), _lib.stream_ptr()),
+                   "dh_vae_encoder_encode")
+        mom = (mom @ self._q_w.t() + self._q_b).permute(0, 3, 1, 2).contiguous()         # quant_conv (1x1)
+        dist = _Gaussian(mom)
+        return _Out(latent_dist=dist) if return_dict else (dist,)
+
+
 class NativeDecodeVAE(nn.Module):
-    """AutoencoderKL whose `decode` runs on the native engine (`encode` stays PyTorch-ROCm: once per image)."""
+    """AutoencoderKL whose `decode` AND `encode` run on the native engine kernels (the module keeps the parameters)."""
 
     def __init__(self, vae, latent_size=64, dtype=torch.float16):
         super().__init__()
         self.vae, self.config = vae, vae.config
-        self._latent_size, self._dtype, self._dec = latent_size, dtype, None
+        self._latent_size, self._dtype, self._dec, self._enc = latent_size, dtype, None, None
 
     def to(self, device):
         self.vae = self.vae.to(device)
         if torch.device(device).type == "cuda":
-            self._dec = HipVAEDecoder(vars(self.vae.config), self._latent_size, self._dtype, device).load_state_dict(self.vae.state_dict())
+            sd = self.vae.state_dict()
+            self._dec = HipVAEDecoder(vars(self.vae.config), self._latent_size, self._dtype, device).load_state_dict(sd)
+            self._enc = HipVAEEncoder(vars(self.vae.config), self._latent_size, self._dtype, device).load_state_dict(sd)
         return self
 
     def encode(self, x, return_dict=True):
-        return self.vae.encode(x, return_dict)
+        if x.shape[-1] != 8 * self._latent_size or x.shape[-2] != 8 * self._latent_size:
+            return self.vae.encode(x, return_dict)          # another resolution than the engine was built for
+        return self._enc.encode(x, return_dict)
 
     def decode(self, z, return_dict=True):
         return self._dec.decode(z, return_dict)

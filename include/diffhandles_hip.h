@@ -261,6 +261,12 @@ int dh_vae_decoder_param_info(const dh_vae_decoder* v, int i, const char** name,
 int dh_vae_decoder_load_param(dh_vae_decoder* v, int i, const float* src, void* stream);   /* DEVICE f32, torch layout */
 size_t dh_vae_decoder_bytes(const dh_vae_decoder* v);
 int dh_vae_decoder_decode(dh_vae_decoder* v, const float* z, int batch, float* image, void* stream);
+/* The encoder half on the same kernels (stable_null_inverter.py:72-83 image2latent: `vae.encode(image)['latent_dist'].mean`,
+ * once per image).  The handle has the decoder's type and shares its parameter / destroy / bytes entry points; the state-dict
+ * names are "encoder.*".  image: [B][8h][8w][out_channels] f32 channels-last in [-1, 1]; moments: [B][h][w][2 * latent_channels]
+ * f32 (conv_out of the encoder: the caller applies the 1x1 quant_conv and takes the first latent_channels as the mean). */
+int dh_vae_encoder_create(const dh_vae_config* cfg, dh_vae_decoder** out);
+int dh_vae_encoder_encode(dh_vae_decoder* v, const float* image, int batch, float* moments, void* stream);
 
 #ifdef __cplusplus
 }
