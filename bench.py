@@ -163,10 +163,10 @@ def main():
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     conf = C.load_default()
     lat = args.res // 8
-    # the SD AutoencoderKL architecture with random weights, its decoder on the engine's kernels ("sd-native"): the decode on
-    # an edit's critical path is a real one (the encoder, once per image, stays PyTorch-ROCm)
+    # the SD AutoencoderKL and the SD-2 CLIP text tower with random weights, both on the engine's kernels ("sd-native" /
+    # "sd2-native"): the decode on an edit's critical path, the encode and the prompt embedding of the per-image phase are real ones
     dh = DiffusionHandles(conf, dtype=dtype, unet_config=dict(SD2_DEPTH, sample_size=lat), max_batch=max(2, 2 * K),
-                          vae="sd-native").to(dev)
+                          vae="sd-native", text_encoder="sd2-native").to(dev)
     gd = dh.diffuser
     depth, bg_depth, mask = (t.to(dev) for t in make_scene(args.res))
     prompt = "a sphere on a plane"

@@ -32,6 +32,11 @@ class VAEConfig(ctypes.Structure):
                 ("layers_per_block", c_i), ("norm_groups", c_i), ("latent_size", c_i), ("dtype", c_i)]
 
 
+class TextConfig(ctypes.Structure):
+    _fields_ = [("hidden", c_i), ("heads", c_i), ("layers", c_i), ("intermediate", c_i), ("max_tokens", c_i),
+                ("max_batch", c_i), ("eps", c_f), ("dtype", c_i)]
+
+
 # name -> (restype, argtypes); mirrors include/diffhandles_hip.h one to one
 SIGNATURES = {
     "dh_last_error": (ctypes.c_char_p, []),
@@ -80,6 +85,14 @@ SIGNATURES = {
     "dh_vae_decoder_decode": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "dh_vae_encoder_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
     "dh_vae_encoder_encode": (c_i, [c_p, c_p, c_i, c_p, c_p]),
+    "dh_text_encoder_create": (c_i, [c_p, ctypes.POINTER(c_p)]),
+    "dh_text_encoder_destroy": (None, [c_p]),
+    "dh_text_encoder_num_params": (c_i, [c_p]),
+    "dh_text_encoder_param_info": (c_i, [c_p, c_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i),
+                                         ctypes.POINTER(ctypes.c_int64)]),
+    "dh_text_encoder_load_param": (c_i, [c_p, c_i, c_p, c_p]),
+    "dh_text_encoder_bytes": (c_sz, [c_p]),
+    "dh_text_encoder_encode": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "dh_gemm_profile_begin": (c_i, []),
     "dh_gemm_profile_end": (c_i, [ctypes.POINTER(c_d), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(c_d)]),
     "dh_ddim_cfg_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_p]),

@@ -159,7 +159,7 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // puts KS waves on every SIMD instead of one, so one wave's softmax VALU work hides under another's MFMAs.
 template <class T, int KS, int QW, bool DB>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
-                                                       float* lse, int H, int Nq, int Nk) {
+                                                       float* lse, int H, int Nq, int Nk, int causal) {
   // DB (key-split blocks of grids that fit the chip once or twice): the K/V tiles are double-buffered per wave group --
   // tile it+1, fetched one iteration ago, is committed to the other buffer after tile it has been multiplied, so ONE
   // block-wide barrier per key tile orders both "tile it is visible" and "everyone has left tile it-1" (N = 4096, B = 1:
@@ -223,6 +223,14 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     } else {
     s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
     s[1] = tile_times_frags<T>(sK, 32, ln, hi, qf);
+    }
+    if (causal) {                  // text tower: key j is visible to query i only for j <= i (forward only)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + t2 * 32 + acc_row(r, hi) > (int)qrow) s[t2][r] = -INFINITY;
     }
     if (k0 + 64 > Nk) {            // ragged last tile: mask the keys past Nk
       // (the empty asm keeps this a real branch: flattened into selects it cost 32 compares + 32 selects + the key
@@ -639,17 +647,17 @@ static int attn_row_waves(int rows, int hb, int loop_rows) {
 
 template <class T, int KS, int QW>
 static void attn_fwd_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
-                            long ldo, float* lse, int H, int Nq, int Nk) {
+                            long ldo, float* lse, int H, int Nq, int Nk, int causal) {
   const dim3 grid(cdiv(Nq, 32 * QW), H, B);
   if constexpr (KS >= 2 && KS * QW < 16) {      // (the 16-wave block has no registers to spare for the second fetch)
     if ((long)grid.x * grid.y * grid.z <= 512) {
       hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, true>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
-                         ldk, (T*)o, ldo, lse, H, Nq, Nk);
+                         ldk, (T*)o, ldo, lse, H, Nq, Nk, causal);
       return;
     }
   }
   hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, false>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
-                     ldk, (T*)o, ldo, lse, H, Nq, Nk);
+                     ldk, (T*)o, ldo, lse, H, Nq, Nk, causal);
 }
 template <class T, int KS, int QW>
 static void attn_dq_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
@@ -682,14 +690,14 @@ static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, cons
   } while (0)
 
 void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o, long ldo,
-                          float* lse, int B, int H, int Nq, int Nk, hipStream_t st) {
+                          float* lse, int B, int H, int Nq, int Nk, hipStream_t st, int causal) {
   const int ks = attn_key_split((Nk + 63) / 64, 4);
   const int qw = attn_row_waves(Nq, H * B, Nk);
 #define DH_ATTN_FWD(T_)                                                                         \
   do {                                                                                          \
-    if (ks == 4) DH_ATTN_QW(attn_fwd_launch, T_, 4, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk);       \
-    else if (ks == 2) DH_ATTN_QW(attn_fwd_launch, T_, 2, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk);  \
-    else DH_ATTN_QW(attn_fwd_launch, T_, 1, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk);               \
+    if (ks == 4) DH_ATTN_QW(attn_fwd_launch, T_, 4, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk, causal);       \
+    else if (ks == 2) DH_ATTN_QW(attn_fwd_launch, T_, 2, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk, causal);  \
+    else DH_ATTN_QW(attn_fwd_launch, T_, 1, B, st, q, ldq, k, v, ldk, o, ldo, lse, H, Nq, Nk, causal);               \
   } while (0)
   if (dtype == DH_DTYPE_F16) DH_ATTN_FWD(f16);
   else DH_ATTN_FWD(bf16);

@@ -88,6 +88,8 @@ struct GnBwdSplit { void* out0 = nullptr; void* out1 = nullptr; int split_c = 0;
 void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* beta,
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st, int have_partials = 0, GnBwdSplit split = GnBwdSplit());
+// y = gelu(x) (erf form), n elements (the text tower's MLP)
+void launch_gelu(int dtype, const void* x, void* y, size_t n, hipStream_t st);
 // LayerNorm over C per row; stats [rows][2]
 void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           int rows, int C, float eps, hipStream_t st);
@@ -116,7 +118,7 @@ void launch_set_scalar(float* p, float v, hipStream_t st);
 // flash attention, head dim 64.  q [B*Nq][ldq], k/v [B*Nk][ldk] (head h at column h*64),
 // o [B*Nq][ldo]; lse [B][H][Nq] f32 (natural log)
 void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o,
-                          long ldo, float* lse, int B, int H, int Nq, int Nk, hipStream_t st);
+                          long ldo, float* lse, int B, int H, int Nq, int Nk, hipStream_t st, int causal = 0);
 // delta[b][h][q] = sum_d dO*O
 void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o, long lddo, float* delta, int B,
                             int H, int Nq, hipStream_t st);

@@ -1055,6 +1055,25 @@ void launch_timestep_embedding(int dtype, const float* t, int dim, int B, void* 
   else hipLaunchKernelGGL((k_timestep<bf16>), dim3(cdiv(B * dim, 256)), dim3(256), 0, st, t, dim, B, (bf16*)out);
 }
 
+// y = gelu(x), 8 elements per thread (n % 8 == 0)
+template <class T>
+__global__ void __launch_bounds__(256) k_gelu(const T* x, T* y, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 raw = *reinterpret_cast<const uint4*>(x + i * 8);
+  const T* v = reinterpret_cast<const T*>(&raw);
+  T o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = from_f32<T>(gelu_f(to_f32<T>(v[k])));
+  *reinterpret_cast<uint4*>(y + i * 8) = *reinterpret_cast<uint4*>(o);
+}
+void launch_gelu(int dtype, const void* x, void* y, size_t n, hipStream_t st) {
+  const size_t n8 = n / 8;
+  const unsigned nb = (unsigned)((n8 + 255) / 256);
+  if (dtype == DH_DTYPE_F16) hipLaunchKernelGGL((k_gelu<f16>), dim3(nb), dim3(256), 0, st, (const f16*)x, (f16*)y, n8);
+  else hipLaunchKernelGGL((k_gelu<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n8);
+}
+
 __global__ void k_lane_ops_probe(const float* in, float* out, unsigned* ex) {
   const int lane = threadIdx.x;
   const float v = in[lane];

@@ -130,12 +130,21 @@ class GuidedStableDiffuser(GuidedDiffuser):
             if self.tokenizer is None and os.environ.get("DIFFHANDLES_TOKENIZER_DIR"):
                 from transformers import CLIPTokenizer
                 self.tokenizer = CLIPTokenizer.from_pretrained(os.environ["DIFFHANDLES_TOKENIZER_DIR"])
-            if self.text_encoder is None and os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR"):
+            text_native = isinstance(self.text_encoder, str) and self.text_encoder.endswith("-native")
+            if (self.text_encoder is None or text_native) and os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR"):
                 self.text_encoder = build_text_encoder(os.environ["DIFFHANDLES_TEXT_ENCODER_DIR"])
             if self.vae is None and os.environ.get("DIFFHANDLES_VAE_SAFETENSORS"):
                 self.vae = AutoencoderKL.from_safetensors(os.environ["DIFFHANDLES_VAE_SAFETENSORS"])
             if isinstance(self.text_encoder, str):
-                self.text_encoder = build_text_encoder()
+                self.text_encoder = build_text_encoder()           # "sd2" / "sd2-native": the SD-2 text configuration, random weights
+            if text_native:
+                # the CLIP text transformer on the engine's kernels (csrc/text_engine.cpp); the module only supplies the weights
+                from .vae import HipTextEncoder
+                tc = self.text_encoder.config.to_dict()
+                keys = ("hidden_size", "num_attention_heads", "num_hidden_layers", "intermediate_size", "max_position_embeddings",
+                        "layer_norm_eps", "hidden_act", "vocab_size")
+                self.text_encoder = HipTextEncoder({k: tc[k] for k in keys if k in tc}, self.dtype, max_batch=2,
+                                                   device=device).load_state_dict(self.text_encoder.state_dict())
             if isinstance(self.vae, str):
                 # "sd": the SD VAE architecture in PyTorch-ROCm; "sd-native": the same with the decoder on the engine's kernels
                 native = self.vae == "sd-native"

@@ -344,3 +344,82 @@ class NativeDecodeVAE(nn.Module):
 
     def decode(self, z, return_dict=True):
         return self._dec.decode(z, return_dict)
+
+
+class HipTextEncoder:
+    """transformers' `CLIPTextModel` call surface (`enc(ids)[0]` -> last_hidden_state [B,77,hidden]) with the transformer on the
+    native engine kernels (csrc/text_engine.cpp): LayerNorm, MFMA GEMMs, the causal flash-attention forward, erf-GELU.  The token
+    and position embedding tables stay torch tensors (a gather); weights come from a CLIPTextModel state dict."""
+
+    def __init__(self, config=None, dtype=torch.float16, max_batch=2, device=None):
+        import ctypes
+        from . import _lib
+        _lib.require_gpu()
+        c = dict(SD2_TEXT, **(config or {}))
+        if c.get("hidden_act", "gelu") != "gelu":
+            raise NotImplementedError("the native text tower implements the erf GELU of the SD-2 text encoder")
+        self.config = SimpleNamespace(**c)
+        self.dtype = dtype
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = _lib.TextConfig()
+        cfg.hidden, cfg.heads, cfg.layers = c["hidden_size"], c["num_attention_heads"], c["num_hidden_layers"]
+        cfg.intermediate, cfg.max_tokens, cfg.max_batch = c["intermediate_size"], c["max_position_embeddings"], int(max_batch)
+        cfg.eps, cfg.dtype = float(c.get("layer_norm_eps", 1e-5)), _lib.DTYPE_CODE[dtype]
+        self._L = _lib.lib()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dh_text_encoder_create(ctypes.byref(cfg), ctypes.byref(h)), "dh_text_encoder_create")
+        self._h = h
+        self._tok = self._pos = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.dh_text_encoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd):
+        import ctypes
+        from . import _lib
+        st = _lib.stream_ptr()
+
+        def get(key):       # published checkpoints carry the "text_model." prefix; newer transformers state dicts do not
+            return sd[key] if key in sd else sd[key[len("text_model."):]]
+
+        for i in range(self._L.dh_text_encoder_num_params(self._h)):
+            name, nd, shp = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int64 * 2)()
+            _lib.check(self._L.dh_text_encoder_param_info(self._h, i, ctypes.byref(name), ctypes.byref(nd), shp))
+            key, shape = name.value.decode(), tuple(int(shp[k]) for k in range(nd.value))
+            t = get(key).detach()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{key}: expected shape {shape}, got {tuple(t.shape)}")
+            t = t.to(self.device, torch.float32).contiguous()
+            _lib.check(self._L.dh_text_encoder_load_param(self._h, i, _lib.ptr(t), st), f"load {key}")
+        self._tok = get("text_model.embeddings.token_embedding.weight").detach().to(self.device, torch.float32)
+        self._pos = get("text_model.embeddings.position_embedding.weight").detach().to(self.device, torch.float32)
+        torch.cuda.synchronize(self.device)
+        return self
+
+    def workspace_bytes(self):
+        return int(self._L.dh_text_encoder_bytes(self._h))
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    @torch.no_grad()
+    def __call__(self, input_ids, attention_mask=None):
+        from . import _lib
+        if attention_mask is not None:
+            raise NotImplementedError("the reference calls the text encoder without a padding mask")
+        ids = input_ids.to(self.device)
+        B, T = ids.shape
+        emb = (self._tok[ids] + self._pos[:T]).contiguous()
+        out = torch.empty_like(emb)
+        _lib.check(self._L.dh_text_encoder_encode(self._h, _lib.ptr(emb), B, T, _lib.ptr(out), _lib.stream_ptr()),
+                   "dh_text_encoder_encode")
+        return (out,)

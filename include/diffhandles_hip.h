@@ -268,6 +268,32 @@ int dh_vae_decoder_decode(dh_vae_decoder* v, const float* z, int batch, float* i
 int dh_vae_encoder_create(const dh_vae_config* cfg, dh_vae_decoder** out);
 int dh_vae_encoder_encode(dh_vae_decoder* v, const float* image, int batch, float* moments, void* stream);
 
+/* --------------------------------------------------------------------------------------
+ * CLIP text tower on the engine's kernels (guided_stable_diffuser.py:96-108 `self.text_encoder(ids)[0]`,
+ * stable_null_inverter.py:85-103): pre-norm transformer layers with causal attention (heads of 64), erf-GELU MLP and the
+ * final LayerNorm.  transformers' CLIPTextModel is [ext]; parameter names are its state-dict names
+ * ("text_model.encoder.layers.N.*", "text_model.final_layer_norm.*").  The token + position embedding lookup stays with the
+ * caller: embeds [B][tokens][hidden] f32 is their sum; out [B][tokens][hidden] f32 = last_hidden_state.  Forward only.
+ * ------------------------------------------------------------------------------------ */
+typedef struct dh_text_encoder dh_text_encoder;
+typedef struct dh_text_config {
+  int hidden;        /* 1024 */
+  int heads;         /* 16 (head dim 64) */
+  int layers;        /* 23 */
+  int intermediate;  /* 4096 */
+  int max_tokens;    /* 77 */
+  int max_batch;     /* prompts per call */
+  float eps;         /* 1e-5 */
+  int dtype;         /* DH_DTYPE_F16 or DH_DTYPE_BF16 */
+} dh_text_config;
+int dh_text_encoder_create(const dh_text_config* cfg, dh_text_encoder** out);
+void dh_text_encoder_destroy(dh_text_encoder* e);
+int dh_text_encoder_num_params(const dh_text_encoder* e);
+int dh_text_encoder_param_info(const dh_text_encoder* e, int i, const char** name, int* ndim, int64_t* shape2);
+int dh_text_encoder_load_param(dh_text_encoder* e, int i, const float* src, void* stream);   /* DEVICE f32, torch layout */
+size_t dh_text_encoder_bytes(const dh_text_encoder* e);
+int dh_text_encoder_encode(dh_text_encoder* e, const float* embeds, int batch, int tokens, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
