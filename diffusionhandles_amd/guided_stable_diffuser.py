@@ -130,11 +130,17 @@ class GuidedStableDiffuser(GuidedDiffuser):
             if self.tokenizer is None and os.environ.get("DIFFHANDLES_TOKENIZER_DIR"):
                 from transformers import CLIPTokenizer
                 self.tokenizer = CLIPTokenizer.from_pretrained(os.environ["DIFFHANDLES_TOKENIZER_DIR"])
-            text_native = isinstance(self.text_encoder, str) and self.text_encoder.endswith("-native")
+            # DIFFHANDLES_NATIVE_AUX=1: checkpoints given through the environment run on the engine's kernels too
+            native_aux = os.environ.get("DIFFHANDLES_NATIVE_AUX") == "1"
+            text_native = (isinstance(self.text_encoder, str) and self.text_encoder.endswith("-native")) or (
+                native_aux and self.text_encoder is None and bool(os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR")))
             if (self.text_encoder is None or text_native) and os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR"):
                 self.text_encoder = build_text_encoder(os.environ["DIFFHANDLES_TEXT_ENCODER_DIR"])
             if self.vae is None and os.environ.get("DIFFHANDLES_VAE_SAFETENSORS"):
                 self.vae = AutoencoderKL.from_safetensors(os.environ["DIFFHANDLES_VAE_SAFETENSORS"])
+                if native_aux:
+                    from .vae import NativeDecodeVAE
+                    self.vae = NativeDecodeVAE(self.vae, self._unet_config["sample_size"], self.dtype)
             if isinstance(self.text_encoder, str):
                 self.text_encoder = build_text_encoder()           # "sd2" / "sd2-native": the SD-2 text configuration, random weights
             if text_native:
