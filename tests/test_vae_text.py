@@ -174,3 +174,35 @@ def test_diffuser_with_native_text_tower_and_vae():
     assert z.shape == (1, 4, 64, 64) and torch.isfinite(z).all()
     rec = gd.vae.decode(z)["sample"]
     assert rec.shape == (1, 3, 512, 512) and torch.isfinite(rec).all()
+
+
+@pytest.mark.gpu
+def test_native_aux_error_paths():
+    """The native text tower / VAE refuse what they were not built for instead of computing something else."""
+    from diffusionhandles_amd.vae import AutoencoderKL, HipTextEncoder, HipVAEDecoder, HipVAEEncoder, build_text_encoder
+    dev = torch.device("cuda:0")
+    small = dict(num_hidden_layers=1)
+    m = build_text_encoder(config=small).to(dev).eval()
+    enc = HipTextEncoder(small, max_batch=1).load_state_dict(m.state_dict())
+    ids = torch.zeros(2, 77, dtype=torch.int64, device=dev)
+    with pytest.raises(RuntimeError):
+        enc(ids)                                                  # batch 2 > max_batch 1
+    with pytest.raises(NotImplementedError):
+        enc(ids[:1], attention_mask=torch.ones(1, 77, device=dev))
+    with pytest.raises(NotImplementedError):
+        HipTextEncoder(dict(small, hidden_act="quick_gelu"))
+    vae = AutoencoderKL().to(dev).eval()
+    ve = HipVAEEncoder(latent_size=16).load_state_dict(vae.state_dict())
+    with pytest.raises(ValueError):
+        ve.encode(torch.zeros(1, 3, 256, 256, device=dev))        # built for 128x128 images
+    with pytest.raises(NotImplementedError):
+        ve.decode(torch.zeros(1, 4, 16, 16, device=dev))
+    vd = HipVAEDecoder(latent_size=16).load_state_dict(vae.state_dict())
+    with pytest.raises(ValueError):
+        vd.decode(torch.zeros(1, 4, 32, 32, device=dev))
+    import ctypes
+    from diffusionhandles_amd import _lib
+    out = torch.zeros(1, 16, 16, 8, device=dev)
+    img = torch.zeros(1, 128, 128, 3, device=dev)
+    rc = _lib.lib().dh_vae_encoder_encode(vd._h, _lib.ptr(img), 1, _lib.ptr(out), _lib.stream_ptr())
+    assert rc != 0 and b"decoder" in _lib.lib().dh_last_error()   # a decoder handle is not an encoder
