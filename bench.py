@@ -29,8 +29,6 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -52,7 +50,54 @@ def parse():
     ap.add_argument("--no-phases", dest="phases", action="store_false", help="skip inversion / initial inference / whole-edit timing")
     ap.add_argument("--no-res768", dest="res768", action="store_false", help="skip the 768x768 bf16 record (config 5)")
     ap.add_argument("--no-time-edit", dest="phases", action="store_false", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="print the per-rank environment / command the N-rank launcher would start (one JSON line) and exit")
     return ap.parse_args()
+
+
+def rank_environments(n, port, base=None):
+    """The environment of each of the n ranks the launcher starts: one process per GPU, rendezvous on 127.0.0.1."""
+    envs = []
+    for r in range(n):
+        env = dict(os.environ if base is None else base)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        envs.append(env)
+    return envs
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher in front (RANK unset): start N copies of this script, one rank per GPU
+    (the reference's own multi-GPU shape is one process per device too, webapp/start_webapps_in_tmux.sh:21-43).  The parent
+    never touches the GPU - no torch.cuda call, no library load - and nothing is exec'd: children are ordinary
+    subprocesses, rank 0's stdout (the one JSON line) passes through, the worst child return code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv
+    envs = rank_environments(args.gpus, port)
+    if args.dry_run_launch:
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+        print(json.dumps({"launch": [{"cmd": cmd, "env": {k: e[k] for k in keys}} for e in envs]}))
+        return 0
+    procs = [subprocess.Popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL) for r, e in enumerate(envs)]
+    rcs = []
+    deadline = None
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is not None:
+                procs.remove(p)
+                rcs.append(rc)
+                if rc != 0 and deadline is None:       # a rank died: the others wait at a barrier; give them a minute, then end them
+                    deadline = time.time() + 60
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.2)
+    return max((abs(rc) for rc in rcs), default=0)
 
 
 def cpu_baseline():
@@ -65,7 +110,7 @@ def cpu_baseline():
     from oracle import unet_torch as U
     from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
     host = os.cpu_count() or 1
-    threads = min(host, 32)      # more threads than this oversubscribes torch's CPU kernels
+    threads = host
     torch.set_num_threads(threads)
     unet = U.UNetTorch(U.SD2_DEPTH).eval()      # default torch init: values do not matter for timing
     for p_ in unet.parameters():
@@ -121,6 +166,11 @@ def cpu_baseline():
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
+        argv = [a for a in sys.argv[1:] if a != "--dry-run-launch"]
+        raise SystemExit(launch_ranks(args, argv))
+    global torch
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

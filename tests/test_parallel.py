@@ -120,3 +120,47 @@ def test_two_rank_sharded_driver_batches_and_identity():
         for gi, v, d in allr:
             assert abs(v - (gi + 0.1 * gi + k)) < 1e-3 and d == float(gi)
     assert res[0][4] == [0, 2] and res[1][4] == [1]
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`python bench.py --gpus N` with no launcher in front starts N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* per child, 127.0.0.1 rendezvous) and never touches the GPU in the parent: --dry-run-launch prints the plan."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--dry-run-launch"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    plan = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert len(plan) == 4
+    ports = {p["env"]["MASTER_PORT"] for p in plan}
+    assert len(ports) == 1 and int(ports.pop()) > 0
+    for r, p in enumerate(plan):
+        assert p["env"]["RANK"] == str(r) and p["env"]["LOCAL_RANK"] == str(r) and p["env"]["WORLD_SIZE"] == "4"
+        assert p["env"]["MASTER_ADDR"] == "127.0.0.1"
+        assert p["cmd"][1].endswith("bench.py") and "--dry-run-launch" not in p["cmd"] and p["cmd"][-4:] == ["--gpus", "4", "--steps", "3"]
+
+
+def test_bench_launcher_children_see_their_rank(tmp_path):
+    """The launcher really spawns the children with those environments and returns the worst return code."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("dh_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    envs = bench.rank_environments(3, 12345, base={"PATH": os.environ.get("PATH", "")})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and all(e["WORLD_SIZE"] == "3" for e in envs)
+    # a stand-in script in place of bench.py: each child writes its rank; rank 1 fails
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys\nr = os.environ['RANK']\nopen(os.path.join(os.path.dirname(__file__), 'r' + r), 'w')"
+                      ".write(os.environ['WORLD_SIZE'] + ' ' + os.environ['MASTER_PORT'])\nsys.exit(3 if r == '1' else 0)\n")
+    old = bench.__file__
+    try:
+        bench.__file__ = str(script)
+        rc = bench.launch_ranks(types.SimpleNamespace(gpus=3, dry_run_launch=False), [])
+    finally:
+        bench.__file__ = old
+    assert rc == 3
+    seen = sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("r"))
+    assert seen == ["r0", "r1", "r2"]
+    assert len({(tmp_path / n).read_text() for n in seen}) == 1
