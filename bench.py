@@ -110,7 +110,9 @@ def cpu_baseline():
     from oracle import unet_torch as U
     from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
     host = os.cpu_count() or 1
-    threads = host
+    # 32 threads: measured on the 256-core GPU host, torch's CPU kernels at 256 threads take 136 s for the forward that
+    # takes 2.3 s at 32 (oversubscribed intra-op pool); DH_CPU_BASELINE_THREADS overrides
+    threads = int(os.environ.get("DH_CPU_BASELINE_THREADS", min(host, 32)))
     torch.set_num_threads(threads)
     unet = U.UNetTorch(U.SD2_DEPTH).eval()      # default torch init: values do not matter for timing
     for p_ in unet.parameters():

@@ -99,6 +99,8 @@ SIGNATURES = {
     "dh_latent_update": (c_i, [c_p, c_p, c_p, c_f, c_f, c_i, c_p]),
     "dh_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_p]),
     "dh_mse_fwd_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
+    "dh_mse_cotangent": (c_i, [c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "dh_adam_step_scaled": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_p]),
 }
 
 # test hooks (csrc/debug_api.cpp): single-kernel entry points used only by tests/

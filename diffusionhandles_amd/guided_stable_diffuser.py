@@ -263,11 +263,11 @@ class GuidedStableDiffuser(GuidedDiffuser):
         s = torch.cat([x, depth_nhwc], dim=-1) if self.conf.use_depth else x
         return s.expand(reps, -1, -1, -1).contiguous() if reps > 1 else s.contiguous()
 
-    def _cfg_eps(self, x, depth_nhwc, t, uncond, cond):
+    def _cfg_eps(self, x, depth_nhwc, t, uncond, cond, want_acts=False):
         sample = self._unet_input(x, depth_nhwc, 2)
         text = torch.cat([uncond.reshape(1, *cond.shape[1:]).to(self.device, torch.float32), cond]).contiguous()
-        eps, _ = self.unet.forward(sample, float(t), text, save_for_backward=False, want_acts=False)
-        return eps[0:1], eps[1:2]
+        eps, acts = self.unet.forward(sample, float(t), text, save_for_backward=False, want_acts=want_acts)
+        return (eps[0:1], eps[1:2], acts) if want_acts else (eps[0:1], eps[1:2])
 
     # ---- reference API ----------------------------------------------------------------------
     @torch.no_grad()
@@ -293,10 +293,13 @@ class GuidedStableDiffuser(GuidedDiffuser):
         T = len(timesteps)
         store = [torch.empty((T,) + shp, dtype=self.dtype, device=self.device) for shp in self.unet.act_shapes]
         for t_idx, t in enumerate(timesteps):
-            _, acts = self.unet.forward(self._unet_input(x, depth_nhwc), float(t), cond, save_for_backward=False)
+            # the reference runs a cond-only B=1 pass for the activations and then the B=2 CFG pass (guided_stable_diffuser.py
+            # :222-257: three samples per step); the conditional half of the CFG pass has exactly the inputs of the B=1 pass, so
+            # the activations are captured there (two samples per step).  Same values up to the engine's batch-dependent tile
+            # selection (16-bit: < 1e-2 against the oracle's B=1 activations, tests/test_loops_gpu.py).
+            eu, ec, acts = self._cfg_eps(x, depth_nhwc, t, uncond_embeddings[t_idx], cond, want_acts=True)
             for k in range(3):
-                store[k][t_idx].copy_(acts[k][0])
-            eu, ec = self._cfg_eps(x, depth_nhwc, t, uncond_embeddings[t_idx], cond)
+                store[k][t_idx].copy_(acts[k][1])
             x = self.ddim_step(x, eu, ec, t)
         activations = [a.permute(0, 3, 1, 2) for a in store]      # [T,C,h,w] views of channels-last storage
         return activations, x.permute(0, 3, 1, 2), uncond_embeddings, init_latents

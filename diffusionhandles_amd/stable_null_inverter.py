@@ -19,8 +19,12 @@ class StableNullInverter(NullInverter):
         self.num_ddim_steps = num_ddim_steps
         self.guidance_scale = guidance_scale
         self.model.scheduler.set_timesteps(self.num_ddim_steps)
-        # the eps cotangent is ~1e-6: scale it through the 16-bit backward pass
-        self.eps_grad_scale = 65536.0 if model.dtype == torch.float16 else 1.0
+        # the eps cotangent is ~1e-6 and shrinks as the optimisation converges: every inner step scales it by the power of
+        # two that brings its largest element to (128, 256] before the 16-bit backward pass and divides the text gradient
+        # by the same factor (dh_mse_cotangent / dh_adam_step_scaled; the backward is linear, the factor cancels exactly).
+        # Measured at the full SD-2-depth size (tools/probe_text_grad.py): fp16 text-gradient error 2.4e-3 for
+        # max |cotangent| in [1, 4096], 1.9e-2 at 2^-4, 9e-2 at 2^-8 (fp16 subnormals); bf16 2.2e-2 at any amplitude.
+        self.cotangent_amp = 256.0
 
     def to(self, device):
         self.model.to(device)
@@ -88,8 +92,8 @@ class StableNullInverter(NullInverter):
         L = _lib.lib()
         n = cur.numel()
         loss_dev = torch.zeros(1, dtype=torch.float32, device=cur.device)
-        d_rec = torch.empty_like(cur)
-        S = self.eps_grad_scale
+        scale_dev = torch.ones(1, dtype=torch.float32, device=cur.device)
+        d_eps = torch.empty_like(cur)
         m = torch.zeros_like(uncond)
         v = torch.zeros_like(uncond)
         lr = 1e-2 * (1.0 - i / 100.0)
@@ -98,22 +102,26 @@ class StableNullInverter(NullInverter):
         # d rec / d eps_u = (1 - w) * (sqrt(1-a_p) - sqrt(a_p) sqrt(1-a_t) / sqrt(a_t))
         k = (1.0 - self.guidance_scale) * ((1 - a_p) ** 0.5 - (a_p ** 0.5) * ((1 - a_t) ** 0.5) / (a_t ** 0.5))
         eps_c = self.get_noise_pred_single(cur, t, cond, depth)
+        self._eps_c = eps_c                                     # the post-loop CFG step of this timestep reuses it
         taken = 0
         for j in range(num_inner_steps):
             eps_u = self.get_noise_pred_single(cur, t, uncond, depth, save=True)
             rec = self._step(cur, eps_u, eps_c, self.guidance_scale, a_t, a_p)
-            _lib.check(L.dh_mse_fwd_bwd(_lib.ptr(rec), _lib.ptr(target), n, _lib.ptr(loss_dev), _lib.ptr(d_rec),
-                                        _lib.stream_ptr()), "dh_mse_fwd_bwd")
-            d_eps = (d_rec * (k * S)).contiguous()
+            _lib.check(L.dh_mse_cotangent(_lib.ptr(rec), _lib.ptr(target), n, k, self.cotangent_amp, _lib.ptr(loss_dev),
+                                          _lib.ptr(d_eps), _lib.ptr(scale_dev), _lib.stream_ptr()), "dh_mse_cotangent")
             _, d_text = self.model.unet.backward(None, d_eps, want_sample_grad=False, want_text_grad=True)
-            g = (d_text / S).contiguous()
-            _lib.check(L.dh_adam_step(_lib.ptr(uncond), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), lr, 0.9, 0.999, 1e-8,
-                                      j + 1, uncond.numel(), _lib.stream_ptr()), "dh_adam_step")
+            _lib.check(L.dh_adam_step_scaled(_lib.ptr(uncond), _lib.ptr(d_text), _lib.ptr(scale_dev), _lib.ptr(m), _lib.ptr(v),
+                                             lr, 0.9, 0.999, 1e-8, j + 1, uncond.numel(), _lib.stream_ptr()),
+                       "dh_adam_step_scaled")
             taken = j + 1
-            loss = loss_dev.item()                             # the reference's early stop (one sync per inner step)
+            # the reference's early stop: one host read per inner step.  It stalls the queue for ~50 us out of the ~9 ms of
+            # an inner step; skipping the remaining passes when it fires is worth far more than the stall costs.
+            loss = loss_dev.item()
             if record is not None:
                 record.setdefault("loss", []).append(loss)
-                record.setdefault("grad", []).append(g.clone())
+                record.setdefault("grad", []).append(d_text / scale_dev)
+                record.setdefault("scale", []).append(float(scale_dev.item()))
+                record.setdefault("d_eps", []).append(d_eps / scale_dev)
             if loss < epsilon + i * 2e-5:
                 break
         return taken
@@ -133,8 +141,11 @@ class StableNullInverter(NullInverter):
             a_t, a_p = self.scheduler.step_alphas(t)
             self.inner_steps_taken.append(self.null_step(cur, uncond, cond, depth, i, target, num_inner_steps, epsilon))
             out.append(uncond[:1].clone())
-            eu, ec = self.model._cfg_eps(cur, depth, t, uncond, cond)
-            cur = self._step(cur, eu, ec, self.guidance_scale, a_t, a_p)
+            # the CFG step with the optimised embedding (reference :162-165 runs a B=2 pass): its conditional half has the
+            # inputs of the eps_c this timestep already computed (same latent, timestep, prompt), so only the
+            # unconditional half is run, as a B=1 pass
+            eu = self.get_noise_pred_single(cur, t, uncond, depth)
+            cur = self._step(cur, eu, self._eps_c, self.guidance_scale, a_t, a_p)
         return torch.stack(out, dim=0)
 
     def invert(self, target_img, depth, prompt, num_inner_steps=10, early_stop_epsilon=1e-5, verbose=False,

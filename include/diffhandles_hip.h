@@ -236,6 +236,17 @@ int dh_adam_step(float* p, const float* g, float* m, float* v, float lr, float b
 /* mse(rec, target) and d mse / d rec                        stable_null_inverter.py:152 */
 int dh_mse_fwd_bwd(const float* rec, const float* target, int n, float* loss_out, float* d_rec,
                    void* stream);
+/* The same loss, and the cotangent that seeds the engine's backward of a null-text inner step
+ * (stable_null_inverter.py:150-154: loss.backward() through prev_step and the CFG combine down to eps_uncond):
+ *   d_eps = (d mse / d rec) * k * S,   k = d rec / d eps_uncond (a scalar of the timestep),
+ * S = the power of two that brings max |d_eps| into (amp / 2, amp] (amp <= 0: S = 1), written to scale_out[0] (device).
+ * The 16-bit backward is linear in its cotangent: S only keeps it out of the fp16 subnormal range and is divided out
+ * again by dh_adam_step_scaled. */
+int dh_mse_cotangent(const float* rec, const float* target, int n, float k, float amp, float* loss_out,
+                     float* d_eps, float* scale_out, void* stream);
+/* dh_adam_step on g / g_scale[0] (g_scale: device scalar, the S of dh_mse_cotangent) */
+int dh_adam_step_scaled(float* p, const float* g, const float* g_scale, float* m, float* v, float lr, float beta1,
+                        float beta2, float eps, int step, int n, void* stream);
 
 /* --------------------------------------------------------------------------------------
  * SD AutoencoderKL decoder on the engine's kernels: the decode that ends every edit

@@ -66,26 +66,31 @@ def init_depth(disparity, size):
     return 2.0 * (d - lo) / (hi - lo) - 1.0
 
 
+def _with_depth(x, depth64):
+    """use_depth (guided_stable_diffuser.py:218, 244, 400, 454): the depth map is a fifth input channel, or absent."""
+    return x if depth64 is None else torch.cat([x, depth64], dim=1)
+
+
 def _eps_cfg(unet, x, depth64, t, uncond, cond):
-    inp = torch.cat([torch.cat([x] * 2), torch.cat([depth64] * 2)], dim=1)
+    inp = _with_depth(torch.cat([x] * 2), None if depth64 is None else torch.cat([depth64] * 2))
     e = unet(inp, t, encoder_hidden_states=torch.cat([uncond.expand(*cond.shape), cond]), return_dict=False)[0]
     eu, ec = e.chunk(2)
     return eu + CFG_SCALE * (ec - eu)
 
 
 @torch.no_grad()
-def initial_inference(unet, sched, init_latents, disparity, uncond_list, cond, num_steps=50, seed=2773):
+def initial_inference(unet, sched, init_latents, disparity, uncond_list, cond, num_steps=50, seed=2773, use_depth=True):
     torch.manual_seed(seed)
     sched.set_timesteps(num_steps)
     s = unet.config.sample_size
-    depth64 = init_depth(disparity, (s, s))
+    depth64 = init_depth(disparity, (s, s)) if use_depth else None
     if init_latents is None:
-        noise = torch.randn([1, unet.config.in_channels - 1, s, s])
+        noise = torch.randn([1, unet.config.in_channels - 1 if use_depth else unet.config.in_channels, s, s])
         init_latents = sched.add_noise(torch.zeros_like(noise), noise, sched.timesteps[0])
     x = init_latents
     acts = ([], [], [])
     for i, t in enumerate(sched.timesteps):
-        out = unet(torch.cat([x, depth64], dim=1), t, encoder_hidden_states=cond, return_dict=False)
+        out = unet(_with_depth(x, depth64), t, encoder_hidden_states=cond, return_dict=False)
         for k in range(3):
             acts[k].append(out[4 + k][0])
         x = sched.step(_eps_cfg(unet, x, depth64, t, uncond_list[i], cond), t, x)
@@ -104,7 +109,7 @@ def guided_inference(unet, sched, latents, disparity, uncond_list, cond, acts_or
     # is its U-Net's latent size: it supports 512 x 512 only.  The grid here is the latent size, identical at 512 x 512 and
     # the consistent choice elsewhere (768 x 768: 96 x 96 cells of 8 px, the resolution of the guided activations).
     cells = G.cells_from_correspondences(corr, disparity.shape[-1], conf.bg_erosion, grid=s)
-    depth64 = init_depth(disparity, (s, s))
+    depth64 = init_depth(disparity, (s, s)) if getattr(conf, "use_depth", True) else None
     x = latents
     for i, t in enumerate(sched.timesteps):
         size = tuple(acts_orig[2][i].shape[-2:])
@@ -112,7 +117,7 @@ def guided_inference(unet, sched, latents, disparity, uncond_list, cond, acts_or
         while it < conf.num_optsteps and i < conf.guidance_max_step:
             with torch.enable_grad():
                 x = x.detach().requires_grad_(True)
-                out = unet(torch.cat([x, depth64], dim=1), t, encoder_hidden_states=cond, return_dict=False)
+                out = unet(_with_depth(x, depth64), t, encoder_hidden_states=cond, return_dict=False)
                 fgw, bgw = G.guidance_weights(i, it, fg_weight, bg_weight, conf.guidance_max_step,
                                               conf.guidance_schedule_type)
                 loss = 0.0

@@ -77,3 +77,41 @@ def test_inversion_first_steps_match_reference(setup, golden):
     lat, unc = L.null_text_inversion(unet, L.DDIM(), lat0, disp, unc0, cond, num_inner_steps=5, null_steps=2)
     assert np.allclose(lat[-1].numpy(), g7["inv_init_noise"], atol=1e-5)
     assert np.allclose(unc.numpy(), g7["inv_uncond_first"][:2], atol=1e-5)
+
+
+VARIANTS = ["bg_erosion_10_local_avg", "local_avg_bg_loss", "linear_schedule", "quadratic_schedule", "no_depth"]
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_guided_variants_match_reference(name, golden):
+    """The oracle loop under the reference's own variant configurations (test/config/<name>.yaml: eroded background masks,
+    'local_avg' background loss, linear / quadratic schedules over 50 guided steps, use_depth false with a 4-channel U-Net)
+    against the trajectories the REFERENCE's guided_inference produced with them (tools/make_golden_variants.py, g14).
+    Two timesteps: t_idx 1 is where the falling schedules first differ from the constant one."""
+    import json
+    g14 = golden("g14_loop_variants.npz")
+    conf = SimpleNamespace(**json.loads(str(g14[name + ".conf"])))
+    cfg = dict(U.TINY) if conf.use_depth else dict(U.TINY, in_channels=4)
+    torch.manual_seed(0)
+    unet = U.init_synthetic_(U.UNetTorch(cfg), seed=0).eval()
+    depth, bg, mask = make_scene(512)
+    disp = D.normalize_depth(1.0 / depth)[0]
+    cond = text_embedding("a sphere on a plane", U.TINY["cross_attention_dim"])
+    unc = text_embedding("", U.TINY["cross_attention_dim"])[None].expand(50, -1, -1, -1).contiguous()
+    noise = torch.from_numpy(g14["noise"])
+    disp_e, corr = D.transform_depth_pc(depth, bg, mask, rot_angle=TRANSFORMS[2][0], rot_axis=[0, 1, 0],
+                                        translation=TRANSFORMS[2][1])
+
+    class TwoSteps(L.DDIM):
+        def set_timesteps(self, n):
+            super().set_timesteps(n)
+            self.timesteps = self.timesteps[:2]
+    acts, _, _, _ = L.initial_inference(unet, TwoSteps(), noise, disp, unc, cond, use_depth=conf.use_depth)
+    rec = {}
+    L.guided_inference(unet, TwoSteps(), noise, disp_e, unc, cond, acts, corr.numpy(), conf, record=rec)
+    got = torch.stack(rec["opt"]).numpy()
+    assert np.allclose(got[:3], g14[name + ".opt_t0"], atol=2e-5), np.abs(got[:3] - g14[name + ".opt_t0"]).max()
+    assert np.allclose(got[:, 0, :, ::4, ::4], g14[name + ".opt_all"][:6], atol=5e-5)
+    assert np.allclose(torch.stack(rec["step"]).numpy(), g14[name + ".step"][:2], atol=5e-5)
+    # the reference's loop and the oracle's agreed to this when the fixture was written (acts, latent, after-opt, after-step)
+    assert float(g14[name + ".ref_minus_oracle"].max()) < 2e-4

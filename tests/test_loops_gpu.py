@@ -94,6 +94,41 @@ def test_guided_inference_matches_oracle(rig):
     print("guided final latent rel err", e_fin)
     assert e_fin < 0.25
     assert len(rec_p["opt"]) == 38 * 3 and len(rec_p["step"]) == 50
+    rig.rec_o, rig.disp_e, rig.corr = rec_o, disp_e, corr
+
+
+def test_guided_loop_teacher_forced_all_steps(rig):
+    """Every one of the 50 steps of the guided loop (38 guided: all three layer phases, all iteration multipliers; 12
+    unguided: t_idx >= guidance_max_step) held tightly: the product's step i is started from the ORACLE's latent after step
+    i - 1, so the chaotic divergence of the free-running trajectories (an L1 energy: its gradient is a sign) cannot hide an
+    error in a late step.  Per step: the latent after the step rel-L2 < 2e-2, the first optimisation iteration's update (the
+    guidance gradient) rel-L2 < 6e-2, the update of all three iterations < 0.2 (flipped signs accumulate)."""
+    if not hasattr(rig, "rec_o"):
+        test_guided_inference_matches_oracle(rig)
+    gd, rec_o = rig.gd, rig.rec_o
+    unc = rig.unc0[None].expand(50, -1, -1, -1).contiguous()
+    worst_step, worst_upd, worst_upd3 = 0.0, 0.0, 0.0
+    with torch.no_grad(), gd.on_stream():
+        gd.scheduler.set_timesteps(50)
+        ts = gd.scheduler.timesteps
+        st = gd.prepare_guidance(rig.disp_e, rig.prompt, rig.acts, rig.corr)
+        for i in range(50):
+            x_in = rig.noise.to(dev()) if i == 0 else rec_o["step"][i - 1]
+            rec = {}
+            x_out = gd.guided_step(st, x_in.permute(0, 2, 3, 1).contiguous(), i, ts[i], unc[i], record=rec)
+            e = rel(x_out.permute(0, 3, 1, 2), rec_o["step"][i])
+            worst_step = max(worst_step, e)
+            assert e < 2e-2, (i, e)
+            if i < 38:
+                assert len(rec["opt"]) == 3
+                eu = rel(rec["opt"][0] - x_in, rec_o["opt"][3 * i] - x_in)               # first iteration: the guidance gradient
+                eu3 = rel(rec["opt"][2] - x_in, rec_o["opt"][3 * i + 2] - x_in)          # all three (signs of an L1 energy flip)
+                worst_upd, worst_upd3 = max(worst_upd, eu), max(worst_upd3, eu3)
+                assert eu < 6e-2 and eu3 < 0.2, (i, eu, eu3)
+            else:
+                assert "opt" not in rec or len(rec["opt"]) == 0
+    print("teacher-forced guided loop: worst step rel err", worst_step, "worst first-iteration update rel err", worst_upd,
+          "worst three-iteration update rel err", worst_upd3)
 
 
 def test_adam_and_mse_kernels_match_torch():
@@ -274,9 +309,22 @@ def test_null_text_step_full_size_matches_oracle():
     assert n == 5
     print("full-size null step: losses product", prec["loss"], "oracle", o_loss)
     e0 = rel(prec["grad"][0], o_grad[0])
-    print("first-step text gradient rel err", e0)
-    assert abs(prec["loss"][0] - o_loss[0]) < 2e-2 * o_loss[0]       # measured 0.9 %
-    assert e0 < 6e-2                                                 # measured 3.2e-2 (the engine's full-size backward tolerance)
+    print("first-step text gradient rel err (end to end)", e0)
+    assert abs(prec["loss"][0] - o_loss[0]) < 2e-2 * o_loss[0]       # measured 1.6 %
+    # Two different things are folded into e0.  (1) The engine's BACKWARD, seeded with the same cotangent as the oracle's
+    # autograd: held tightly below.  Round 2 ran it with a fixed 65536x scale that left the cotangent at ~2^-5, most of it
+    # in the fp16 subnormals (tools/probe_text_grad.py: 1.9e-2 at 2^-4, 2.4e-3 from 2^0 up); the per-step power-of-two
+    # scale (dh_mse_cotangent) removes that.  (2) The cotangent itself, d mse / d rec = 2 (rec - target) / n, is the SMALL
+    # DIFFERENCE of two latents (loss 6e-5: rms difference 8e-3 of O(1) values), so the 16-bit forward's ~1e-3 error in eps is
+    # a few per cent of it (the first loss already differs by 1.6 %) -- inherent to 16-bit storage, bounded loosely.
+    assert e0 < 6e-2                                                 # measured 3.3e-2
+    assert all(s_ > 0 and (s_ == 2.0 ** round(np.log2(s_))) for s_ in prec["scale"]), prec["scale"]
+    d_eps_p = prec["d_eps"][0].permute(0, 3, 1, 2)                   # the product's own cotangent (unscaled), [1,4,64,64]
+    unc_b = unc0.clone().requires_grad_(True)
+    g_iso, = torch.autograd.grad(L._eps_single(ref, cur, depth64, t, unc_b), unc_b, d_eps_p)
+    e_iso = rel(prec["grad"][0], g_iso)
+    print("text gradient rel err, engine backward alone (oracle autograd seeded with the product's cotangent)", e_iso)
+    assert e_iso < 1e-2                                              # measured 2.4e-3 by the probe
     for j in range(1, 5):
         print("inner step", j, "text gradient rel err", rel(prec["grad"][j], o_grad[j]))
     # later inner steps start from unconds that differ by the Adam sign noise of near-zero-gradient elements (see
