@@ -691,7 +691,9 @@ static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, cons
 
 void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o, long ldo,
                           float* lse, int B, int H, int Nq, int Nk, hipStream_t st, int causal) {
-  const int ks = attn_key_split((Nk + 63) / 64, 4);
+  // causal: no key split.  A wave group whose whole key range lies after a query row would carry m = -inf into the merge
+  // (exp2(-inf - -inf) = NaN); with one group the first tile always holds key 0, visible to every row
+  const int ks = attn_key_split((Nk + 63) / 64, causal ? 1 : 4);
   const int qw = attn_row_waves(Nq, H * B, Nk);
 #define DH_ATTN_FWD(T_)                                                                         \
   do {                                                                                          \

@@ -125,38 +125,34 @@ class GuidedStableDiffuser(GuidedDiffuser):
                     self.unet.init_synthetic(self._synthetic_seed)     # no checkpoint offline: seeded weights
             from .synthetic import SyntheticTextEncoder, SyntheticTokenizer, SyntheticVAE
             from .vae import AutoencoderKL, build_text_encoder
-            # real modules when checkpoints are given (PyTorch-ROCm; once per image / edit), "sd" / "sd2" = the real
-            # architectures with random weights, otherwise the cheap deterministic stand-ins (no checkpoints offline)
+            # Checkpoints named through the environment run on the ENGINE's kernels (csrc/vae_engine.cpp, csrc/text_engine.cpp):
+            # the PyTorch-ROCm modules of vae.py only carry the parameters (and serve as the tests' oracles).  "sd" / "sd2"
+            # name those torch modules with random weights (test oracles), "sd-native" / "sd2-native" the native engines with
+            # random weights; with nothing given the cheap deterministic stand-ins of synthetic.py are used (no checkpoints offline).
             if self.tokenizer is None and os.environ.get("DIFFHANDLES_TOKENIZER_DIR"):
                 from transformers import CLIPTokenizer
                 self.tokenizer = CLIPTokenizer.from_pretrained(os.environ["DIFFHANDLES_TOKENIZER_DIR"])
-            # DIFFHANDLES_NATIVE_AUX=1: checkpoints given through the environment run on the engine's kernels too
-            native_aux = os.environ.get("DIFFHANDLES_NATIVE_AUX") == "1"
-            text_native = (isinstance(self.text_encoder, str) and self.text_encoder.endswith("-native")) or (
-                native_aux and self.text_encoder is None and bool(os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR")))
-            if (self.text_encoder is None or text_native) and os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR"):
+            text_native = isinstance(self.text_encoder, str) and self.text_encoder.endswith("-native")
+            if self.text_encoder is None and os.environ.get("DIFFHANDLES_TEXT_ENCODER_DIR"):
                 self.text_encoder = build_text_encoder(os.environ["DIFFHANDLES_TEXT_ENCODER_DIR"])
-            if self.vae is None and os.environ.get("DIFFHANDLES_VAE_SAFETENSORS"):
-                self.vae = AutoencoderKL.from_safetensors(os.environ["DIFFHANDLES_VAE_SAFETENSORS"])
-                if native_aux:
-                    from .vae import NativeDecodeVAE
-                    self.vae = NativeDecodeVAE(self.vae, self._unet_config["sample_size"], self.dtype)
-            if isinstance(self.text_encoder, str):
-                self.text_encoder = build_text_encoder()           # "sd2" / "sd2-native": the SD-2 text configuration, random weights
+                text_native = True
+            elif isinstance(self.text_encoder, str):
+                self.text_encoder = build_text_encoder()           # the SD-2 text configuration, random weights
             if text_native:
-                # the CLIP text transformer on the engine's kernels (csrc/text_engine.cpp); the module only supplies the weights
                 from .vae import HipTextEncoder
                 tc = self.text_encoder.config.to_dict()
                 keys = ("hidden_size", "num_attention_heads", "num_hidden_layers", "intermediate_size", "max_position_embeddings",
                         "layer_norm_eps", "hidden_act", "vocab_size")
                 self.text_encoder = HipTextEncoder({k: tc[k] for k in keys if k in tc}, self.dtype, max_batch=2,
                                                    device=device).load_state_dict(self.text_encoder.state_dict())
-            if isinstance(self.vae, str):
-                # "sd": the SD VAE architecture in PyTorch-ROCm; "sd-native": the same with the decoder on the engine's kernels
+            from .vae import NativeDecodeVAE
+            if self.vae is None and os.environ.get("DIFFHANDLES_VAE_SAFETENSORS"):
+                self.vae = NativeDecodeVAE(AutoencoderKL.from_safetensors(os.environ["DIFFHANDLES_VAE_SAFETENSORS"]),
+                                           self._unet_config["sample_size"], self.dtype)
+            elif isinstance(self.vae, str):
                 native = self.vae == "sd-native"
                 self.vae = AutoencoderKL()
                 if native:
-                    from .vae import NativeDecodeVAE
                     self.vae = NativeDecodeVAE(self.vae, self._unet_config["sample_size"], self.dtype)
             if self.tokenizer is None:
                 self.tokenizer = SyntheticTokenizer()

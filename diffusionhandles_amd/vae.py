@@ -331,18 +331,27 @@ class NativeDecodeVAE(nn.Module):
 
     def to(self, device):
         self.vae = self.vae.to(device)
-        if torch.device(device).type == "cuda":
-            sd = self.vae.state_dict()
-            self._dec = HipVAEDecoder(vars(self.vae.config), self._latent_size, self._dtype, device).load_state_dict(sd)
-            self._enc = HipVAEEncoder(vars(self.vae.config), self._latent_size, self._dtype, device).load_state_dict(sd)
+        self._device = torch.device(device)
+        if self._device.type == "cuda":
+            self._dec = HipVAEDecoder(vars(self.vae.config), self._latent_size, self._dtype, device).load_state_dict(
+                self.vae.state_dict())
+            self._enc = None            # built on the first encode(): only the inversion of an input image needs it
         return self
 
+    def _native_size(self, h, w):
+        return self._dec is not None and h == self._latent_size and w == self._latent_size
+
     def encode(self, x, return_dict=True):
-        if x.shape[-1] != 8 * self._latent_size or x.shape[-2] != 8 * self._latent_size:
-            return self.vae.encode(x, return_dict)          # another resolution than the engine was built for
+        if not self._native_size(x.shape[-2] // 8, x.shape[-1] // 8) or x.shape[-1] % 8 or x.shape[-2] % 8:
+            return self.vae.encode(x, return_dict)          # another resolution than the engines were built for (or not on a GPU yet)
+        if self._enc is None:
+            self._enc = HipVAEEncoder(vars(self.vae.config), self._latent_size, self._dtype, self._device).load_state_dict(
+                self.vae.state_dict())
         return self._enc.encode(x, return_dict)
 
     def decode(self, z, return_dict=True):
+        if not self._native_size(z.shape[-2], z.shape[-1]):
+            return self.vae.decode(z, return_dict)          # the same fallback as encode
         return self._dec.decode(z, return_dict)
 
 

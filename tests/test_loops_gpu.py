@@ -406,6 +406,44 @@ def test_scene_harness_end_to_end_on_the_reference_scene(tmp_path):
     assert html.count("<tr>") == 3 and "edit_001_disparity.png" in html            # header + one row per edit
 
 
+def test_scene_harness_identity_cache_round_trip_and_skip_existing(tmp_path):
+    """The harness's input-image identity cache (the reference's --cache_input_image_identity npz, which is also its web
+    services' wire format: keys null_text_emb, init_noise, activations1..3, latent_image; test_diffusion_handles.py:85-113,
+    webapp/webapps/diffhandles_webapp.py:82-94) and --skip_existing (:133-135, 216-225): a first run writes the cache, a second
+    run in another directory READS it (no inversion, no initial inference) and reproduces the edit bit for bit, a third run
+    with --skip-existing finds every output in place and does nothing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scene = os.path.join(root, "tests", "golden", "scene_banana_fruits")
+    tool = os.path.join(root, "tools", "run_edit.py")
+    out1, out2 = str(tmp_path / "a"), str(tmp_path / "b")
+
+    def run(*extra):
+        r = subprocess.run([sys.executable, tool, "--scene", scene, "--max-edits", "1", *extra], capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    rep1 = run("--out", out1, "--skip-inversion")
+    assert rep1["identity_from_cache"] is False and os.path.exists(os.path.join(out1, "identity.npz"))
+    with np.load(os.path.join(out1, "identity.npz")) as z:
+        assert sorted(z.files) == ["activations1", "activations2", "activations3", "init_noise", "latent_image", "null_text_emb"]
+        assert z["activations1"].shape == (50, 1280, 32, 32) and z["activations3"].shape == (50, 320, 64, 64)
+        assert z["null_text_emb"].shape == (50, 1, 77, 1024) and z["init_noise"].shape == (1, 4, 64, 64)
+        assert all(z[k].dtype == np.float32 for k in z.files)
+    rep2 = run("--out", out2, "--identity-cache", os.path.join(out1, "identity.npz"))
+    assert rep2["identity_from_cache"] is True and not os.path.exists(os.path.join(out2, "identity.npz"))
+    for f in ("recon.png", "edit_000.png", "edit_000_disparity.png"):
+        assert open(os.path.join(out1, f), "rb").read() == open(os.path.join(out2, f), "rb").read(), f
+    before = os.path.getmtime(os.path.join(out2, "edit_000.png"))
+    rep3 = run("--out", out2, "--identity-cache", os.path.join(out1, "identity.npz"), "--skip-existing")
+    assert rep3.get("skipped_scene") is True and rep3["edits"] == [dict(name="edit_000", skipped=True)]
+    assert os.path.getmtime(os.path.join(out2, "edit_000.png")) == before
+
+
 def test_sharded_edit_driver_on_one_gpu(tmp_path):
     """tools/run_edits_sharded.py (BASELINE config 4's driver) on the one GPU of the box: 5 edits in batches of 2 (so a
     ragged last batch), identity from initial inference, images written, report with the whole-job edits/s."""

@@ -104,8 +104,15 @@ def test_native_vae_encoder_matches_the_torch_restatement(dtype, tol):
         assert err < tol
         assert torch.equal(enc.encode(img, return_dict=False)[0].mean, got.mean)          # deterministic, tuple form
     wrap = NativeDecodeVAE(vae, latent_size=32, dtype=dtype).to(dev)
+    assert wrap._enc is None                                     # the encoder engine is built by the first encode()
     img = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(9)).to(dev) * 2 - 1
     z = wrap.encode(img)["latent_dist"].mean
+    assert wrap._enc is not None
+    # another resolution than the engines were built for: both directions fall back to the module
+    z16 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(10)).to(dev)
+    with torch.no_grad():
+        assert torch.equal(wrap.decode(z16)["sample"], vae.decode(z16)["sample"])
+        assert torch.equal(wrap.encode(img[..., :128, :128])["latent_dist"].mean, vae.encode(img[..., :128, :128])["latent_dist"].mean)
     with torch.no_grad():
         zr = vae.encode(img)["latent_dist"].mean
     assert ((z - zr).norm() / zr.norm()).item() < tol
@@ -174,6 +181,31 @@ def test_diffuser_with_native_text_tower_and_vae():
     assert z.shape == (1, 4, 64, 64) and torch.isfinite(z).all()
     rec = gd.vae.decode(z)["sample"]
     assert rec.shape == (1, 3, 512, 512) and torch.isfinite(rec).all()
+
+
+@pytest.mark.gpu
+def test_native_text_encoder_long_causal_sequence():
+    """Causal attention over more than 448 tokens (8+ key tiles, where the non-causal forward splits the keys over wave groups):
+    576 tokens, two layers, against transformers' CLIPTextModel; finite and causal."""
+    from diffusionhandles_amd.vae import HipTextEncoder, build_text_encoder
+    dev = torch.device("cuda:0")
+    cfg = dict(num_hidden_layers=2, max_position_embeddings=600)
+    torch.manual_seed(13)
+    ref_model = build_text_encoder(config=cfg).to(dev).eval()
+    with torch.no_grad():
+        for p in ref_model.parameters():
+            p.copy_(p.half().float())
+    enc = HipTextEncoder(cfg, max_batch=1).load_state_dict(ref_model.state_dict())
+    ids = torch.randint(0, 49408, (1, 576), generator=torch.Generator().manual_seed(6)).to(dev)
+    with torch.no_grad():
+        ref = ref_model(ids)[0]
+    got = enc(ids)[0]
+    assert torch.isfinite(got).all()
+    err = ((got - ref).norm() / ref.norm()).item()
+    print(f"native text encoder, 576 tokens: rel L2 {err:.3e}")
+    assert err < 1e-2
+    ids2 = ids.clone(); ids2[:, 500:] = (ids2[:, 500:] + 3) % 49408
+    assert torch.equal(enc(ids2)[0][:, :500], got[:, :500])
 
 
 @pytest.mark.gpu
