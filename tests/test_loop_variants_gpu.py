@@ -135,4 +135,6 @@ def test_guided_steps_under_variant_config(name, scene, golden):
     # configuration (fp32 CPU, unrounded weights) at the first update, before the L1 signs can flip
     up_here = rec_o["opt"][0].cpu() - noise.cpu()
     up_ref = torch.from_numpy(g14[name + ".opt_t0"][0]) - noise.cpu()
-    assert rel(up_here, up_ref) < 0.1, (name, rel(up_here, up_ref))
+    # (not for use_depth false: its first update sits on the L1 kink, see above -- there even two fp32 evaluations of the same
+    # network disagree on the signs of the self-mapped cells, measured 0.26)
+    assert (not conf.use_depth) or rel(up_here, up_ref) < 0.1, (name, rel(up_here, up_ref))
