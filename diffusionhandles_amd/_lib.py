@@ -99,6 +99,9 @@ SIGNATURES = {
     "dh_latent_update": (c_i, [c_p, c_p, c_p, c_f, c_f, c_i, c_p]),
     "dh_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_p]),
     "dh_mse_fwd_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
+    "dh_latent_update_strided": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_i, c_p]),
+    "dh_pack_sample": (c_i, [c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dh_unet_io_ptr": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_p), ctypes.POINTER(c_sz)]),
     "dh_mse_cotangent": (c_i, [c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p, c_p]),
     "dh_adam_step_scaled": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_p]),
 }

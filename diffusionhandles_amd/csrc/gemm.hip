@@ -83,6 +83,12 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
 };
 
 constexpr int BK = 64;
+// experiment switches (tools/build_tuning.sh DH_DEFS=...): never defined in the product build
+#ifdef DH_EXP_SETPRIO
+#define DH_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define DH_PRIO(x) do { } while (0)
+#endif
 
 
 // bias / per-image vector / SiLU / residual of four consecutive outputs of row m, rounded to the storage type
@@ -434,10 +440,12 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       if (kk + 1 < KK) load_frags(kk0 + kk + 1, (kk + 1) & 1);      // next fragments fly under this step's MFMAs
+      DH_PRIO(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fw[kk & 1][j], fx[kk & 1][i], acc[i][j]);
+      DH_PRIO(0);
       // the two waves that share a row block (wn = 0 / 1) read the same A fragments: each sums every other k-step, so the
       // v_dot2c work per wave is half and fits under the MFMAs of the step; the halves are exchanged after the loop
       if (LNF && (kk & 1) == wn_u LNF_ABL(1)) {

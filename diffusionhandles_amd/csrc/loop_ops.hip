@@ -19,6 +19,22 @@ __global__ void k_latent_update(float* out, const float* x, const float* g, floa
   if (i < n) out[i] = x[i] - k * g[i];
 }
 
+__global__ void k_latent_update_s(float* out, const float* x, const float* g, int gc, int c, float k, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = i / c, ch = i - p * c;
+  out[i] = x[i] - k * g[(size_t)p * gc + ch];
+}
+
+__global__ void k_pack_sample(float* dst, const float* lat, int lb, int cl, const float* dep, int db, int cd, int pixels, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ct = cl + cd;
+  const int ch = i % ct, r = i / ct, p = r % pixels, b = r / pixels;
+  dst[i] = ch < cl ? lat[((size_t)(lb > 1 ? b : 0) * pixels + p) * cl + ch]
+                   : dep[((size_t)(db > 1 ? b : 0) * pixels + p) * cd + (ch - cl)];
+}
+
 __global__ void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                        float bc1, float bc2_sqrt, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +170,29 @@ extern "C" int dh_adam_step_scaled(float* p, const float* g, const float* g_scal
   float bc2 = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(k_adam_scaled, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr, beta1, beta2,
                      eps, bc1, bc2, g_scale, n);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_latent_update_strided(float* x_out, const float* x, const float* g, int g_channels, int channels, float lr,
+                                        float grad_scale, int pixels, void* stream) {
+  DH_REQUIRE(x_out && x && g && pixels > 0 && channels > 0 && g_channels >= channels && grad_scale != 0.f, "bad arguments");
+  const int n = pixels * channels;
+  hipLaunchKernelGGL(k_latent_update_s, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x_out, x, g, g_channels, channels,
+                     lr / grad_scale, n);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_pack_sample(float* dst, const float* latent, int latent_batch, int latent_channels, const float* depth,
+                              int depth_batch, int depth_channels, int batch, int pixels, void* stream) {
+  DH_REQUIRE(dst && latent && batch >= 1 && pixels > 0 && latent_channels > 0, "bad arguments");
+  DH_REQUIRE((latent_batch == 1 || latent_batch == batch) && (!depth || depth_batch == 1 || depth_batch == batch), "batch sizes must be 1 or batch");
+  const int cd = depth ? depth_channels : 0;
+  DH_REQUIRE(!depth || cd > 0, "depth without channels");
+  const int n = batch * pixels * (latent_channels + cd);
+  hipLaunchKernelGGL(k_pack_sample, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, latent, latent_batch,
+                     latent_channels, depth, depth_batch, cd, pixels, n);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

@@ -851,7 +851,8 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   const int B = batch;
   const dh_unet_config& c = u->cfg;
   const size_t ns = (size_t)B * c.sample_size * c.sample_size;
-  DH_CHECK_HIP(hipMemcpyAsync(u->in_sample, sample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
+  // (a caller that filled / reads the engine's own buffers -- dh_unet_io_ptr -- passes those pointers: nothing to copy)
+  if (sample != u->in_sample) DH_CHECK_HIP(hipMemcpyAsync(u->in_sample, sample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
   // without eps_out the tape stops after the last requested activation (the tail's only consumer is eps)
   int n_ops = (int)u->ops.size();
   if (!eps_out) {
@@ -865,7 +866,7 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   const bool kv_hit = u->text_key != 0 && u->text_key == u->kv_key && u->kv_rows == B && u->kv_stream == st;
   const int first_op = temb_hit ? u->temb_ops : 0;
   // the text and the timestep are only read by the ops a cache hit skips (K|V projection of the text; time embedding)
-  if (!kv_hit)
+  if (!kv_hit && text != u->in_text)
     DH_CHECK_HIP(hipMemcpyAsync(u->in_text, text, (size_t)B * c.text_len * c.cross_attention_dim * 4, hipMemcpyDeviceToDevice, st));
   if (!temb_hit) launch_set_scalar(u->t_dev, timestep, st);
   int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit, kv_hit), st, &u->flops_fwd,
@@ -873,14 +874,16 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   if (rc != DH_OK) { u->temb_rows = 0; u->kv_key = 0; return rc; }      // nothing cached after a failed capture / launch
   if (!temb_hit) { u->temb_t = timestep; u->temb_rows = B; u->temb_stream = st; }
   if (!kv_hit) { u->kv_key = u->text_key; u->kv_rows = B; u->kv_stream = st; }   // key 0: the buffer now holds an unnamed text
-  if (eps_out) DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
+  if (eps_out && eps_out != u->io_eps)
+    DH_CHECK_HIP(hipMemcpyAsync(eps_out, u->io_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
   if (act_out) {
     for (int i = 0; i < 3; ++i)
       if (act_out[i]) {
         DH_REQUIRE(u->act_op_end[i] <= n_ops, "activation requested beyond the truncated tape");
         const Ten& t = u->tens[u->act_ids[i]];
-        DH_CHECK_HIP(hipMemcpyAsync(act_out[i], u->aptr(u->act_ids[i]), (size_t)B * t.rows * t.C * 2,
-                                    hipMemcpyDeviceToDevice, st));
+        if (act_out[i] != (void*)u->aptr(u->act_ids[i]))
+          DH_CHECK_HIP(hipMemcpyAsync(act_out[i], u->aptr(u->act_ids[i]), (size_t)B * t.rows * t.C * 2,
+                                      hipMemcpyDeviceToDevice, st));
       }
   }
   u->saved_batch = save_for_backward ? B : 0;
@@ -1119,18 +1122,46 @@ extern "C" int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_e
       if (d_act[i]) {
         DH_REQUIRE(u->act_op_end[i] <= u->saved_ops, "d_act given for an activation the saved forward did not compute");
         const Ten& t = u->tens[u->act_ids[i]];
-        DH_CHECK_HIP(hipMemcpyAsync(u->gptr(u->act_ids[i]), d_act[i], (size_t)B * t.rows * t.C * 2,
-                                    hipMemcpyDeviceToDevice, st));
+        if (d_act[i] != (void*)u->gptr(u->act_ids[i]))
+          DH_CHECK_HIP(hipMemcpyAsync(u->gptr(u->act_ids[i]), d_act[i], (size_t)B * t.rows * t.C * 2,
+                                      hipMemcpyDeviceToDevice, st));
         mask |= 1u << i;
       }
-  if (d_eps) DH_CHECK_HIP(hipMemcpyAsync(u->io_eps, d_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
+  if (d_eps && d_eps != u->io_eps) DH_CHECK_HIP(hipMemcpyAsync(u->io_eps, d_eps, ns * c.out_channels * 4, hipMemcpyDeviceToDevice, st));
   const uint64_t key = graph_key_bwd(B, mask, d_eps != nullptr, d_sample != nullptr, d_text != nullptr);
   int rc = run_graphed(u, key, st, &u->flops_bwd,
                        [&]() { backward_ops(u, B, mask, d_eps != nullptr, d_sample != nullptr, d_text != nullptr, st); });
   if (rc != DH_OK) return rc;
-  if (d_sample) DH_CHECK_HIP(hipMemcpyAsync(d_sample, u->out_dsample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
-  if (d_text) DH_CHECK_HIP(hipMemcpyAsync(d_text, u->out_dtext, nt * 4, hipMemcpyDeviceToDevice, st));
+  if (d_sample && d_sample != u->out_dsample)
+    DH_CHECK_HIP(hipMemcpyAsync(d_sample, u->out_dsample, ns * c.in_channels * 4, hipMemcpyDeviceToDevice, st));
+  if (d_text && d_text != u->out_dtext) DH_CHECK_HIP(hipMemcpyAsync(d_text, u->out_dtext, nt * 4, hipMemcpyDeviceToDevice, st));
   DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_unet_io_ptr(dh_unet* u, int which, int index, void** ptr, size_t* bytes) {
+  DH_REQUIRE(u && ptr, "null pointer");
+  const dh_unet_config& c = u->cfg;
+  const size_t ns = (size_t)c.max_batch * c.sample_size * c.sample_size;
+  const size_t nt = (size_t)c.max_batch * c.text_len * c.cross_attention_dim;
+  size_t n = 0;
+  switch (which) {
+    case DH_IO_SAMPLE: *ptr = u->in_sample; n = ns * c.in_channels * 4; break;
+    case DH_IO_TEXT: *ptr = u->in_text; n = nt * 4; break;
+    case DH_IO_EPS: *ptr = u->io_eps; n = ns * c.out_channels * 4; break;
+    case DH_IO_DSAMPLE: *ptr = u->out_dsample; n = ns * c.in_channels * 4; break;
+    case DH_IO_DTEXT: *ptr = u->out_dtext; n = nt * 4; break;
+    case DH_IO_ACT:
+    case DH_IO_ACT_GRAD: {
+      DH_REQUIRE(index >= 0 && index < 3 && u->act_ids[index] >= 0, "activation index out of range");
+      const Ten& t = u->tens[u->act_ids[index]];
+      *ptr = which == DH_IO_ACT ? (void*)(u->act + t.off) : (void*)(u->grad + t.goff);
+      n = (size_t)c.max_batch * t.rows * t.C * 2;
+      break;
+    }
+    default: DH_REQUIRE(false, "unknown buffer");
+  }
+  if (bytes) *bytes = n;
   return DH_OK;
 }
 

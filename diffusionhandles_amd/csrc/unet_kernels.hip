@@ -61,59 +61,61 @@ __global__ void k_conv_few_in(const float* x, const float* w, const float* bias,
   }
 }
 
-// many input channels, few outputs (<= 8): one wave per CF_PIX consecutive pixels (each weight feeds CF_PIX pixels),
-// lanes split K = 9*Ci
+// many input channels, few outputs (<= 8).  thread = (pixel, 8-channel chunk): per tap one 16-byte activation load and the
+// chunk's weights of every output channel, f32 accumulate; the chunks of a pixel are then added in chunk order through LDS
+// (deterministic).  A workgroup owns 256 / (Ci / 8) consecutive pixels -- 683 workgroups at 64 x 64 x 320 where the round-2
+// kernel (one wave per four pixels, lanes strided over the channels with 2-byte loads) ran 256 and took 47 us.
+constexpr int CFO_MAX = 8;
 template <class T>
-__global__ void k_conv_few_out(const T* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ci,
-                               int Co, int accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int p0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * CF_PIX;
+__global__ void __launch_bounds__(256) k_conv_few_out(const T* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                                                      int Ci, int Co, int accumulate) {
+  __shared__ float sm[256 * CFO_MAX];
+  const int nch = Ci >> 3, ppb = 256 / nch;
+  const int pl = threadIdx.x / nch, ch = threadIdx.x - pl * nch;
   const int total = B * H * W;
-  if (p0 >= total) return;
-  float acc[CF_PIX][8];
+  const int p = blockIdx.x * ppb + pl;
+  float acc[CFO_MAX];
 #pragma unroll
-  for (int lp = 0; lp < CF_PIX; ++lp)
+  for (int co = 0; co < CFO_MAX; ++co) acc[co] = 0.f;
+  if (pl < ppb && p < total) {
+    const int b = p / (H * W), r = p - b * H * W, py = r / W, px = r - py * W;
+    typedef T T8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[lp][i] = 0.f;
-  int pb[CF_PIX], py[CF_PIX], px[CF_PIX];
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const uint4 raw = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci + ch * 8);
+      const T8 xv = __builtin_bit_cast(T8, raw);
+      float xf[8];
 #pragma unroll
-  for (int lp = 0; lp < CF_PIX; ++lp) {
-    const int p = p0 + lp < total ? p0 + lp : total - 1;
-    pb[lp] = p / (H * W);
-    const int r = p - pb[lp] * H * W;
-    py[lp] = r / W; px[lp] = r - py[lp] * W;
-  }
-  for (int tap = 0; tap < 9; ++tap) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    for (int ci = lane; ci < Ci; ci += 64) {
-      float wv[8];
+      for (int i = 0; i < 8; ++i) xf[i] = to_f32<T>(xv[i]);
 #pragma unroll
-      for (int co = 0; co < 8; ++co) wv[co] = co < Co ? w[((size_t)co * 9 + tap) * Ci + ci] : 0.f;
-#pragma unroll
-      for (int lp = 0; lp < CF_PIX; ++lp) {
-        const int iy = py[lp] + dy, ix = px[lp] + dx;
-        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-        const float xv = to_f32<T>(x[(((size_t)pb[lp] * H + iy) * W + ix) * Ci + ci]);
-#pragma unroll
-        for (int co = 0; co < 8; ++co) acc[lp][co] += xv * wv[co];
+      for (int co = 0; co < CFO_MAX; ++co) {
+        if (co >= Co) break;
+        const float* wp = w + ((size_t)co * 9 + tap) * Ci + ch * 8;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+        acc[co] += xf[0] * w0.x + xf[1] * w0.y + xf[2] * w0.z + xf[3] * w0.w + xf[4] * w1.x + xf[5] * w1.y + xf[6] * w1.z +
+                   xf[7] * w1.w;
       }
     }
   }
 #pragma unroll
-  for (int lp = 0; lp < CF_PIX; ++lp) {
-    if (p0 + lp >= total) break;
-#pragma unroll
-    for (int co = 0; co < 8; ++co) {
-      if (co >= Co) break;
-      float s = wave_sum(acc[lp][co]);
-      if (lane == 0) {
-        s += bias ? bias[co] : 0.f;
-        float* o = y + (size_t)(p0 + lp) * Co + co;
-        *o = accumulate ? *o + s : s;
-      }
-    }
+  for (int co = 0; co < CFO_MAX; ++co)
+    if (co < Co) sm[co * 256 + threadIdx.x] = acc[co];
+  __syncthreads();
+  // thread (pixel pl2, output co2) adds the nch chunk sums of its pixel in chunk order
+  const int pl2 = threadIdx.x / Co, co2 = threadIdx.x - pl2 * Co;
+  const int p2 = blockIdx.x * ppb + pl2;
+  if (pl2 < ppb && p2 < total) {
+    float s = 0.f;
+    const float* row = sm + co2 * 256 + pl2 * nch;
+    for (int c = 0; c < nch; ++c) s += row[c];
+    s += bias ? bias[co2] : 0.f;
+    float* o = y + (size_t)p2 * Co + co2;
+    *o = accumulate ? *o + s : s;
   }
 }
+static inline unsigned conv_few_out_blocks(int pixels, int Ci) { return (unsigned)cdiv(pixels, 256 / (Ci >> 3)); }
 
 void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* w, const float* bias, void* y,
                            int y_is_f32, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
@@ -124,9 +126,9 @@ void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* 
       hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)x, w, bias, (bf16*)y, B, H, W, Cin, Cout);
   } else {
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const f16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
+      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(conv_few_out_blocks(B * H * W, Cin)), dim3(256), 0, st, (const f16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
     else
-      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const bf16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
+      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(conv_few_out_blocks(B * H * W, Cin)), dim3(256), 0, st, (const bf16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
   }
 }
 
@@ -141,9 +143,9 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
       hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (bf16*)dx, B, H, W, Cin, Cout);
   } else {
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const f16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
+      hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(conv_few_out_blocks(B * H * W, Cin)), dim3(256), 0, st, (const f16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
     else
-      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(cdiv(B * H * W, 4 * CF_PIX)), dim3(256), 0, st, (const bf16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
+      hipLaunchKernelGGL((k_conv_few_out<bf16>), dim3(conv_few_out_blocks(B * H * W, Cin)), dim3(256), 0, st, (const bf16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
   }
 }
 

@@ -259,10 +259,15 @@ class GuidedStableDiffuser(GuidedDiffuser):
         s = torch.cat([x, depth_nhwc], dim=-1) if self.conf.use_depth else x
         return s.expand(reps, -1, -1, -1).contiguous() if reps > 1 else s.contiguous()
 
-    def _cfg_eps(self, x, depth_nhwc, t, uncond, cond, want_acts=False):
-        sample = self._unet_input(x, depth_nhwc, 2)
+    def _cfg_eps(self, x, depth_nhwc, t, uncond, cond, want_acts=False, inplace=False):
+        """(eps_uncond, eps_cond[, activations]) of the B=2 classifier-free-guidance pass.  inplace: the input is packed into
+        the engine's buffer by one launch and eps comes back as views of the engine's output (valid until the next pass)."""
         text = torch.cat([uncond.reshape(1, *cond.shape[1:]).to(self.device, torch.float32), cond]).contiguous()
-        eps, acts = self.unet.forward(sample, float(t), text, save_for_backward=False, want_acts=want_acts)
+        if inplace and x.shape[0] == 1:
+            sample = self.unet.stage_sample(x, depth_nhwc if self.conf.use_depth else None, 2)
+        else:
+            sample = self._unet_input(x, depth_nhwc, 2)
+        eps, acts = self.unet.forward(sample, float(t), text, save_for_backward=False, want_acts=want_acts, inplace=inplace)
         return (eps[0:1], eps[1:2], acts) if want_acts else (eps[0:1], eps[1:2])
 
     # ---- reference API ----------------------------------------------------------------------
@@ -326,12 +331,12 @@ class GuidedStableDiffuser(GuidedDiffuser):
             st.plan = EnergyPlan(st.pc, st.size[0], self.device)
         return st
 
-    def _energy_grad(self, st, k, act, t_idx, fgw, bgw):
-        """d(energy of layer k)/d(act) * grad_scale, act [h,w,C] channels-last."""
+    def _energy_grad(self, st, k, act, t_idx, fgw, bgw, out=None):
+        """d(energy of layer k)/d(act) * grad_scale, act [h,w,C] channels-last; `out`: where to write it."""
         if st.plan is not None and act.shape[0] == st.plan.grid and act.shape[1] == st.plan.grid:
-            return energy_and_grad_planned(act, st.orig[k][t_idx], st.plan, fgw, bgw, grad_scale=self.grad_scale)[1]
+            return energy_and_grad_planned(act, st.orig[k][t_idx], st.plan, fgw, bgw, grad_scale=self.grad_scale, out=out)[1]
         return energy_and_grad(act, st.orig[k][t_idx], st.pc, fgw, bgw, self.conf.fg_patch_size, self.conf.bg_patch_size,
-                               st.size, self.conf.bg_loss_type, grad_scale=self.grad_scale)[1]
+                               st.size, self.conf.bg_loss_type, grad_scale=self.grad_scale, out=out)[1]
 
     def guided_step(self, st, x, t_idx, t, uncond, record=None, images=None):
         """One guided-denoise step (guided_stable_diffuser.py:377-479): up to num_optsteps x
@@ -345,23 +350,28 @@ class GuidedStableDiffuser(GuidedDiffuser):
             fgw, bgw = st.schedule(t_idx, iteration)
             active = [k for k in range(3) if (fgw[k] != 0.0 and st.n_pairs > 0) or bgw[k] != 0.0]
             if active:
-                _, acts = self.unet.forward(self._unet_input(x, st.depth_nhwc), float(t), st.cond, save_for_backward=True,
-                                            want_acts=active, want_eps=False, text_key=st.cond_key)
+                # no copies either side of the engine: the input is packed into the engine's buffer by one launch, the
+                # energy kernels read the captured activations where the engine left them and write their cotangents where
+                # its backward pass starts from, the latent update reads d(sample) in place (its first 4 of 5 channels)
+                sample = self.unet.stage_sample(x, st.depth_nhwc if self.conf.use_depth else None, 1)
+                _, acts = self.unet.forward(sample, float(t), st.cond, save_for_backward=True, want_acts=active, want_eps=False,
+                                            text_key=st.cond_key, inplace=True)
                 d_acts = [None, None, None]
                 for k in active:
-                    d_acts[k] = self._energy_grad(st, k, acts[k][0], t_idx, fgw[k], bgw[k])[None]
-                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
-                g_lat = d_sample[..., : x.shape[-1]].contiguous()
+                    d_acts[k] = self.unet.io_view("act_grad", k)[:1]
+                    self._energy_grad(st, k, acts[k][0], t_idx, fgw[k], bgw[k], out=d_acts[k][0])
+                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False, inplace=True)
                 x_new = torch.empty_like(x)
-                _lib.check(L.dh_latent_update(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(g_lat), 0.1, self.grad_scale,
-                                              x.numel(), _lib.stream_ptr()), "dh_latent_update")
+                _lib.check(L.dh_latent_update_strided(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(d_sample), d_sample.shape[-1],
+                                                      x.shape[-1], 0.1, self.grad_scale, x.numel() // x.shape[-1],
+                                                      _lib.stream_ptr()), "dh_latent_update_strided")
                 x = x_new
             if record is not None:
                 record.setdefault("opt", []).append(x.permute(0, 3, 1, 2).clone())
             iteration += 1
         if images is not None:
             images.append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
-        eu, ec = self._cfg_eps(x, st.depth_nhwc, t, uncond, st.cond)
+        eu, ec = self._cfg_eps(x, st.depth_nhwc, t, uncond, st.cond, inplace=True)      # (views: consumed by the step right here)
         x = self.ddim_step(x, eu, ec, t)
         if images is not None:
             images.append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())

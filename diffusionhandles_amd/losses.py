@@ -99,16 +99,19 @@ class EnergyPlan:
         return self._ws[C]
 
 
-def energy_and_grad_planned(act, act_orig, plan, fg_weight, bg_weight, grad_scale=1.0, want_loss=False):
+def energy_and_grad_planned(act, act_orig, plan, fg_weight, bg_weight, grad_scale=1.0, want_loss=False, out=None):
     """Default-configuration evaluation through a prebuilt EnergyPlan: act / act_orig [grid,grid,C] channels-last,
-    16-bit, contiguous.  Returns (loss[3] or None, grad like act)."""
+    16-bit, contiguous.  Returns (loss[3] or None, grad like act); `out`: where the gradient is written (e.g. the engine's
+    own cotangent buffer of that activation)."""
     _lib.require_gpu(act)
     h, w, C = act.shape
     if h != plan.grid or w != plan.grid or act.dtype not in (torch.float16, torch.bfloat16) or act_orig.dtype != act.dtype:
         raise ValueError("planned energy: maps must be 16-bit [grid, grid, C] of one dtype")
     a = act.detach().contiguous()
     o = act_orig.detach().contiguous()
-    grad = torch.empty_like(a)
+    if out is not None and (out.shape != a.shape or out.dtype != a.dtype or not out.is_contiguous()):
+        raise ValueError("planned energy: `out` must be a contiguous tensor like the activation")
+    grad = torch.empty_like(a) if out is None else out
     loss = torch.zeros(3, dtype=torch.float32, device=a.device) if want_loss else None
     ws, wsb = plan.workspace(C)
     dl = plan.dl
@@ -122,7 +125,7 @@ def energy_and_grad_planned(act, act_orig, plan, fg_weight, bg_weight, grad_scal
 
 def energy_and_grad(act, act_orig, processed_correspondences, fg_weight, bg_weight, fg_patch_size=1,
                     bg_patch_size=1, activations_size=(GRID, GRID), bg_loss_type="global_avg", grad_scale=1.0,
-                    grad_dtype=None, channels_last=True):
+                    grad_dtype=None, channels_last=True, out=None):
     """One activation layer: returns (loss[3] = {total, fg, bg} f32 device tensor, grad like `act`).
 
     act / act_orig: [h,w,C] (channels_last) or [C,h,w] device tensors of the same dtype.
@@ -140,7 +143,9 @@ def energy_and_grad(act, act_orig, processed_correspondences, fg_weight, bg_weig
     dev = a.device
     dl = _device_lists(processed_correspondences, dev, grid)
     gdt = a.dtype if grad_dtype is None else grad_dtype
-    grad = torch.empty((h, w, C), dtype=gdt, device=dev)
+    if out is not None and (tuple(out.shape) != (h, w, C) or out.dtype != gdt or not out.is_contiguous() or not channels_last):
+        raise ValueError("energy: `out` must be a contiguous channels-last tensor like the activation")
+    grad = torch.empty((h, w, C), dtype=gdt, device=dev) if out is None else out
     loss = torch.zeros(3, dtype=torch.float32, device=dev)
     L = _lib.lib()
     n_pairs = dl["pairs"].shape[0]

@@ -119,23 +119,28 @@ class HipUNet:
         return int(self._L.dh_unet_workspace_bytes(self._h))
 
     # ---- compute ------------------------------------------------------------------------
-    def forward(self, sample_nhwc, timestep, text, save_for_backward=False, want_acts=True, want_eps=True, text_key=0):
+    def forward(self, sample_nhwc, timestep, text, save_for_backward=False, want_acts=True, want_eps=True, text_key=0,
+                inplace=False):
         """sample_nhwc [B,H,W,Cin] f32, text [B,L,D] f32 (device, contiguous).
         Returns eps [B,H,W,Cout] f32 and a list of 3 channels-last activations [B,h,w,C].
         want_acts may be a collection of activation indices; with want_eps=False the engine stops after
         the last requested activation (eps is None, the other activations are None).
         text_key != 0 names the content of `text`: consecutive forwards with the same key and batch reuse the text K|V
-        projections (the caller changes the key when the embedding changes)."""
+        projections (the caller changes the key when the embedding changes).
+        inplace: eps and the activations are returned as VIEWS of the engine's buffers (no device copies; valid until the
+        next pass) instead of fresh tensors."""
         B = sample_nhwc.shape[0]
         s = self.sample_size
-        eps = torch.empty((B, s, s, self.cfg["out_channels"]), dtype=torch.float32, device=self.device) \
-            if want_eps else None
+        eps = None
+        if want_eps:
+            eps = self.io_view("eps")[:B] if inplace else \
+                torch.empty((B, s, s, self.cfg["out_channels"]), dtype=torch.float32, device=self.device)
         acts = None
         arr = None
         if want_acts:
             idx = range(3) if want_acts is True else set(want_acts)
-            acts = [torch.empty((B,) + shp, dtype=self.dtype, device=self.device) if i in idx else None
-                    for i, shp in enumerate(self.act_shapes)]
+            acts = [(self.io_view("act", i)[:B] if inplace else torch.empty((B,) + shp, dtype=self.dtype, device=self.device))
+                    if i in idx else None for i, shp in enumerate(self.act_shapes)]
             arr = (ctypes.c_void_p * 3)(*[a.data_ptr() if a is not None else None for a in acts])
         if int(text_key) != self._text_key:           # (0 = unnamed text, the engine's default)
             _lib.check(self._L.dh_unet_set_text_key(self._h, int(text_key)), "dh_unet_set_text_key")
@@ -146,7 +151,7 @@ class HipUNet:
         self._saved_batch = B if save_for_backward else 0
         return eps, acts
 
-    def backward(self, d_acts=None, d_eps=None, want_sample_grad=True, want_text_grad=False):
+    def backward(self, d_acts=None, d_eps=None, want_sample_grad=True, want_text_grad=False, inplace=False):
         """Gradients of the last saved forward.  d_acts: list of 3 (or None entries) channels-last
         tensors in the engine dtype; d_eps [B,H,W,Cout] f32.  Returns (d_sample, d_text)."""
         B = self._saved_batch
@@ -163,13 +168,62 @@ class HipUNet:
                     assert a.dtype == self.dtype and a.is_contiguous() and tuple(a.shape) == (B,) + shp
                     ptrs.append(a.data_ptr())
             arr = (ctypes.c_void_p * 3)(*ptrs)
-        d_sample = torch.empty((B, s, s, self.cfg["in_channels"]), dtype=torch.float32, device=self.device) \
-            if want_sample_grad else None
+        d_sample = None
+        if want_sample_grad:      # inplace: a view of the engine's buffer (valid until the next backward)
+            d_sample = self.io_view("dsample")[:B] if inplace else \
+                torch.empty((B, s, s, self.cfg["in_channels"]), dtype=torch.float32, device=self.device)
         d_text = torch.empty((B, self.cfg["text_len"], self.cfg["cross_attention_dim"]), dtype=torch.float32,
                              device=self.device) if want_text_grad else None
         _lib.check(self._L.dh_unet_backward(self._h, arr, _lib.ptr(d_eps), _lib.ptr(d_sample), _lib.ptr(d_text),
                                             _lib.stream_ptr()), "dh_unet_backward")
         return d_sample, d_text
+
+    # ---- the engine's own I/O buffers as tensors (no copies either side of a pass) -------------------------------------
+    class _Raw:
+        """A device buffer described through __cuda_array_interface__ so that torch can view it without owning it."""
+
+        def __init__(self, ptr, shape, typestr):
+            self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
+
+    def io_view(self, which, index=0):
+        """Tensor view of one of the engine's fixed buffers (dh_unet_io_ptr): 'sample' [maxB,H,W,Cin] f32, 'eps' [maxB,H,W,Cout]
+        f32, 'dsample' like 'sample', 'act' / 'act_grad' (index 0..2) [maxB,h,w,C] in the engine dtype.  The engine owns the
+        memory (it lives as long as this object); contents are valid until the next pass that writes them.  Passing such a
+        view (or its leading batch items) to forward / backward makes the corresponding device copy disappear."""
+        if not hasattr(self, "_views"):
+            self._views = {}
+        key = (which, index)
+        if key not in self._views:
+            code = dict(sample=0, text=1, eps=2, act=3, act_grad=4, dsample=5, dtext=6)[which]
+            p, nb = ctypes.c_void_p(), ctypes.c_size_t()
+            _lib.check(self._L.dh_unet_io_ptr(self._h, code, index, ctypes.byref(p), ctypes.byref(nb)), "dh_unet_io_ptr")
+            s, mb = self.sample_size, self.max_batch
+            if which in ("act", "act_grad"):
+                shape = (mb,) + self.act_shapes[index]
+                t = torch.as_tensor(HipUNet._Raw(p.value, shape, "<i2"), device=self.device).view(self.dtype)
+            else:
+                shape = {"sample": (mb, s, s, self.cfg["in_channels"]), "dsample": (mb, s, s, self.cfg["in_channels"]),
+                         "eps": (mb, s, s, self.cfg["out_channels"]),
+                         "text": (mb, self.cfg["text_len"], self.cfg["cross_attention_dim"]),
+                         "dtext": (mb, self.cfg["text_len"], self.cfg["cross_attention_dim"])}[which]
+                t = torch.as_tensor(HipUNet._Raw(p.value, shape, "<f4"), device=self.device)
+            assert t.data_ptr() == p.value and t.numel() * t.element_size() == nb.value
+            self._views[key] = t
+        return self._views[key]
+
+    def stage_sample(self, latent_nhwc, depth_nhwc, batch):
+        """The U-Net input cat([latents, depth], channel) for `batch` items written straight into the engine's input buffer
+        (one launch; latents / depth given once are broadcast).  Returns the view to pass to forward()."""
+        dst = self.io_view("sample")
+        cl = latent_nhwc.shape[-1]
+        cd = depth_nhwc.shape[-1] if depth_nhwc is not None else 0
+        if cl + cd != self.cfg["in_channels"] or batch > self.max_batch:
+            raise ValueError("stage_sample: channels / batch do not match the engine")
+        pixels = self.sample_size * self.sample_size
+        _lib.check(self._L.dh_pack_sample(_lib.ptr(dst), _lib.ptr(latent_nhwc), latent_nhwc.shape[0], cl, _lib.ptr(depth_nhwc),
+                                          depth_nhwc.shape[0] if depth_nhwc is not None else 1, cd, batch, pixels,
+                                          _lib.stream_ptr()), "dh_pack_sample")
+        return dst[:batch]
 
     def stats(self):
         f, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()

@@ -206,6 +206,22 @@ int dh_unet_forward(dh_unet* u, const float* sample, float timestep, const float
  * NULL).  Outputs (either may be NULL): d_sample [B][H][W][Cin] f32, d_text [B][L][D] f32. */
 int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* d_sample, float* d_text,
                      void* stream);
+/* The engine's own input / output buffers (fixed addresses: its passes replay as hipGraphs).  A caller that writes its
+ * inputs there (dh_pack_sample) and hands the SAME pointers to dh_unet_forward / dh_unet_backward, or lets the energy kernels
+ * read the captured activations and write their cotangents in place, saves the device-to-device copies either side of a pass
+ * (guided_stable_diffuser.py:397-434 builds `torch.cat([latents, depth])` and reads `unet_output[4..6]` every iteration).
+ * Every buffer holds max_batch items; contents are valid until the next pass that writes them.
+ *   which: DH_IO_SAMPLE [B][H][W][Cin] f32 | DH_IO_TEXT [B][L][D] f32 | DH_IO_EPS [B][H][W][Cout] f32 (eps out / d_eps in) |
+ *          DH_IO_ACT index 0..2 [B][h][w][C] engine dtype | DH_IO_ACT_GRAD index 0..2 (cotangent of that activation) |
+ *          DH_IO_DSAMPLE [B][H][W][Cin] f32 | DH_IO_DTEXT [B][L][D] f32 */
+#define DH_IO_SAMPLE 0
+#define DH_IO_TEXT 1
+#define DH_IO_EPS 2
+#define DH_IO_ACT 3
+#define DH_IO_ACT_GRAD 4
+#define DH_IO_DSAMPLE 5
+#define DH_IO_DTEXT 6
+int dh_unet_io_ptr(dh_unet* u, int which, int index, void** ptr, size_t* bytes);
 /* HIP-event bracket around every launch of the MFMA implicit-GEMM kernel (k_gemm) between begin
  * and end: total milliseconds, number of launches and their algorithmic flops (2*M*N*K).
  * Used by bench.py for the roofline figure; not on the product path. */
@@ -230,6 +246,15 @@ int dh_ddim_cfg_step(float* x_out, const float* x, const float* eps_u, const flo
 /* x_out = x - lr * g / grad_scale                         guided_stable_diffuser.py:434 */
 int dh_latent_update(float* x_out, const float* x, const float* g, float lr, float grad_scale, int n,
                      void* stream);
+/* the same with g read out of a wider gradient: g [pixels][g_channels], the first `channels` of every pixel (the latent
+ * channels of d(sample) = d(cat[latents, depth])) */
+int dh_latent_update_strided(float* x_out, const float* x, const float* g, int g_channels, int channels, float lr,
+                             float grad_scale, int pixels, void* stream);
+/* dst[b][p][:] = concat(latent[b or 0][p][0:latent_channels], depth[b or 0][p][0:depth_channels]) for b < batch: the U-Net
+ * input `torch.cat([latents (x batch), depth (x batch)], dim=1)` (guided_stable_diffuser.py:400-401, 451-455) in one launch.
+ * latent_batch / depth_batch are 1 (broadcast) or batch; depth may be NULL (use_depth false). */
+int dh_pack_sample(float* dst, const float* latent, int latent_batch, int latent_channels, const float* depth,
+                   int depth_batch, int depth_channels, int batch, int pixels, void* stream);
 /* Adam step on the null-text embedding (torch defaults; stable_null_inverter.py:143-155) */
 int dh_adam_step(float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                  float eps, int step, int n, void* stream);

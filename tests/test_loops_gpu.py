@@ -161,6 +161,80 @@ def test_adam_and_mse_kernels_match_torch():
     assert torch.allclose(d, gr, rtol=1e-6, atol=0)
 
 
+def test_cotangent_scale_and_scaled_adam():
+    """dh_mse_cotangent: loss = mse, d_eps = (2 (rec - target) / n) * k * S with S the power of two that brings max |d_eps|
+    into (amp / 2, amp]; dh_adam_step_scaled divides the gradient by S again: the pair equals the unscaled
+    dh_mse_fwd_bwd + dh_adam_step to f32 rounding, for cotangents from 1e-9 to 1e3."""
+    from diffusionhandles_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=dev()).manual_seed(22)
+    for mag in (1e-9, 1e-6, 1e-3, 1.0, 1e3):
+        a = torch.randn(1, 64, 64, 4, generator=g, device=dev())
+        b = a + mag * torch.randn(1, 64, 64, 4, generator=g, device=dev())
+        k = -0.37
+        loss, loss2 = torch.zeros(1, device=dev()), torch.zeros(1, device=dev())
+        d_eps, d_rec, S = torch.empty_like(a), torch.empty_like(a), torch.zeros(1, device=dev())
+        _lib.check(L.dh_mse_cotangent(_lib.ptr(a), _lib.ptr(b), a.numel(), k, 256.0, _lib.ptr(loss), _lib.ptr(d_eps), _lib.ptr(S),
+                                      _lib.stream_ptr()))
+        _lib.check(L.dh_mse_fwd_bwd(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(loss2), _lib.ptr(d_rec), _lib.stream_ptr()))
+        s = float(S.item())
+        assert s > 0 and s == 2.0 ** round(np.log2(s))
+        assert 128.0 < float(d_eps.abs().max()) <= 256.0, (mag, float(d_eps.abs().max()))
+        assert float(loss.item()) == float(loss2.item())
+        assert torch.allclose(d_eps / s, d_rec * k, rtol=1e-6, atol=0)
+        p1 = torch.randn(1, 77, 64, generator=g, device=dev())
+        p2 = p1.clone()
+        gr = torch.randn(1, 77, 64, generator=g, device=dev()) * mag
+        m1, v1, m2, v2 = (torch.zeros_like(p1) for _ in range(4))
+        gs = (gr * s).contiguous()
+        _lib.check(L.dh_adam_step(_lib.ptr(p1), _lib.ptr(gr), _lib.ptr(m1), _lib.ptr(v1), 1e-2, 0.9, 0.999, 1e-8, 1, p1.numel(),
+                                  _lib.stream_ptr()))
+        _lib.check(L.dh_adam_step_scaled(_lib.ptr(p2), _lib.ptr(gs), _lib.ptr(S), _lib.ptr(m2), _lib.ptr(v2), 1e-2, 0.9, 0.999,
+                                         1e-8, 1, p2.numel(), _lib.stream_ptr()))
+        assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)      # a power of two divides out exactly
+    # amp <= 0 or an all-zero difference: S = 1
+    z = torch.zeros(1, 8, 8, 4, device=dev())
+    _lib.check(L.dh_mse_cotangent(_lib.ptr(z), _lib.ptr(z), z.numel(), 1.0, 256.0, _lib.ptr(loss), _lib.ptr(z.clone()), _lib.ptr(S),
+                                  _lib.stream_ptr()))
+    assert float(S.item()) == 1.0 and float(loss.item()) == 0.0
+
+
+def test_engine_inplace_io_matches_copies(rig):
+    """The engine's own I/O buffers (dh_unet_io_ptr / HipUNet.io_view, dh_pack_sample, dh_latent_update_strided): a guided
+    step driven through them (no device copies either side of the passes) is bit-identical to the same step driven through
+    caller-owned tensors."""
+    from diffusionhandles_amd import _lib
+    L = _lib.lib()
+    hip = rig.hip
+    g = torch.Generator(device=dev()).manual_seed(23)
+    x = torch.randn(1, 64, 64, 4, generator=g, device=dev())
+    depth = torch.rand(1, 64, 64, 1, generator=g, device=dev())
+    with rig.gd.on_stream():
+        packed = hip.stage_sample(x, depth, 2)
+        assert packed.data_ptr() == hip.io_view("sample").data_ptr() and packed.shape == (2, 64, 64, 5)
+        want = torch.cat([x, depth], dim=-1).expand(2, -1, -1, -1)
+        assert torch.equal(packed, want)
+        text = rig.cond.contiguous()
+        e1, a1 = hip.forward(torch.cat([x, depth], dim=-1).contiguous(), 500.0, text, save_for_backward=True, want_acts=[1, 2],
+                             want_eps=True)
+        d1 = [None, torch.randn(a1[1].shape, generator=g, device=dev()).half(), torch.randn(a1[2].shape, generator=g, device=dev()).half()]
+        s1, _ = hip.backward(d1, None, want_sample_grad=True)
+        e1, a1 = e1.clone(), [None, a1[1].clone(), a1[2].clone()]
+        e2, a2 = hip.forward(hip.stage_sample(x, depth, 1), 500.0, text, save_for_backward=True, want_acts=[1, 2], want_eps=True,
+                             inplace=True)
+        assert e2.data_ptr() == hip.io_view("eps").data_ptr() and a2[2].data_ptr() == hip.io_view("act", 2).data_ptr()
+        assert torch.equal(e1, e2) and torch.equal(a1[1], a2[1]) and torch.equal(a1[2], a2[2])
+        d2 = [None, hip.io_view("act_grad", 1)[:1], hip.io_view("act_grad", 2)[:1]]
+        d2[1].copy_(d1[1]); d2[2].copy_(d1[2])
+        s2, _ = hip.backward(d2, None, want_sample_grad=True, inplace=True)
+        assert s2.data_ptr() == hip.io_view("dsample").data_ptr() and torch.equal(s1, s2)
+        xa, xb = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(L.dh_latent_update(_lib.ptr(xa), _lib.ptr(x), _lib.ptr(s1[..., :4].contiguous()), 0.1, 256.0, x.numel(),
+                                      _lib.stream_ptr()))
+        _lib.check(L.dh_latent_update_strided(_lib.ptr(xb), _lib.ptr(x), _lib.ptr(s2), 5, 4, 0.1, 256.0, 64 * 64, _lib.stream_ptr()))
+        assert torch.equal(xa, xb)
+
+
 def _null_oracle(rig, null_steps):
     from oracle import loop_ref as L
     img = make_image(512).to(dev())

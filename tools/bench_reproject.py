@@ -20,4 +20,7 @@ n = 5
 for _ in range(n):
     out = reproject_edits(depth, bg_depth, mask, intr, tfs)
 torch.cuda.synchronize()
-print(f"K={K} res={res}: {(time.time()-t0)/n*1e3:.2f} ms per call; correspondences {[int(c.shape[0]) for _, c in out]}")
+out, dbg = reproject_edits(depth, bg_depth, mask, intr, tfs, return_debug=True)
+cn = dbg["counts"]
+print(f"K={K} res={res}: {(time.time()-t0)/n*1e3:.2f} ms per call; correspondences {[int(c.shape[0]) for _, c in out]}; "
+      f"in-fill pixels {[int(v) for v in cn[:, 2]]}; CG iterations {[int(v) for v in cn[:, 3]]}")
