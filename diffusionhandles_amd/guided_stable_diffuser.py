@@ -107,6 +107,9 @@ class GuidedStableDiffuser(GuidedDiffuser):
         self.device = torch.device("cpu")
         # fp16 needs the guidance gradient scaled through the backward pass
         self.grad_scale = 256.0 if dtype == torch.float16 else 1.0
+        # guided_step drives the engine through its own I/O buffers (no device copies / torch.cat around the passes); False
+        # routes the same kernels through caller-owned tensors (bit-identical; kept for tools/ab_inplace.py)
+        self._inplace_io = True
 
     # ---- plumbing -----------------------------------------------------------------------
     def to(self, device=None):
@@ -353,14 +356,16 @@ class GuidedStableDiffuser(GuidedDiffuser):
                 # no copies either side of the engine: the input is packed into the engine's buffer by one launch, the
                 # energy kernels read the captured activations where the engine left them and write their cotangents where
                 # its backward pass starts from, the latent update reads d(sample) in place (its first 4 of 5 channels)
-                sample = self.unet.stage_sample(x, st.depth_nhwc if self.conf.use_depth else None, 1)
+                ip = self._inplace_io
+                sample = self.unet.stage_sample(x, st.depth_nhwc if self.conf.use_depth else None, 1) if ip else \
+                    self._unet_input(x, st.depth_nhwc)
                 _, acts = self.unet.forward(sample, float(t), st.cond, save_for_backward=True, want_acts=active, want_eps=False,
-                                            text_key=st.cond_key, inplace=True)
+                                            text_key=st.cond_key, inplace=ip)
                 d_acts = [None, None, None]
                 for k in active:
-                    d_acts[k] = self.unet.io_view("act_grad", k)[:1]
+                    d_acts[k] = self.unet.io_view("act_grad", k)[:1] if ip else torch.empty_like(acts[k])
                     self._energy_grad(st, k, acts[k][0], t_idx, fgw[k], bgw[k], out=d_acts[k][0])
-                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False, inplace=True)
+                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False, inplace=ip)
                 x_new = torch.empty_like(x)
                 _lib.check(L.dh_latent_update_strided(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(d_sample), d_sample.shape[-1],
                                                       x.shape[-1], 0.1, self.grad_scale, x.numel() // x.shape[-1],
@@ -371,7 +376,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
             iteration += 1
         if images is not None:
             images.append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())
-        eu, ec = self._cfg_eps(x, st.depth_nhwc, t, uncond, st.cond, inplace=True)      # (views: consumed by the step right here)
+        eu, ec = self._cfg_eps(x, st.depth_nhwc, t, uncond, st.cond, inplace=self._inplace_io)      # (views: consumed by the step right here)
         x = self.ddim_step(x, eu, ec, t)
         if images is not None:
             images.append(self.decode_latent_image(x.permute(0, 3, 1, 2)).cpu())

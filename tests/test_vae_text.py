@@ -111,10 +111,12 @@ def test_native_vae_encoder_matches_the_torch_restatement(dtype, tol):
     # another resolution than the engines were built for: both directions fall back to the module
     z16 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(10)).to(dev)
     with torch.no_grad():
-        # (allclose, not equal: MIOpen may pick another convolution algorithm on the second call of the same module)
-        assert torch.allclose(wrap.decode(z16)["sample"], vae.decode(z16)["sample"], rtol=1e-4, atol=1e-5)
-        assert torch.allclose(wrap.encode(img[..., :128, :128])["latent_dist"].mean,
-                              vae.encode(img[..., :128, :128])["latent_dist"].mean, rtol=1e-4, atol=1e-5)
+        # (a relative-L2 bound, not equality: MIOpen may pick another convolution algorithm on the second call of the module)
+        d_a, d_b = wrap.decode(z16)["sample"], vae.decode(z16)["sample"]
+        assert ((d_a - d_b).norm() / d_b.norm()).item() < 1e-3
+        e_a = wrap.encode(img[..., :128, :128])["latent_dist"].mean
+        e_b = vae.encode(img[..., :128, :128])["latent_dist"].mean
+        assert ((e_a - e_b).norm() / e_b.norm()).item() < 1e-3
     with torch.no_grad():
         zr = vae.encode(img)["latent_dist"].mean
     assert ((z - zr).norm() / zr.norm()).item() < tol
