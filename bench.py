@@ -329,7 +329,7 @@ def main():
         tfs = [(TRANSFORMS[(i + rank) % 8][0], Y, torch.tensor(TRANSFORMS[(i + rank) % 8][1])) for i in range(K)]
         with torch.no_grad():
             # batched guided steps (every rank runs them: they also capture the batch-K graphs the whole-edit timing replays)
-            edits = reproject_edits(depth, bg_depth, mask, gd.get_depth_intrinsics(), tfs)
+            edits = reproject_edits(depth, bg_depth, mask, gd.get_depth_intrinsics(), tfs, device_correspondences=True)
             sts = [gd.prepare_guidance(d, prompt, acts, c) for d, c in edits]
             xb = x0.expand(K, -1, -1, -1).contiguous()
             with gd.on_stream():
@@ -407,7 +407,7 @@ def main():
                             "us": round(sec * 1e6, 2), "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK,
                             "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK, 4)})
             tfs8 = [(TRANSFORMS[i % 8][0], Y, torch.tensor(TRANSFORMS[i % 8][1])) for i in range(8)]
-            sec = timed(lambda: reproject_edits(depth_, bg_, mask_, gd_.get_depth_intrinsics(), tfs8), n=5)
+            sec = timed(lambda: reproject_edits(depth_, bg_, mask_, gd_.get_depth_intrinsics(), tfs8, device_correspondences=True), n=5)
             per_edit = 9e6 * (res / 512.0) ** 2
             out.append({"kernel": f"batched K=8 unproject -> SE(3) -> z-buffer -> index maps at {res}x{res} (whole reproject_edits "
                                   "call, host glue included)", "bound": "hbm", "bytes": int(8 * per_edit),

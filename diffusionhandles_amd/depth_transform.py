@@ -91,11 +91,14 @@ def _xform_rows(transforms):
 
 
 def reproject_edits(depth, bg_depth, fg_mask, intrinsics, transforms, use_input_depth_normalization=False,
-                    return_debug=False):
+                    return_debug=False, device_correspondences=False):
     """K edits of one image.  transforms: list of (rot_angle_deg, rot_axis[3], translation[3]).
 
     Returns a list of (disparity [1,1,H,W] f32 on depth.device, correspondences [N,4] int64 CPU),
-    plus a dict of the intermediate device tensors when return_debug is set.
+    plus a dict of the intermediate device tensors when return_debug is set.  The reference hands the correspondences
+    over as a CPU tensor (depth_transform.py:339-343) and so does `transform_depth`; device_correspondences=True leaves
+    them where the kernels wrote them, for callers that feed them straight back to the device (the batched edit path:
+    `process_correspondences` accepts either) -- K device-to-host copies and K uploads less per call.
     """
     if fg_mask.shape[-2] != fg_mask.shape[-1]:
         raise RuntimeError(f"Expected fg_mask to be square, got shape {fg_mask.shape[-2]} x {fg_mask.shape[-1]}.")
@@ -154,7 +157,7 @@ def reproject_edits(depth, bg_depth, fg_mask, intrinsics, transforms, use_input_
     out = []
     for e in range(K):
         n = int(counts_h[e, 0])
-        out.append((disp[e][None, None].to(out_dev), corr[e, :n].cpu()))
+        out.append((disp[e][None, None].to(out_dev), corr[e, :n] if device_correspondences else corr[e, :n].cpu()))
     if return_debug:
         dbg = dict(zmap=zmap, raw_mask=raw, clean_mask=clean, vis=vis, target_xy=txy, counts=counts_h,
                    fg_pix=fg_pix[:n_fg], corr_dev=corr)

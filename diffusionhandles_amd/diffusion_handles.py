@@ -49,7 +49,7 @@ class DiffusionHandles:
         from .depth_transform import reproject_edits
         with torch.no_grad():
             edits = reproject_edits(depth, bg_depth, fg_mask, self.diffuser.get_depth_intrinsics(device=depth.device),
-                                    transforms, use_input_depth_normalization)
+                                    transforms, use_input_depth_normalization, device_correspondences=True)
             imgs = self.diffuser.guided_inference_batch(init_noise, [d for d, _ in edits], null_text_emb, prompt,
                                                         activations, [c for _, c in edits], fg_weight, bg_weight)
         return imgs, [d for d, _ in edits]
