@@ -226,17 +226,9 @@ template <> __device__ __forceinline__ void frag_sums<bf16>(const uint4& f_in, f
 // MW = 2: eight waves laid out 4 (M) x 2 (N) over a 256-row tile, 64 x (BN/2) outputs per wave as before: the A and W
 // tiles are shared by twice the MFMA work, so the staging traffic per flop (the TA / LDS-DMA issue that bounds the
 // 4-wave kernel on big grids) drops by a quarter and two waves share every SIMD.  For grids that fill the machine.
-// GNS (the 128 x 64 two-K-group tile only): the GroupNorm that consumes this output takes its slice statistics from this
-// epilogue instead of a k_gn_partial pass over the tensor.  The rounded outputs of the tile are staged through the (idle)
-// rings, a thread sums one column over 32 rows, and one thread per group adds its columns and the four row blocks in a fixed
-// order: (count, mean, M2) of (this row tile, this column tile's part of the group).  Slice index = 2 * (row tile of the
-// image) + (1 if the group starts in the column tile to the left): a group straddles at most two column tiles (64 columns,
-// >= 8 channels per group); the tile that holds a group's first column also zeroes the group's second slot when the group ends
-// inside it.  No atomics; the GroupNorm kernels merge the slices with Chan's formula as before.
-template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1, bool LNF = false, bool GNS = false>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1, bool LNF = false>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
 __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) {
   static_assert((WG == 1) + (KG == 1) + (MW == 1) >= 2, "one kind of wave grouping per instantiation");
-  static_assert(!GNS || (BM == 128 && BN == 64 && KG == 2 && WG == 1 && MW == 1 && !LNF), "epilogue statistics: 128 x 64 two-K-group tile only");
   static_assert(!LNF || (WG == 1 && MODE == GM_DENSE), "the folded LayerNorm needs every k-step of a row in one wave group");
   DH_STAMP(0);
   constexpr int NWV = 4 * MW;                               // waves that share one staged tile
@@ -559,46 +551,6 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
   }
 
-  // GNS: where the rounded outputs are staged (beyond the K-group merge buffer, which group 0 may still be reading)
-  unsigned short* gns_tile = reinterpret_cast<unsigned short*>(smem_all + 65536);      // [128][64] 16-bit
-  float* gns_red = reinterpret_cast<float*>(smem_all + 65536 + 16384);                // [4 row blocks][64 columns][2]
-  auto gns_stash = [&](int i, int j, const uint2 (&w)[4]) {
-    if (!GNS) return;
-    unsigned short* row = gns_tile + (wm * (BM / (2 * MW)) + i * 32 + ln) * 64 + wn * (BN / 2) + j * 32 + 4 * hi;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(row + 8 * g) = w[g];
-  };
-  auto gns_finish = [&]() {
-    if (!GNS) return;
-    __syncthreads();                       // (the waves of K group 1 have exited: the barrier counts the live ones)
-    const int c = tid & 63, rb = tid >> 6;
-    float a = 0.f, q = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < 32; ++r) {
-      const float v = to_f32<T>(reinterpret_cast<const T*>(gns_tile)[(rb * 32 + r) * 64 + c]);
-      a += v; q += v * v;
-    }
-    gns_red[(rb * 64 + c) * 2] = a;
-    gns_red[(rb * 64 + c) * 2 + 1] = q;
-    __syncthreads();
-    const int cpg = p.N / p.gn_G;
-    const int g_first = n0 / cpg, g_last = (n0 + BN - 1) / cpg;
-    const int g = g_first + tid;
-    if (g <= g_last && g < p.gn_G) {
-      const int c_lo = g * cpg > n0 ? g * cpg - n0 : 0;
-      const int c_hi = (g + 1) * cpg < n0 + BN ? (g + 1) * cpg - n0 : BN;
-      float sa = 0.f, sq = 0.f;
-      for (int rb2 = 0; rb2 < 4; ++rb2)
-        for (int cc = c_lo; cc < c_hi; ++cc) { sa += gns_red[(rb2 * 64 + cc) * 2]; sq += gns_red[(rb2 * 64 + cc) * 2 + 1]; }
-      const int img = m0 / p.gn_HW, rt = (m0 - img * p.gn_HW) / BM, S = p.gn_S;
-      const int piece = g * cpg < n0 ? 1 : 0;
-      const float cnt = (float)(BM * (c_hi - c_lo));
-      float* o = p.gn_part + ((size_t)(img * p.gn_G + g) * 3) * S + 2 * rt + piece;
-      o[0] = cnt; o[S] = sa / cnt; o[2 * S] = sq - sa * sa / cnt;
-      if (!piece && (g + 1) * cpg <= n0 + BN) { o[1] = 0.f; o[S + 1] = 0.f; o[2 * S + 1] = 0.f; }     // the group ends here: its second slot is empty
-    }
-  };
-
   DH_STAMP(5);
   // the common epilogue as straight-line code: bias and residual already sit in registers (prefetched under the K loop), no
   // per-image vector, no SiLU.  The general path below carries a fallback load and a ~90-instruction SiLU block per 4-column
@@ -628,13 +580,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
           o[0] = from_f32<T>(v0); o[1] = from_f32<T>(v1); o[2] = from_f32<T>(v2); o[3] = from_f32<T>(v3);
           w[g] = __builtin_bit_cast(uint2, o);
         }
-        gns_stash(i, j, w);
         const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
         *reinterpret_cast<uint4*>(orow + j * 32) = ca;
         *reinterpret_cast<uint4*>(orow + j * 32 + 16) = cb;
       }
     }
-    gns_finish();
     DH_STAMP(6);
 #ifdef DH_TUNING
     if (p.ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DH_STAMP(7); }
@@ -658,14 +608,12 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         for (int g = 0; g < 4; ++g)
           w[g] = epilogue_pack<T>(p, m, nb + 8 * g + 4 * hi, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
                                   acc[i][j][4 * g + 3], pre_r, rpre[i][j][g], pre_b, bpre[j][g]);
-        gns_stash(i, j, w);
         const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
         T* out = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 8 * hi;
         *reinterpret_cast<uint4*>(out) = ca;
         *reinterpret_cast<uint4*>(out + 16) = cb;
       }
     }
-    gns_finish();
     DH_STAMP(6);
 #ifdef DH_TUNING
     if (p.ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DH_STAMP(7); }
@@ -886,12 +834,8 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
     else hipLaunchKernelGGL(KERNEL, grid, dim3(TH), 0, st, k);                                              \
   } while (0)
 template <class T, int BM, int BN, int ST, int WG, int KG, int MW>
-static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k, bool gns = false) {
+static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k) {
   constexpr int TH = 256 * WG * KG * MW;
-  if constexpr (BM == 128 && BN == 64 && KG == 2 && WG == 1 && MW == 1) {
-    if (gns && gm == GM_DENSE && !lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, true>)); return; }
-    if (gns && gm == GM_CONV_S1) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_CONV_S1, 0, WG, KG, MW, false, true>)); return; }
-  }
   if (gm == GM_DENSE) {
     if constexpr (WG == 1) {
       if (lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true>)); return; }
@@ -1034,19 +978,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (kMw128 && BM == 128 && BN == 128 && tiles_per_split >= kMw128) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k);
   // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
   // x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge; 64x64 tiles: no K grouping wins in situ)
-  else if (BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) {
-    // the GroupNorm that follows takes its slice statistics from this epilogue (forward statistics; unsplit K; whole 128-row
-    // tiles inside one image; at most 64 slices = 32 row tiles per image; the wide-store epilogues)
-    bool gns = false;
-    if (splits == 1 && k.gn_part && !k.gnb_x && !lnf && gm != GM_GENERIC && k.gn_G > 0 && k.gn_HW > 0 && k.wide_store &&
-        k.M % 128 == 0 && k.gn_HW % 128 == 0 && k.N % 64 == 0 && k.N % k.gn_G == 0 && k.N / k.gn_G >= 8 && k.gn_HW / 128 <= 32 &&
-        k.M % k.gn_HW == 0) {
-      gns = true;
-      k.gn_S = 2 * (k.gn_HW / 128);
-    }
-    launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k, gns);
-    if (gns && gn_done) *gn_done = k.gn_S;
-  }
+  else if (BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k);
   else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 1>(gm, lnf, grid, st, k);
   else if (BM == 64) launch_tile<T, 64, 64, 4, 1, 1, 1>(gm, lnf, grid, st, k);      // (rings of 6 / 8 stages: +2 % on the pass)
   else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) launch_tile<T, 128, 128, 2, 1, 1, 1>(gm, lnf, grid, st, k);   // 64 KiB: two workgroups per CU
@@ -1059,7 +991,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
       k.gn_S = gn_slices(k.gn_HW, k.M / k.gn_HW);
       if (k.gnb_x) hipLaunchKernelGGL((k_splitk_reduce_gn<T, true>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
       else hipLaunchKernelGGL((k_splitk_reduce_gn<T, false>), dim3(k.gn_S, cdiv(k.gn_G, GN_GB), k.M / k.gn_HW), dim3(256), 0, st, k);
-      if (gn_done) *gn_done = k.gn_S;
+      if (gn_done) *gn_done = 1;
     } else if (k.lnb_x && lnb_done && !k.bias && !k.rowvec && !k.R && !k.act_silu && k.N % 8 == 0 && k.ldc == k.N) {
       // the rows are the dy of a LayerNorm: reduce + LayerNorm backward in one launch (dy itself is not written)
       launch_splitk_reduce_ln_bwd(dtype, k.partial, splits, k.lnb_x, k.lnb_gamma, k.lnb_stats, k.lnb_add, k.lnb_dx, k.M, k.N, st);

@@ -799,7 +799,7 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit,
         if (o.gn_next >= 0 && oi + 1 < n_ops && a.C % 8 == 0 && b2.C % 8 == 0 && t.C % G == 0 &&
             (GN_GB * (t.C / G)) % 8 == 0 && GN_GB * (t.C / G) <= 2048) {
           launch_concat_gn(dt, u->aptr(o.in0), a.C, u->aptr(o.in1), b2.C, u->aptr(o.out), u->small, B, t.rows, G, st);
-          gn_have = gn_slices(t.rows, B);
+          gn_have = 1;
         } else {
           launch_copy_cols(dt, u->aptr(o.in0), a.C, u->aptr(o.out), t.C, B * t.rows, a.C, 0, st);
           launch_copy_cols(dt, u->aptr(o.in1), b2.C, u->aptr(o.out) + a.C, t.C, B * t.rows, b2.C, 0, st);

@@ -29,8 +29,7 @@ struct GemmArgs {
   int act_silu = 0;
   float* partial = nullptr; size_t partial_elems = 0;   // split-K scratch (f32)
   // optional: the output feeds a GroupNorm next.  When the launch goes through the split-K reduce, that kernel
-  // also leaves the GroupNorm slice statistics (gn_partial layout) and *gn_done is set to the number of slices it wrote per
-  // (image, group) -- so does the unsplit 128 x 64 tile, from its epilogue (GNS, gemm.hip).
+  // also leaves the GroupNorm slice statistics (gn_partial layout) and *gn_done is set to 1.
   float* gn_part = nullptr; int gn_HW = 0, gn_G = 0; int* gn_done = nullptr;
   // gnb_x != NULL: the output is the gradient dy of a GroupNorm(+SiLU) whose INPUT is gnb_x; the reduce then leaves the
   // backward slice statistics (sum d, sum d*xhat with d = dy * gamma * act') in gn_part (k_gn_partial<bwd> layout)
@@ -72,7 +71,7 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
                            int accumulate, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 
 // GroupNorm (+SiLU): y = act(gn(x));  stats = [B*G][2] (mean, rstd) saved for backward.
-// have_partials != 0: the slice statistics in `scratch` were already left by the producer of x, in that many slices
+// have_partials != 0: the slice statistics in `scratch` were already left by the producer of x
 // (split-K reduce / concat), only the apply kernel runs.
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,

@@ -381,7 +381,7 @@ void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const fl
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                           int have_partials) {
   DH_ABLATE(2);
-  const int S = have_partials > 0 ? have_partials : gn_slices(HW, B);      // the producer's slice count when it left the statistics
+  const int S = gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);
@@ -490,7 +490,7 @@ void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float*
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st, int have_partials, GnBwdSplit split) {
   DH_ABLATE(2);
-  const int S = have_partials > 0 ? have_partials : gn_slices(HW, B);      // the producer's slice count when it left the statistics
+  const int S = gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);

@@ -75,8 +75,12 @@ __global__ void __launch_bounds__(64 * WAVES) k_ingest_reg(const unsigned char* 
 #pragma unroll
       for (int q = 0; q < PPW; ++q) *reinterpret_cast<uint4*>(st + q * 1024) = regs[d][q];
       if (t + DEPTH < tiles) fetch(t + DEPTH, regs[d]);
-      __syncthreads();
+      // raw barrier: __syncthreads() would carry a vmcnt(0) and drain the loads that are meant to stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       acc += ring[(t & 1) * 16384 + threadIdx.x * 4];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   }
   if (acc == 0xdeadbeefu) sink[0] = acc;
