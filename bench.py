@@ -9,6 +9,8 @@ synthetic scene, seeded random weights of the exact architecture, the per-image 
 (original activations, null-text list, initial noise) resident in HBM before the timed region.
 N > 1: one process per GPU, each an independent edit, no collective on the data path
 (weak scaling); torch.distributed is used only for the timing barriers and the MAX reductions.
+`python bench.py --gpus N` with no launcher in front starts the N ranks itself (launch_ranks: the parent never touches
+the GPU); under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are used as given.
 
 Next to the headline the same run reports (rank 0 unless stated; none of it inside the timed region):
   roofline        dominant kernel (k_gemm_dma) by HIP events on its stream, + committed PMC traffic
@@ -306,7 +308,7 @@ def main():
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, gfx950 x2 fetch
         # correction) of the same U-Net fwd+bwd launch mix; null when the workload differs from the measured one.
         traffic = None
-        for name in ("r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+        for name in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.res == 512 and args.dtype == "fp16":
                 with open(pmc) as fh:

@@ -21,18 +21,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // WAVES waves; a stage = 16 KiB = 16 pieces of 1 KiB; ring of ST stages; every wave issues 16 / WAVES pieces per stage
 template <int WAVES, int ST>
-__global__ void __launch_bounds__(64 * WAVES) k_ingest(const unsigned char* src, size_t per_wg, size_t wg_stride, size_t wrap, unsigned* sink) {
+__global__ void __launch_bounds__(64 * WAVES) k_ingest(const unsigned char* src, size_t per_wg, size_t wg_stride, size_t wrap, unsigned* sink) {      // wrap: a power of two
   __shared__ __attribute__((aligned(1024))) unsigned char ring[ST * 16384];
   constexpr int PPW = 16 / WAVES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)ring);
-  const size_t base = ((size_t)blockIdx.x * wg_stride) % wrap;
+  const size_t base = ((size_t)blockIdx.x * wg_stride) & (wrap - 1), msk = wrap - 1;
   const int tiles = (int)(per_wg / 16384);
   auto issue = [&](int t) {
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + (t % ST) * 16384 + wave * PPW * 1024);
 #pragma unroll
     for (int q = 0; q < PPW; ++q)
-      dma16(src + (base + (size_t)t * 16384 + (size_t)(wave * PPW + q) * 1024 + lane * 16) % wrap, sbase + q * 1024);
+      dma16(src + ((base + (size_t)t * 16384 + (size_t)(wave * PPW + q) * 1024 + lane * 16) & msk), sbase + q * 1024);
   };
 #pragma unroll
   for (int s = 0; s < ST - 1; ++s)
@@ -54,13 +54,13 @@ __global__ void __launch_bounds__(64 * WAVES) k_ingest_reg(const unsigned char* 
   __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * 16384];
   constexpr int PPW = 16 / WAVES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t base = ((size_t)blockIdx.x * wg_stride) % wrap;
+  const size_t base = ((size_t)blockIdx.x * wg_stride) & (wrap - 1), msk = wrap - 1;
   const int tiles = (int)(per_wg / 16384);
   uint4 regs[DEPTH][PPW];
   auto fetch = [&](int t, uint4 (&r)[PPW]) {
 #pragma unroll
     for (int q = 0; q < PPW; ++q)
-      r[q] = *reinterpret_cast<const uint4*>(src + (base + (size_t)t * 16384 + (size_t)(wave * PPW + q) * 1024 + lane * 16) % wrap);
+      r[q] = *reinterpret_cast<const uint4*>(src + ((base + (size_t)t * 16384 + (size_t)(wave * PPW + q) * 1024 + lane * 16) & msk));
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
