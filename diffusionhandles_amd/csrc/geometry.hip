@@ -59,13 +59,30 @@ __global__ void __launch_bounds__(CEN_CHUNK) k_centroid(const float* depth, cons
       const int base = (c - 1) * CEN_CHUNK;
       const int m = n - base < CEN_CHUNK ? n - base : CEN_CHUNK;
       const float* v = sv[(c - 1) & 1][t];
+      // the adds are one dependent chain (the order IS the result); what can overlap them is the LDS read of the NEXT
+      // batch: two register batches of 16, the loads of one issued before the adds of the other
       int k = 0;
-      for (; k + 8 <= m; k += 8) {
-        float u[8];
+      float u[16], w[16];
+      if (m >= 16) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = v[k + j];
+        for (int j = 0; j < 16; ++j) u[j] = v[j];
+      }
+      for (; k + 32 <= m; k += 32) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = acc + u[j];
+        for (int j = 0; j < 16; ++j) w[j] = v[k + 16 + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = acc + u[j];
+        if (k + 48 <= m) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) u[j] = v[k + 32 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = acc + w[j];
+      }
+      if (k + 16 <= m) {          // (u holds v[k .. k+16) here: loaded by the prologue or by the last loop pass)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = acc + u[j];
+        k += 16;
       }
       for (; k < m; ++k) acc = acc + v[k];
     }
@@ -221,8 +238,64 @@ __global__ void k_morph(const uint8_t* src, uint8_t* dst, int res, const int2* o
     if (yy < 0 || yy >= res || xx < 0 || xx >= res) continue;
     int v = s[yy * res + xx] ? 1 : 0;
     acc = dilate ? (acc | v) : (acc & v);
+    if (acc == dilate) break;          // decided: a set pixel found (dilate) / a clear one (erode); most waves lie in uniform regions
   }
   dst[(size_t)e * res * res + p] = (uint8_t)acc;
+}
+
+// The same morphology on BIT rows (res % 32 == 0): a thread owns one 32-pixel word of the output; a tap (dx, dy) is a funnel
+// shift of three source words of row y + dy, so the 76 taps of the 10 x 10 closing ellipse cost 76 shifts per 32 pixels instead
+// of 76 byte loads per pixel (57 us per pass at K = 8, 512 x 512: 75 GB/s of useful traffic).  Erosion = NOT dilate(NOT x) with
+// the same tap list: taps outside the image are ignored either way (clear rows / words of the complemented image).
+//   out = inv_out ^ dilate(inv_in ^ src)
+__global__ void k_pack_bits(const uint8_t* src, unsigned* dst, int n_words) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint4 a = *reinterpret_cast<const uint4*>(src + (size_t)w * 32), b = *reinterpret_cast<const uint4*>(src + (size_t)w * 32 + 16);
+  const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned bits = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bits |= ((v[i] >> (8 * j)) & 0xffu ? 1u : 0u) << (4 * i + j);
+  dst[w] = bits;
+}
+__global__ void k_unpack_bits(const unsigned* src, uint8_t* dst, int n_words) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const unsigned bits = src[w];
+  unsigned v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i] |= ((bits >> (4 * i + j)) & 1u) << (8 * j);
+  }
+  *reinterpret_cast<uint4*>(dst + (size_t)w * 32) = make_uint4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<uint4*>(dst + (size_t)w * 32 + 16) = make_uint4(v[4], v[5], v[6], v[7]);
+}
+__global__ void k_morph_bits(const unsigned* src, unsigned* dst, int res, const int2* offs, int n_off, int inv_in, int inv_out) {
+  const int wpr = res >> 5;                                  // words per row
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // word of this edit's image
+  if (idx >= wpr * res) return;
+  const unsigned* s = src + (size_t)blockIdx.y * wpr * res;
+  const int y = idx / wpr, wx = idx - y * wpr;
+  const unsigned flip = inv_in ? 0xffffffffu : 0u;
+  unsigned acc = 0;
+  for (int k = 0; k < n_off; ++k) {
+    const int yy = y + offs[k].y, dx = offs[k].x;            // out(x) |= in(x + dx)
+    if (yy < 0 || yy >= res) continue;
+    const unsigned* row = s + (size_t)yy * wpr;
+    const unsigned c = row[wx] ^ flip;
+    const unsigned l = wx > 0 ? row[wx - 1] ^ flip : 0u;     // pixels left of this word (outside the image: clear)
+    const unsigned r = wx + 1 < wpr ? row[wx + 1] ^ flip : 0u;
+    unsigned v;
+    if (dx == 0) v = c;
+    else if (dx > 0) v = dx >= 32 ? r : (c >> dx) | (r << (32 - dx));
+    else v = dx <= -32 ? l : (c << -dx) | (l >> (32 + dx));
+    acc |= v;
+  }
+  dst[(size_t)blockIdx.y * wpr * res + idx] = inv_out ? ~acc : acc;
 }
 
 __global__ void k_keep_flags(int n_fg, int R2, int P, const int* pix_arr, const uint8_t* vis, const uint8_t* clean,
@@ -286,7 +359,8 @@ __global__ void k_normalize(int R2, float* disp, const unsigned int* minmax, con
 // ones stay on chip in k_cg_fill_lds, which visits the unknowns in the same order: identical iterates.)
 __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const uint8_t* inpaint, const int* unk,
                                                   const int* counts, int count_stride, int slot_n, int slot_it,
-                                                  double* vx, double* vr, double* vp, double* vq, int max_iter,
+                                                  double* __restrict__ vx, double* __restrict__ vr, double* __restrict__ vp,
+                                                  double* __restrict__ vq, int max_iter,
                                                   double tol2, int* counts_out, const float* rhs_extra, int min_n,
                                                   int* pixmap, int2* nb_ud, size_t nb_ud_stride, int2* nb_lr,
                                                   size_t nb_lr_stride) {
@@ -297,13 +371,15 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
   float* d = disp + (size_t)e * R2;
   const uint8_t* mk = inpaint + (size_t)e * R2;
   const int* U = unk + (size_t)e * R2;
-  double* x = vx + (size_t)e * R2;
-  double* r = vr + (size_t)e * R2;
-  double* p = vp + (size_t)e * R2;
-  double* q = vq + (size_t)e * R2;
+  // (__restrict__: without it every store to q / x / r / p orders the loads of the next element behind it and an iteration
+  // is ~20 dependent L2 round trips per pass; with it the loads of an unrolled batch are issued together)
+  double* __restrict__ x = vx + (size_t)e * R2;
+  double* __restrict__ r = vr + (size_t)e * R2;
+  double* __restrict__ p = vp + (size_t)e * R2;
+  double* __restrict__ q = vq + (size_t)e * R2;
   int* map = pixmap + (size_t)e * R2;
-  int2* nud = nb_ud + (size_t)e * nb_ud_stride;
-  int2* nlr = nb_lr + (size_t)e * nb_lr_stride;
+  int2* __restrict__ nud = nb_ud + (size_t)e * nb_ud_stride;
+  int2* __restrict__ nlr = nb_lr + (size_t)e * nb_lr_stride;
   for (int i = threadIdx.x; i < n; i += blockDim.x) map[U[i]] = i;
   __syncthreads();
   double part = 0.0;
@@ -329,7 +405,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
     if (!(rs > tol2 * bnorm)) break;
     __syncthreads();
     part = 0.0;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const int2 ud = nud[i], lr = nlr[i];
       const double pi = p[i];
@@ -344,7 +420,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
     const double pq = block_sum(part, sm);
     const double alpha = rs / pq;
     part = 0.0;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       x[i] += alpha * p[i];
       double rr = r[i] - alpha * q[i];
@@ -353,13 +429,148 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
     }
     const double rsn = block_sum(part, sm);
     const double beta = rsn / rs;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = r[i] + beta * p[i];
     rs = rsn;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) d[U[i]] = (float)x[i];
   if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = it;
+}
+
+
+// The same CG for holes too large for one CU's LDS, on CGM_WGS workgroups per system.  One workgroup is bound by its CU's
+// memory pipe (15 eight-byte accesses per unknown and iteration through one L1: 37 us per iteration at 20 000 unknowns,
+// rocprofv3); here every workgroup owns a contiguous 1 / CGM_WGS of the unknowns and the iteration has TWO grid-wide seams (the two
+// dot products): search directions are double-buffered and rebuilt on the fly, p_new[j] = r[j] + beta p_old[j], also for the four
+// neighbours (r and p_old are final after the second seam), so no third seam orders a p update; A p of the own unknowns stays in
+// registers between the two passes.  A seam = agent-scope release, one arrival counter per system (monotonic: epoch * CGM_WGS),
+// relaxed polling by one lane, one agent-scope acquire, __syncthreads (cdna_hip_programming.md Guideline 16); the dot products
+// are per-workgroup partials written before the seam and added by everyone in workgroup order afterwards: identical in every
+// workgroup (the convergence test must agree: it decides whether the next seam is entered) and deterministic.
+constexpr int CGM_WGS = 16, CGM_EPT = 4;       // unknowns per thread <= 4: n <= 16 * 4 * 1024 (8 registers of A p; 8 x 8 spilled)
+struct CgSync { unsigned arrive; unsigned pad[31]; double red[2][CGM_WGS]; };
+typedef __attribute__((address_space(1))) unsigned cg_gu32;
+// FENCED: the payload went through plain stores (release: L2 write-back) and is read with plain loads (acquire: stale lines
+// dropped).  Otherwise everything shared was stored write-through and is loaded past the caches (agent-scope relaxed atomics on
+// 8-byte words, the guide's R1 form): every storing wave drains its stores, one lane counts the arrival -- no fences.
+typedef __attribute__((address_space(1))) unsigned long long cg_gu64;
+__device__ __forceinline__ void cg_put(double* p, double v) {
+  __hip_atomic_store((cg_gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double cg_get(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((cg_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool FENCED>
+__device__ __forceinline__ void cg_seam(CgSync* s, unsigned epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (FENCED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    cg_gu32* ctr = (cg_gu32*)&s->arrive;
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * CGM_WGS) __builtin_amdgcn_s_sleep(1);
+    if (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, const uint8_t* inpaint, const int* unk,
+                                                        const int* counts, int count_stride, int slot_n, int slot_it, double* vx,
+                                                        double* vr, double* vp0, double* vp1, int max_iter, double tol2,
+                                                        int* counts_out, const float* rhs_extra, int min_n, int* pixmap,
+                                                        int2* nb_ud, size_t nb_ud_stride, int2* nb_lr, size_t nb_lr_stride,
+                                                        CgSync* sync) {
+  __shared__ double sm[16];
+  const int e = blockIdx.y, wg = blockIdx.x, R2 = res * res;
+  const int n = counts[e * count_stride + slot_n];
+  if (n <= min_n || n > CGM_WGS * CGM_EPT * 1024) return;          // (uniform over the system's workgroups)
+  CgSync* sy = sync + e;
+  float* d = disp + (size_t)e * R2;
+  const uint8_t* mk = inpaint + (size_t)e * R2;
+  const int* U = unk + (size_t)e * R2;
+  double* x = vx + (size_t)e * R2;
+  double* r = vr + (size_t)e * R2;
+  double* P[2] = {vp0 + (size_t)e * R2, vp1 + (size_t)e * R2};
+  int* map = pixmap + (size_t)e * R2;
+  int2* nud = nb_ud + (size_t)e * nb_ud_stride;
+  int2* nlr = nb_lr + (size_t)e * nb_lr_stride;
+  const int per = (n + CGM_WGS - 1) / CGM_WGS, i0 = wg * per, i1 = i0 + per < n ? i0 + per : n;
+  unsigned epoch = 0;
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) map[U[i]] = i;
+  cg_seam<true>(sy, ++epoch);                                        // every workgroup's part of the pixel -> unknown map (plain stores / loads)
+  double part = 0.0;
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) {
+    const int pix = U[i], y = pix / res, xx = pix - y * res;
+    double b = 0.0;
+    int2 ud = make_int2(-1, -1), lr = make_int2(-1, -1);
+    if (y > 0) { if (!mk[pix - res]) b += (double)d[pix - res]; else ud.x = map[pix - res]; }
+    if (y < res - 1) { if (!mk[pix + res]) b += (double)d[pix + res]; else ud.y = map[pix + res]; }
+    if (xx > 0) { if (!mk[pix - 1]) b += (double)d[pix - 1]; else lr.x = map[pix - 1]; }
+    if (xx < res - 1) { if (!mk[pix + 1]) b += (double)d[pix + 1]; else lr.y = map[pix + 1]; }
+    if (rhs_extra) b -= (double)rhs_extra[(size_t)e * R2 + pix];
+    nud[i] = ud; nlr[i] = lr;                  // (read back by this thread only)
+    x[i] = 0.0;
+    cg_put(r + i, b); cg_put(P[0] + i, b);
+    part += b * b;
+  }
+  auto all_sum = [&](double v, int slot) -> double {                  // partial of this workgroup -> seam -> sum in workgroup order
+    v = block_sum(v, sm);
+    if (threadIdx.x == 0) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)&sy->red[slot][wg],
+                                              (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cg_seam<false>(sy, ++epoch);
+    double t = 0.0;
+    for (int k = 0; k < CGM_WGS; ++k)
+      t += __longlong_as_double((long long)__hip_atomic_load((__attribute__((address_space(1))) unsigned long long*)&sy->red[slot][k],
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return t;
+  };
+  double rs = all_sum(part, 0);
+  const double bnorm = rs;
+  double beta = 0.0;
+  int cur = 0, it = 0;
+  for (; it < max_iter; ++it) {
+    if (!(rs > tol2 * bnorm)) break;
+    const double* po = P[cur];
+    double* pn = P[cur ^ 1];
+    double ap[CGM_EPT];
+    part = 0.0;
+#pragma unroll
+    for (int k = 0; k < CGM_EPT; ++k) {
+      const int i = i0 + (int)threadIdx.x + k * 1024;
+      ap[k] = 0.0;
+      if (i < i1) {
+        const int2 ud = nud[i], lr = nlr[i];
+        const double pi = cg_get(r + i) + beta * cg_get(po + i);
+        double a = 4.0 * pi;
+        if (ud.x >= 0) a -= cg_get(r + ud.x) + beta * cg_get(po + ud.x);
+        if (ud.y >= 0) a -= cg_get(r + ud.y) + beta * cg_get(po + ud.y);
+        if (lr.x >= 0) a -= cg_get(r + lr.x) + beta * cg_get(po + lr.x);
+        if (lr.y >= 0) a -= cg_get(r + lr.y) + beta * cg_get(po + lr.y);
+        cg_put(pn + i, pi);
+        ap[k] = a;
+        part += pi * a;
+      }
+    }
+    const double pq = all_sum(part, 1);          // (slots alternate: a workgroup still adding slot 0 cannot be overtaken by the next write to it)
+    const double alpha = rs / pq;
+    part = 0.0;
+#pragma unroll
+    for (int k = 0; k < CGM_EPT; ++k) {
+      const int i = i0 + (int)threadIdx.x + k * 1024;
+      if (i < i1) {
+        x[i] += alpha * cg_get(pn + i);        // (this thread's own store of the first pass)
+        const double rr = cg_get(r + i) - alpha * ap[k];
+        cg_put(r + i, rr);
+        part += rr * rr;
+      }
+    }
+    const double rsn = all_sum(part, 0);
+    beta = rsn / rs;
+    rs = rsn;
+    cur ^= 1;
+  }
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) d[U[i]] = (float)x[i];
+  if (threadIdx.x == 0 && wg == 0) counts_out[e * count_stride + slot_it] = it;
 }
 
 // The same iteration with the vectors on chip: thread t owns unknowns t, t + 1024, ... (the order the kernel above
@@ -536,6 +747,7 @@ struct ReprojectWs {
   int2* offs_close;
   int2* offs_open;
   double *vx, *vr, *vp, *vq;
+  CgSync* cgsync;
 };
 
 static bool carve(Arena& a, int res, int n_fg, int K, ReprojectWs& w) {
@@ -560,6 +772,7 @@ static bool carve(Arena& a, int res, int n_fg, int K, ReprojectWs& w) {
   w.vr = a.take<double>(K * R2);
   w.vp = a.take<double>(K * R2);
   w.vq = a.take<double>(K * R2);
+  w.cgsync = a.take<CgSync>(K);
   return a.ok();
 }
 
@@ -644,10 +857,22 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
   hipLaunchKernelGGL(k_fg_vis, dim3(cdiv(n_fg, 256), K), dim3(256), 0, st, n_fg, R2, P, res, w.pix, w.owner, vis,
                      target_xy);
   // CLOSE = dilate, erode ; OPEN = erode, dilate
-  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, raw_mask, w.tmp_a, res, w.offs_close, nc, 1);
-  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_a, w.tmp_b, res, w.offs_close, nc, 0);
-  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_b, w.tmp_a, res, w.offs_open, no, 0);
-  hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_a, clean_mask, res, w.offs_open, no, 1);
+  if (res % 32 == 0 && kc < 32 && ko < 32) {        // bit rows: pack, four passes (erode = NOT dilate NOT), unpack
+    const int nw = K * R2 / 32, wpe = R2 / 32;
+    unsigned* ba = reinterpret_cast<unsigned*>(w.tmp_a);
+    unsigned* bb = reinterpret_cast<unsigned*>(w.tmp_b);
+    hipLaunchKernelGGL(k_pack_bits, dim3(cdiv(nw, 256)), dim3(256), 0, st, raw_mask, ba, nw);
+    hipLaunchKernelGGL(k_morph_bits, dim3(cdiv(wpe, 256), K), dim3(256), 0, st, ba, bb, res, w.offs_close, nc, 0, 0);
+    hipLaunchKernelGGL(k_morph_bits, dim3(cdiv(wpe, 256), K), dim3(256), 0, st, bb, ba, res, w.offs_close, nc, 1, 1);
+    hipLaunchKernelGGL(k_morph_bits, dim3(cdiv(wpe, 256), K), dim3(256), 0, st, ba, bb, res, w.offs_open, no, 1, 1);
+    hipLaunchKernelGGL(k_morph_bits, dim3(cdiv(wpe, 256), K), dim3(256), 0, st, bb, ba, res, w.offs_open, no, 0, 0);
+    hipLaunchKernelGGL(k_unpack_bits, dim3(cdiv(nw, 256)), dim3(256), 0, st, ba, clean_mask, nw);
+  } else {
+    hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, raw_mask, w.tmp_a, res, w.offs_close, nc, 1);
+    hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_a, w.tmp_b, res, w.offs_close, nc, 0);
+    hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_b, w.tmp_a, res, w.offs_open, no, 0);
+    hipLaunchKernelGGL(k_morph, dim3(cdiv(R2, 256), K), dim3(256), 0, st, w.tmp_a, clean_mask, res, w.offs_open, no, 1);
+  }
   hipLaunchKernelGGL(k_keep_flags, dim3(cdiv(n_fg, 256), K), dim3(256), 0, st, n_fg, R2, P, w.pix, vis, clean_mask,
                      w.keep);
   compact(w.keep, n_fg, K, n_fg, w.keep_idx, n_fg, counts + 0, 4, w.block_counts, st);
@@ -666,8 +891,14 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
     hipLaunchKernelGGL(k_cg_fill_lds, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3,
                        w.owner, 20000, 1e-24, counts, (const float*)nullptr, w.vx, w.vr, w.vp, w.vq);
   // scratch of the solve: the z-buffer, owner map and key list are dead by now (last read by k_pixels / k_write_corr)
-  hipLaunchKernelGGL(k_cg_fill, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3, w.vx,
+  // holes beyond one CU's LDS: CGM_WGS workgroups per edit (every polled word zeroed per call); beyond that kernel's
+  // register budget (65 536 unknowns) the single-workgroup kernel
+  DH_CHECK_HIP(hipMemsetAsync(w.cgsync, 0, (size_t)K * sizeof(CgSync), st));
+  hipLaunchKernelGGL(k_cg_fill_multi, dim3(CGM_WGS, K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3, w.vx,
                      w.vr, w.vp, w.vq, 20000, 1e-24, counts, (const float*)nullptr, cg_lds ? CG_SLOTS * 1024 : 0, w.owner,
+                     reinterpret_cast<int2*>(w.zbuf), (size_t)R2, reinterpret_cast<int2*>(w.key), (size_t)P, w.cgsync);
+  hipLaunchKernelGGL(k_cg_fill, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3, w.vx,
+                     w.vr, w.vp, w.vq, 20000, 1e-24, counts, (const float*)nullptr, CGM_WGS * CGM_EPT * 1024, w.owner,
                      reinterpret_cast<int2*>(w.zbuf), (size_t)R2, reinterpret_cast<int2*>(w.key), (size_t)P);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -677,7 +908,7 @@ extern "C" int dh_laplacian_blend_workspace_bytes(int res, size_t* bytes) {
   DH_REQUIRE(res >= 2 && bytes, "bad arguments");
   const size_t R2 = (size_t)res * res;
   *bytes = 4 * align_up(R2 * 8, 256) + 3 * align_up(R2, 256) + 3 * align_up(R2 * 4, 256) + 2 * align_up(R2 * 8, 256) +
-           (size_t)(cdiv((int)R2, CP_TILE) + 2) * 4 + 4096;
+           (size_t)(cdiv((int)R2, CP_TILE) + 2) * 4 + 4096 + align_up(sizeof(CgSync), 256);
   return DH_OK;
 }
 
@@ -702,6 +933,7 @@ extern "C" int dh_laplacian_blend(const float* depth, const float* bg_depth, con
   int2* nb_ud = a.take<int2>(R2);
   int2* nb_lr = a.take<int2>(R2);
   int* bc = a.take<int>(cdiv(R2, CP_TILE) + 2);
+  CgSync* cgs = a.take<CgSync>(1);
   DH_CHECK_HIP(hipMemcpyAsync(m0, fg_mask, R2, hipMemcpyDeviceToDevice, st));
   uint8_t *src = m0, *dst = m1;
   for (int i = 0; i < dilate_iters; ++i) {
@@ -714,8 +946,11 @@ extern "C" int dh_laplacian_blend(const float* depth, const float* bg_depth, con
   compact(src, R2, 1, 0, unk, 0, counts + 2, 1, bc, st);
   hipLaunchKernelGGL(k_cg_fill_lds, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, pixmap, 50000, 1e-24,
                      counts, (const float*)lap, vx, vr, vp, vq);
+  DH_CHECK_HIP(hipMemsetAsync(cgs, 0, sizeof(CgSync), st));
+  hipLaunchKernelGGL(k_cg_fill_multi, dim3(CGM_WGS, 1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, vx, vr, vp, vq,
+                     50000, 1e-24, counts, (const float*)lap, CG_SLOTS * 1024, pixmap, nb_ud, (size_t)R2, nb_lr, (size_t)R2, cgs);
   hipLaunchKernelGGL(k_cg_fill, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, vx, vr, vp, vq, 50000,
-                     1e-24, counts, (const float*)lap, CG_SLOTS * 1024, pixmap, nb_ud, (size_t)R2, nb_lr, (size_t)R2);
+                     1e-24, counts, (const float*)lap, CGM_WGS * CGM_EPT * 1024, pixmap, nb_ud, (size_t)R2, nb_lr, (size_t)R2);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
