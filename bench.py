@@ -250,7 +250,8 @@ def main():
         phases = {"inversion_s": round(time.perf_counter() - t0, 3),
                   "inversion_inner_steps": int(sum(dh.inverter.inner_steps_taken)),
                   "inversion_what": "StableNullInverter.invert: VAE encode, 50 DDIM-inversion forwards, 50 timesteps x (cond forward + "
-                                    "<= 5 x (forward + backward-to-text + Adam) + CFG forward B=2)"}
+                                    "<= 5 x (forward + backward-to-text + Adam) + unconditional forward B=1 for the CFG step, "
+                                    "which reuses the cond forward)"}
         del null_text, inv_noise
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -483,7 +483,8 @@ def test_scene_harness_end_to_end_on_the_reference_scene(tmp_path):
 def test_scene_harness_identity_cache_round_trip_and_skip_existing(tmp_path):
     """The harness's input-image identity cache (the reference's --cache_input_image_identity npz, which is also its web
     services' wire format: keys null_text_emb, init_noise, activations1..3, latent_image; test_diffusion_handles.py:85-113,
-    webapp/webapps/diffhandles_webapp.py:82-94) and --skip_existing (:133-135, 216-225): a first run writes the cache, a second
+    webapp/webapps/diffhandles_webapp.py:82-94) and --skip_existing (:133-135, 216-225): a first run inverts the scene's input
+    image (50 DDIM + 50 null-text timesteps at the full size), reconstructs it and writes the cache, a second
     run in another directory READS it (no inversion, no initial inference) and reproduces the edit bit for bit, a third run
     with --skip-existing finds every output in place and does nothing."""
     import json
@@ -501,7 +502,7 @@ def test_scene_harness_identity_cache_round_trip_and_skip_existing(tmp_path):
                            timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads(r.stdout.strip().splitlines()[-1])
-    rep1 = run("--out", out1, "--skip-inversion")
+    rep1 = run("--out", out1)             # the whole per-image phase: null-text inversion of input.png + initial inference
     assert rep1["identity_from_cache"] is False and os.path.exists(os.path.join(out1, "identity.npz"))
     with np.load(os.path.join(out1, "identity.npz")) as z:
         assert sorted(z.files) == ["activations1", "activations2", "activations3", "init_noise", "latent_image", "null_text_emb"]
