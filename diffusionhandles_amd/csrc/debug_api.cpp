@@ -31,6 +31,28 @@ extern "C" int dh_dbg_gemm(int dtype, const void* A, long lda, const void* W, in
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+// the LayerNorm-folded form of the dense GEMM (engine: qkv / cross-attention q / GEGLU in-projection at B <= 3): A is the
+// LayerNorm INPUT, W already carries gamma, ln_s[n] = sum_k W[n][k], ln_t[n] = sum_k beta[k] W0[n][k] (+ bias);
+// out = rstd (A W^T - mean ln_s) + ln_t, and (mean, rstd) per row land in ln_stats
+extern "C" int dh_dbg_gemm_lnfold(int dtype, const void* A, long lda, const void* W, int M, int N, int K, const float* ln_s,
+                                  const float* ln_t, float* ln_stats, float ln_eps, void* C, long ldc, void* stream) {
+  DH_REQUIRE(A && W && C && ln_s && ln_t && ln_stats && K % 64 == 0 && N % 64 == 0, "bad arguments (N, K must be multiples of 64)");
+  static void* tiled = nullptr;
+  static size_t tiled_cap = 0;
+  const size_t need = (size_t)N * K * 2;
+  if (need > tiled_cap) {
+    if (tiled) (void)hipFree(tiled);
+    DH_CHECK_HIP(hipMalloc(&tiled, need));
+    tiled_cap = need;
+  }
+  launch_tile_weights(dtype, W, tiled, N, K, (hipStream_t)stream);
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = tiled; g.M = M; g.N = N; g.K = K; g.mode = A_DENSE; g.C = C; g.ldc = ldc;
+  g.ln_s = ln_s; g.ln_t = ln_t; g.ln_stats = ln_stats; g.ln_eps = ln_eps;
+  launch_gemm(dtype, g, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
 extern "C" int dh_dbg_groupnorm(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 const void* dy, void* dx, float* scratch, int B, int HW, int C, int G, float eps,
                                 int silu, int accumulate, void* stream) {

@@ -68,6 +68,43 @@ def test_gemm_dense(dtype, M, N, K):
         close(C, F.silu(z), tol, tol, "gemm silu/rowvec")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4096, 960, 320), (1024, 640, 640), (256, 2560, 1280)])
+@pytest.mark.parametrize("mean_over_std", [0.0, 3.0, 30.0])
+def test_gemm_layernorm_fold(dtype, M, N, K, mean_over_std):
+    """The LayerNorm folded into its consuming GEMM (A = the LayerNorm input, W * gamma, out = rstd (A W'^T - mean s) + t; the
+    row sums come out of the K loop as f32 sums of the 16-bit inputs, variance = E[x^2] - mean^2) against LayerNorm followed by
+    the GEMM in fp32, for rows whose mean is 0, 3 and 30 standard deviations away from zero: the one-pass variance could lose
+    accuracy as |mean| / std grows (advisor, round 2).  Measured: it does not matter at 16-bit inputs -- rel-L2 2.6e-4 (fp16) /
+    2.0e-3 (bf16) even at 30 standard deviations, the saved (mean, rstd) within 1e-3 / 2e-2 relative."""
+    g = torch.Generator(device=dev()).manual_seed(M + N + K + int(mean_over_std))
+    x = (torch.randn(M, K, generator=g, device=dev()) + mean_over_std * torch.randn(M, 1, generator=g, device=dev()).sign()).to(dtype)
+    gamma = 1.0 + 0.1 * torch.randn(K, generator=g, device=dev())
+    beta = 0.1 * torch.randn(K, generator=g, device=dev())
+    W0 = (torch.randn(N, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+    bias = torch.randn(N, generator=g, device=dev())
+    Wf = (W0.float() * gamma).to(dtype)                                  # what k_fold_ln stores
+    s = Wf.float().sum(dim=1).contiguous()
+    t = (W0.float() @ beta + bias).contiguous()
+    ref = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W0.float().t() + bias
+    C = torch.empty(M, N, dtype=dtype, device=dev())
+    stats = torch.empty(M, 2, dtype=torch.float32, device=dev())
+    lib = L().lib()
+    L().check(lib.dh_dbg_gemm_lnfold(DT[dtype], P(x), K, P(Wf.contiguous()), M, N, K, P(s), P(t), P(stats), 1e-5, P(C), N,
+                                     L().stream_ptr()), "dh_dbg_gemm_lnfold")
+    mean, var = x.float().mean(dim=1), x.float().var(dim=1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    assert torch.allclose(stats[:, 0], mean, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(stats[:, 1], rstd, rtol=2e-2 if mean_over_std > 10 else 2e-3, atol=0)
+    if mean_over_std <= 3.0:
+        tol = 6e-3 if dtype == torch.float16 else 3e-2
+        close(C, ref, tol, tol, f"LN-folded gemm {M}x{N}x{K} mean/std {mean_over_std}")
+    else:       # mean * s is ~30x the result it is subtracted from: measured 2.6e-4 (fp16) / 2.0e-3 (bf16)
+        err = ((C.float() - ref).norm() / ref.norm()).item()
+        print(f"LN-folded gemm {dtype} {M}x{N}x{K} at |mean| = {mean_over_std} std: rel L2 {err:.3e}")
+        assert err < (2e-3 if dtype == torch.float16 else 1e-2)
+
+
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
