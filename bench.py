@@ -68,7 +68,7 @@ def rank_environments(n, port, base=None):
     return envs
 
 
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, script=None):
     """`python bench.py --gpus N` without a launcher in front (RANK unset): start N copies of this script, one rank per GPU
     (the reference's own multi-GPU shape is one process per device too, webapp/start_webapps_in_tmux.sh:21-43).  The parent
     never touches the GPU - no torch.cuda call, no library load - and nothing is exec'd: children are ordinary
@@ -78,7 +78,7 @@ def launch_ranks(args, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, os.path.abspath(__file__)] + argv
+    cmd = [sys.executable, os.path.abspath(script or __file__)] + argv
     envs = rank_environments(args.gpus, port)
     if args.dry_run_launch:
         keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")

@@ -164,3 +164,16 @@ def test_bench_launcher_children_see_their_rank(tmp_path):
     seen = sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("r"))
     assert seen == ["r0", "r1", "r2"]
     assert len({(tmp_path / n).read_text() for n in seen}) == 1
+
+
+def test_sharded_edit_driver_launch_plan():
+    """tools/run_edits_sharded.py --gpus N (BASELINE config 4's driver) starts its own ranks through the same launcher."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_edits_sharded.py"), "--gpus", "8", "--edits", "64",
+                          "--dry-run-launch"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    plan = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert [p["env"]["RANK"] for p in plan] == [str(r) for r in range(8)]
+    assert all(p["env"]["WORLD_SIZE"] == "8" and p["cmd"][1].endswith("run_edits_sharded.py") and "--edits" in p["cmd"] for p in plan)

@@ -5,6 +5,7 @@ no collective on the per-edit path.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
       tools/run_edits_sharded.py --edits 64 --out /tmp/edits
   python tools/run_edits_sharded.py --edits 8 --out /tmp/edits          # one GPU
+  python tools/run_edits_sharded.py --gpus 8 --edits 64 --out /tmp/edits # starts its own 8 ranks (bench.launch_ranks)
 
 One process per GPU.  Rank 0 computes the per-image identity once (initial inference; --invert adds the null-text
 inversion of the input image) and hands it to the other ranks with one broadcast per tensor (parallel.broadcast_identity;
@@ -50,7 +51,18 @@ def main():
     ap.add_argument("--invert", action="store_true", help="null-text inversion of the input image for the identity")
     ap.add_argument("--recompute-identity", action="store_true", help="every rank computes the identity (no broadcast)")
     ap.add_argument("--no-images", action="store_true", help="do not write PNGs (timing runs)")
+    ap.add_argument("--gpus", type=int, default=1, help="without a launcher in front (RANK unset): start this many ranks")
+    ap.add_argument("--dry-run-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
+        # one process per GPU, started before anything here touches the GPU (the same launcher as bench.py)
+        import importlib.util
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("dh_bench", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        argv = [a for a in sys.argv[1:] if a != "--dry-run-launch"]
+        raise SystemExit(bench.launch_ranks(args, argv, script=__file__))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
