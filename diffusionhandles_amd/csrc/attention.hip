@@ -719,11 +719,16 @@ void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o,
 void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* o,
                              long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq, long lddq,
                              int B, int H, int Nq, int Nk, hipStream_t st) {
-  const int ks = attn_key_split((Nk + 63) / 64, 2);
   const int qw = attn_row_waves(Nq, H * B, Nk);
+  // four key groups like the forward (12 waves per CU instead of 6 at N = 4096: the loop is VALU-bound and one to two waves
+  // per SIMD leave the pipe idle across every LDS wait; guided step +0.45 %, profiles/r03_ab_dq_ks4.txt); the 16-wave block
+  // of the 128-row tile would spill, it keeps two
+  int ks = attn_key_split((Nk + 63) / 64, 4);
+  if (ks == 4 && qw == 4) ks = 2;
 #define DH_ATTN_DQ(T_)                                                                                                          \
   do {                                                                                                                           \
-    if (ks == 2) DH_ATTN_QW(attn_dq_launch, T_, 2, B, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk); \
+    if (ks == 4) DH_ATTN_QW(attn_dq_launch, T_, 4, B, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk); \
+    else if (ks == 2) DH_ATTN_QW(attn_dq_launch, T_, 2, B, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk); \
     else DH_ATTN_QW(attn_dq_launch, T_, 1, B, st, q, ldq, k, v, ldk, o, ldo, d_o, lddo, lse, delta, dq, lddq, H, Nq, Nk);          \
   } while (0)
   if (dtype == DH_DTYPE_F16) DH_ATTN_DQ(f16);
