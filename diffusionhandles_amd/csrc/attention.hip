@@ -459,6 +459,8 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
 
 // ------------------------------------------------------------------------- backward dK, dV
 // 128 keys x KS query ranges per block; the groups' dK / dV partial sums are merged through LDS.
+// (capping this kernel at 168 VGPRs -- three waves per SIMD -- spills 216 bytes per lane into the loop: guided step -5 %,
+// profiles/r03_ab_dkv_occ.txt; a four-group variant needs the register diet first)
 template <class T, int KS, int QW>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
                                                            long lddo, const float* lse, const float* delta, T* dk, T* dv,
