@@ -93,6 +93,7 @@ struct dh_unet {
   // well-known tensors
   int t_text = -1, t_kv = -1, t_conv_in_out = -1, t_final = -1, act_ids[3] = {-1, -1, -1};
   int act_op_end[3] = {0, 0, 0};   // ops [0, act_op_end[i]) produce captured activation i
+  int first_cross_op = 0;           // tape index of the first cross-attention: a backward pass that only wants the text gradient stops there
   int saved_ops = 0;                // number of tape ops the saved forward executed
   // the time-embedding chain (sinusoid -> MLP -> all resnet projections) depends on the timestep only: the 7 passes of
   // a guided step share it.  temb_rows images hold the projections of timestep temb_t (0 rows = nothing cached).
@@ -440,6 +441,9 @@ int build(dh_unet& u) {
     set_error("internal: fused projection sizes do not match");
     return DH_ERR_STATE;
   }
+  u.first_cross_op = 0;
+  for (size_t i = 0; i < u.ops.size(); ++i)
+    if (u.ops[i].type == OP_ATTN && u.ops[i].cross) { u.first_cross_op = (int)i; break; }
   // a GroupNorm directly after the producer of its input takes its slice statistics from that producer
   // (split-K reduce epilogue / concat copy) instead of a statistics pass of its own
   for (size_t i = 0; i + 1 < u.ops.size(); ++i) {
@@ -925,6 +929,9 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
   int cat_done = -1;                    // the GroupNorm backward just run wrote the gradient of concatenation op cat_done to its sources
   for (int oi = (int)u->ops.size() - 1; oi >= 0; --oi) {
     const Op& o = u->ops[oi];
+    // only the text gradient is wanted (null-text optimisation): nothing below the first cross-attention contributes to it
+    // (its self-attention, proj_in, the first resnet, conv_in) -- except the hoisted K|V projection of the text itself
+    if (!want_sample && oi < u->first_cross_op && o.out != u->t_kv) continue;
     switch (o.type) {
       case OP_CONV_OUT: {
         if (!d_eps) break;
