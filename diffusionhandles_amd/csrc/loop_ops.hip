@@ -31,8 +31,8 @@ __global__ void k_pack_sample(float* dst, const float* lat, int lb, int cl, cons
   if (i >= n) return;
   const int ct = cl + cd;
   const int ch = i % ct, r = i / ct, p = r % pixels, b = r / pixels;
-  dst[i] = ch < cl ? lat[((size_t)(lb > 1 ? b : 0) * pixels + p) * cl + ch]
-                   : dep[((size_t)(db > 1 ? b : 0) * pixels + p) * cd + (ch - cl)];
+  dst[i] = ch < cl ? lat[((size_t)(b % lb) * pixels + p) * cl + ch]
+                   : dep[((size_t)(b % db) * pixels + p) * cd + (ch - cl)];
 }
 
 __global__ void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
@@ -187,7 +187,8 @@ extern "C" int dh_latent_update_strided(float* x_out, const float* x, const floa
 extern "C" int dh_pack_sample(float* dst, const float* latent, int latent_batch, int latent_channels, const float* depth,
                               int depth_batch, int depth_channels, int batch, int pixels, void* stream) {
   DH_REQUIRE(dst && latent && batch >= 1 && pixels > 0 && latent_channels > 0, "bad arguments");
-  DH_REQUIRE((latent_batch == 1 || latent_batch == batch) && (!depth || depth_batch == 1 || depth_batch == batch), "batch sizes must be 1 or batch");
+  DH_REQUIRE(latent_batch >= 1 && batch % latent_batch == 0 && (!depth || (depth_batch >= 1 && batch % depth_batch == 0)),
+             "latent / depth batches must divide the batch (item b reads item b mod its batch)");
   const int cd = depth ? depth_channels : 0;
   DH_REQUIRE(!depth || cd > 0, "depth without channels");
   const int n = batch * pixels * (latent_channels + cd);

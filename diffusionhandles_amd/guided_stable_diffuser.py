@@ -387,36 +387,36 @@ class GuidedStableDiffuser(GuidedDiffuser):
         """x: [K,H,W,4]; sts: K guidance states (same prompt / original activations, different edits)."""
         L = _lib.lib()
         K = x.shape[0]
-        depth = torch.cat([st.depth_nhwc for st in sts], dim=0)
+        depth = torch.cat([st.depth_nhwc for st in sts], dim=0) if self.conf.use_depth else None
         cond = sts[0].cond.expand(K, -1, -1).contiguous()
         iteration = 0
         while iteration < self.conf.num_optsteps and t_idx < self.conf.guidance_max_step:
             fgw, bgw = sts[0].schedule(t_idx, iteration)
             active = [k for k in range(3) if fgw[k] != 0.0 or bgw[k] != 0.0]
             if active:
-                sample = torch.cat([x, depth], dim=-1).contiguous() if self.conf.use_depth else x
-                _, acts = self.unet.forward(sample, float(t), cond, save_for_backward=True, want_acts=active,
-                                            want_eps=False, text_key=sts[0].cond_key)
+                # the same in-place engine I/O as guided_step: one pack launch for the K inputs, every edit's energy gradient
+                # written straight into its slice of the engine's cotangent buffer, d(sample) read in place
+                sample = self.unet.stage_sample(x, depth, K)
+                _, acts = self.unet.forward(sample, float(t), cond, save_for_backward=True, want_acts=active, want_eps=False,
+                                            text_key=sts[0].cond_key, inplace=True)
                 d_acts = [None, None, None]
                 for k in active:
-                    g_all = torch.empty_like(acts[k])
+                    d_acts[k] = self.unet.io_view("act_grad", k)[:K]
                     for e, st in enumerate(sts):
                         fw = fgw[k] if st.n_pairs > 0 else 0.0
-                        g_all[e].copy_(self._energy_grad(st, k, acts[k][e], t_idx, fw, bgw[k]))
-                    d_acts[k] = g_all
-                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False)
-                g_lat = d_sample[..., : x.shape[-1]].contiguous()
+                        self._energy_grad(st, k, acts[k][e], t_idx, fw, bgw[k], out=d_acts[k][e])
+                d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False, inplace=True)
                 x_new = torch.empty_like(x)
-                _lib.check(L.dh_latent_update(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(g_lat), 0.1, self.grad_scale,
-                                              x.numel(), _lib.stream_ptr()), "dh_latent_update")
+                _lib.check(L.dh_latent_update_strided(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(d_sample), d_sample.shape[-1],
+                                                      x.shape[-1], 0.1, self.grad_scale, x.numel() // x.shape[-1],
+                                                      _lib.stream_ptr()), "dh_latent_update_strided")
                 x = x_new
             iteration += 1
-        sample = torch.cat([x, depth], dim=-1) if self.conf.use_depth else x
-        sample2 = torch.cat([sample, sample], dim=0).contiguous()
+        sample2 = self.unet.stage_sample(x, depth, 2 * K)          # the K edits twice: unconditional and conditional halves
         unc = uncond.reshape(1, *cond.shape[1:]).to(self.device, torch.float32).expand(K, -1, -1)
         text2 = torch.cat([unc, cond], dim=0).contiguous()
-        eps, _ = self.unet.forward(sample2, float(t), text2, save_for_backward=False, want_acts=False)
-        return self.ddim_step(x, eps[:K].contiguous(), eps[K:].contiguous(), t)
+        eps, _ = self.unet.forward(sample2, float(t), text2, save_for_backward=False, want_acts=False, inplace=True)
+        return self.ddim_step(x, eps[:K], eps[K:], t)
 
     def guided_inference_batch(self, latents, depths, uncond_embeddings, prompt, activations_orig, correspondences_list,
                                fg_weight=None, bg_weight=None):

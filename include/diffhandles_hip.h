@@ -252,7 +252,8 @@ int dh_latent_update_strided(float* x_out, const float* x, const float* g, int g
                              float grad_scale, int pixels, void* stream);
 /* dst[b][p][:] = concat(latent[b or 0][p][0:latent_channels], depth[b or 0][p][0:depth_channels]) for b < batch: the U-Net
  * input `torch.cat([latents (x batch), depth (x batch)], dim=1)` (guided_stable_diffuser.py:400-401, 451-455) in one launch.
- * latent_batch / depth_batch are 1 (broadcast) or batch; depth may be NULL (use_depth false). */
+ * latent_batch / depth_batch divide batch: item b reads latent[b mod latent_batch] (1 = broadcast, batch = one each, K of 2K =
+ * the K edits repeated for the two halves of the CFG pass); depth may be NULL (use_depth false). */
 int dh_pack_sample(float* dst, const float* latent, int latent_batch, int latent_channels, const float* depth,
                    int depth_batch, int depth_channels, int batch, int pixels, void* stream);
 /* Adam step on the null-text embedding (torch defaults; stable_null_inverter.py:143-155) */

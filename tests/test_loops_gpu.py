@@ -214,6 +214,17 @@ def test_engine_inplace_io_matches_copies(rig):
         assert packed.data_ptr() == hip.io_view("sample").data_ptr() and packed.shape == (2, 64, 64, 5)
         want = torch.cat([x, depth], dim=-1).expand(2, -1, -1, -1)
         assert torch.equal(packed, want)
+        # K items repeated for the two halves of a batched CFG pass: item b reads latent / depth b mod K
+        x2 = torch.randn(1, 64, 64, 4, generator=g, device=dev())
+        d2 = torch.rand(1, 64, 64, 1, generator=g, device=dev())
+        xs, ds = torch.cat([x, x2]), torch.cat([depth, d2])
+        both = hip.stage_sample(xs, ds, 2)
+        assert torch.equal(both, torch.cat([xs, ds], dim=-1))
+        hip4 = type(hip)(dict(hip.cfg), dtype=torch.float16, max_batch=4)
+        tiled = hip4.stage_sample(xs, ds, 4)
+        assert torch.equal(tiled, torch.cat([torch.cat([xs, ds], dim=-1)] * 2))
+        no_depth = type(hip)(dict(hip.cfg, in_channels=4), dtype=torch.float16, max_batch=2)
+        assert torch.equal(no_depth.stage_sample(x, None, 2), x.expand(2, -1, -1, -1))
         text = rig.cond.contiguous()
         e1, a1 = hip.forward(torch.cat([x, depth], dim=-1).contiguous(), 500.0, text, save_for_backward=True, want_acts=[1, 2],
                              want_eps=True)
