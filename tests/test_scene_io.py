@@ -231,3 +231,216 @@ def test_exr_rejects_what_it_cannot_read(tmp_path):
     (tmp_path / "junk.exr").write_bytes(b"\0" * 64)
     with pytest.raises(ValueError):
         S.read_exr(str(tmp_path / "junk.exr"))
+
+
+# ---- PIZ written by an encoder of the test's own (forward transforms; the reader only holds the inverses) -----------------
+# OpenEXR's published PIZ block: u16 min/max non-zero bitmap byte, bitmap bytes, i32 length, Huffman block.  The forward
+# wavelet, the forward LUT, the Huffman length assignment (heap), the table packer and the bit writer below share no code with
+# diffusionhandles_amd/scene_io.py, which only has the decoding direction.
+
+def _wenc14(a, b):
+    a, b = a - 65536 if a >= 32768 else a, b - 65536 if b >= 32768 else b
+    return ((a + b) >> 1) & 0xFFFF, (a - b) & 0xFFFF
+
+
+def _wenc16(a, b):
+    ao = (a + 0x8000) & 0xFFFF
+    m, d = (ao + b) >> 1, ao - b
+    if d < 0:
+        m = (m + 0x8000) & 0xFFFF
+    return m, d & 0xFFFF
+
+
+def _wav2_encode(a, mx):
+    """a: list of lists [ny][nx] of ints, in place; fine to coarse."""
+    ny, nx = len(a), len(a[0])
+    enc = _wenc14 if mx < (1 << 14) else _wenc16
+    p, p2 = 1, 2
+    while p2 <= min(nx, ny):
+        y = 0
+        while y <= ny - p2:
+            x = 0
+            while x <= nx - p2:
+                i00, i01 = enc(a[y][x], a[y][x + p])
+                i10, i11 = enc(a[y + p][x], a[y + p][x + p])
+                a[y][x], a[y + p][x] = enc(i00, i10)
+                a[y][x + p], a[y + p][x + p] = enc(i01, i11)
+                x += p2
+            if nx & p:
+                a[y][x], a[y + p][x] = enc(a[y][x], a[y + p][x])
+            y += p2
+        if ny & p:
+            x = 0
+            while x <= nx - p2:
+                a[y][x], a[y][x + p] = enc(a[y][x], a[y][x + p])
+                x += p2
+        p, p2 = p2, p2 << 1
+
+
+class _Bits:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, value, nbits):
+        self.acc = (self.acc << nbits) | value
+        self.n += nbits
+        while self.n >= 8:
+            self.n -= 8
+            self.out.append((self.acc >> self.n) & 255)
+        self.acc &= (1 << self.n) - 1
+
+    def done(self):
+        total = 8 * len(self.out) + self.n
+        if self.n:
+            self.out.append((self.acc << (8 - self.n)) & 255)
+        return bytes(self.out), total
+
+
+def _huf_compress(words, use_runs=True):
+    import heapq
+    freq = {}
+    for s in words:
+        freq[s] = freq.get(s, 0) + 1
+    im, iM = min(freq), max(freq) + 1              # iM: the run-length pseudo symbol, frequency 1
+    freq[iM] = 1
+    heap = [(f, s, (s,)) for s, f in freq.items()]
+    heapq.heapify(heap)
+    length = dict.fromkeys(freq, 0)
+    while len(heap) > 1:
+        fa, sa, ma = heapq.heappop(heap)
+        fb, sb, mb = heapq.heappop(heap)
+        for s in ma + mb:
+            length[s] += 1
+        heapq.heappush(heap, (fa + fb, min(sa, sb), ma + mb))
+    assert max(length.values()) <= 58
+    # canonical codes: longest lengths get the smallest codes; within a length, symbol order
+    count = [0] * 60
+    for l in length.values():
+        count[l] += 1
+    base, c = [0] * 60, 0
+    for l in range(58, 0, -1):
+        base[l], c = c, (c + count[l]) >> 1
+    code = {}
+    for s in sorted(length):
+        code[s] = base[length[s]]
+        base[length[s]] += 1
+    tb = _Bits()                                   # packed table: 6-bit lengths with zero runs
+    s = im
+    while s <= iM:
+        l = length.get(s, 0)
+        if l == 0:
+            run = 1
+            while s + run <= iM and length.get(s + run, 0) == 0 and run < 255 + 6:
+                run += 1
+            if run >= 6:
+                tb.put(63, 6)
+                tb.put(run - 6, 8)
+            elif run >= 2:
+                tb.put(59 + run - 2, 6)
+            else:
+                tb.put(0, 6)
+            s += run
+        else:
+            tb.put(l, 6)
+            s += 1
+    table, _ = tb.done()
+    db = _Bits()
+    i = 0
+    while i < len(words):
+        s, run = words[i], 1
+        while use_runs and i + run < len(words) and words[i + run] == s and run < 256:
+            run += 1
+        db.put(code[s], length[s])
+        if run >= 3:
+            db.put(code[iM], length[iM])
+            db.put(run - 1, 8)
+        else:
+            for _ in range(run - 1):
+                db.put(code[s], length[s])
+        i += run
+    data, nbits = db.done()
+    return struct.pack("<5I", im, iM, len(table), nbits, 0) + table + data
+
+
+def _piz_block(rows, use_runs=True):
+    """rows: per channel a uint16 array [ny, nx, words per pixel] -> PIZ block bytes."""
+    used = np.zeros(65536, bool)
+    for r in rows:
+        used[r.reshape(-1)] = True
+    used[0] = False                                # zero is never stored in the bitmap
+    bitmap = np.packbits(used, bitorder="little")
+    nz = np.nonzero(bitmap)[0]
+    used[0] = True
+    fwd = np.cumsum(used) - 1                      # value -> dense index (0 stays 0)
+    mx = int(used.sum()) - 1
+    words = []
+    for r in rows:
+        d = fwd[r]
+        for j in range(r.shape[2]):
+            plane = [[int(v) for v in line] for line in d[:, :, j]]
+            _wav2_encode(plane, mx)
+            d[:, :, j] = plane
+        words += [int(v) for v in d.reshape(-1)]
+    huf = _huf_compress(words, use_runs)
+    if len(nz):
+        head = struct.pack("<HH", nz[0], nz[-1]) + bitmap[nz[0]:nz[-1] + 1].tobytes()
+    else:
+        head = struct.pack("<HH", 8191, 0)
+    return head + struct.pack("<i", len(huf)) + huf, mx
+
+
+def _exr_piz_bytes(chans, use_runs=True):
+    """Like _exr_bytes for compression 4: 32 scan lines per chunk."""
+    names = sorted(chans)
+    h, w = chans[names[0]].shape
+    ref = _exr_bytes(chans, 0)
+    n_none = h                                     # chunks of the uncompressed twin
+    hdr_len = ref.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    hdr_end = len(ref) - sum(8 + w * sum(chans[n].dtype.itemsize for n in names) for _ in range(h)) - 8 * n_none
+    hdr = ref[:hdr_len] + bytes([4]) + ref[hdr_len + 1:hdr_end]
+    chunks, widest = [], 0
+    for y in range(0, h, 32):
+        ny = min(32, h - y)
+        rows = [np.ascontiguousarray(chans[n][y:y + ny]).astype(chans[n].dtype.newbyteorder("<")).view("<u2")
+                .reshape(ny, w, chans[n].dtype.itemsize // 2) for n in names]
+        blk, mx = _piz_block(rows, use_runs)
+        widest = max(widest, mx)
+        raw = b"".join(chans[n][r].astype(chans[n].dtype.newbyteorder("<")).tobytes() for r in range(y, y + ny) for n in names)
+        chunks.append((y, blk if len(blk) < len(raw) else raw))
+    off0 = len(hdr) + 8 * len(chunks)
+    offs, body = [], b""
+    for y, data in chunks:
+        offs.append(off0 + len(body))
+        body += struct.pack("<ii", y, len(data)) + data
+    return hdr + b"".join(struct.pack("<Q", o) for o in offs) + body, widest
+
+
+@pytest.mark.parametrize("case", ["half14", "wide16", "odd", "flat"])
+def test_exr_piz_round_trip_with_independent_encoder(tmp_path, case):
+    rng = np.random.default_rng({"half14": 1, "wide16": 2, "odd": 3, "flat": 4}[case])
+    if case == "half14":        # few distinct 16-bit values (< 2^14): the 14-bit wavelet
+        yy, xx = np.mgrid[0:40, 0:48]
+        ch = {"Y": (2.0 + 0.01 * xx + 0.02 * yy).astype(np.float16)}
+    elif case == "wide16":      # float32 + uint32 planes, > 2^14 distinct words: the 16-bit (modulo) wavelet
+        yy, xx = np.mgrid[0:70, 0:300]
+        ch = {"Z": (1.0 + 0.001 * xx * yy + rng.random((70, 300)) * 1e-3).astype(np.float32),
+              "id": rng.integers(0, 2 ** 32, (70, 300), dtype=np.uint32), "A": rng.random((70, 300)).astype(np.float16)}
+    elif case == "odd":         # odd sizes at several levels, last chunk of 5 lines, a width below the chunk height
+        ch = {"Y": np.round(rng.random((37, 21)) * 8).astype(np.float16), "Z": (rng.random((37, 21)) * 3).astype(np.float32)}
+    else:                       # long runs: one value everywhere, then a step
+        y = np.full((64, 64), 1.5, np.float16)
+        y[40:, 10:] = 3.0
+        ch = {"Y": y}
+    data, widest = _exr_piz_bytes(ch)
+    assert (widest >= (1 << 14)) == (case == "wide16")
+    (tmp_path / "p.exr").write_bytes(data)
+    got = S.read_exr(str(tmp_path / "p.exr"))
+    for n, a in ch.items():
+        assert np.array_equal(got[n], a.astype(got[n].dtype)), n
+    if case in ("flat", "half14"):
+        assert len(data) < len(_exr_bytes(ch, 0)) // 2         # the blocks really are the compressed form
+        norun, _ = _exr_piz_bytes(ch, use_runs=False)
+        (tmp_path / "q.exr").write_bytes(norun)
+        assert np.array_equal(S.read_exr(str(tmp_path / "q.exr"))["Y"], ch["Y"].astype(np.float32))
+        if case == "flat":
+            assert len(data) < len(norun)                       # the run-length symbol was exercised
