@@ -21,7 +21,7 @@ extern "C" int dh_dbg_gemm(int dtype, const void* A, long lda, const void* W, in
     tiled_cap = need;
   }
   static const bool pretiled = getenv("DH_DBG_PRETILED") != nullptr;   // timing runs: skip the tiling pass
-  if (!pretiled) launch_tile_weights(dtype, W, tiled, N, K, (hipStream_t)stream);
+  if (!pretiled) launch_tile_weights(dtype, W, tiled, N, K, (hipStream_t)stream, mode != 0 ? Cin : 0);
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = tiled; g.M = M; g.N = N; g.K = K; g.mode = mode; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
   g.Hout = Hout; g.Wout = Wout; g.stride = stride; g.up = up; g.bias = bias; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld;

@@ -3,10 +3,11 @@
 //   A(m,k): dense rows, or the im2col view of a channels-last image for a 3x3 convolution
 //           (stride 1/2, optional nearest-2x upsampled source), or the transposed-stride-2
 //           view used by the input-gradient of a stride-2 convolution.  K is ordered
-//           (tap, channel) so a 64-wide K tile lies inside one tap: the gather is a row of
-//           64 contiguous channels of a shifted pixel (zero outside the image).
+//           (64-channel chunk, tap, channel in chunk) -- conv_k_index -- so a 64-wide K tile lies inside
+//           one tap (the gather is a row of 64 contiguous channels of a shifted pixel, zero outside the
+//           image) and the nine taps of a chunk follow each other while its rows are in the L2.
 //   W:      [N][K] with K contiguous (torch Linear layout; conv weights are re-laid to
-//           [Cout][ky][kx][Cin] at load time).
+//           [Cout][Cin/64][ky][kx][64] at load time).
 //
 // 256 threads = 4 waves (2 x 2) per wave group.  Per K tile of 64: LDS-DMA (global_load_lds_dwordx4) into a ring of
 // unpadded, source-swizzled stages (see k_gemm_dma below) -> ds_read_b128 fragments ->
@@ -294,7 +295,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     b_ptr[j] = Wg + ((size_t)((n0 + row) >> 6) * KT) * 4096 + (size_t)(row & 63) * 64 + lane * 8;
   }
   int tap = 0, c0 = 0;
+#ifdef DH_CONV_TAP_MAJOR
   if (MODE != GM_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
+#else
+  if (MODE != GM_DENSE) { const int kt0 = kbeg >> 6, ch = kt0 / 9; tap = kt0 - ch * 9; c0 = ch * BK; }    // conv_k_index order
+#endif
 
   // one 1-KiB piece q (0..NPA-1: A rows, NPA..NP-1: W rows) of K tile kt into ring slot `stage`;
   // the conv (tap, c0) cursor belongs to the tile currently being issued and advances with next_tile()
@@ -340,7 +345,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
   };
   auto next_tile = [&]() {
+#ifdef DH_CONV_TAP_MAJOR
     if (MODE != GM_DENSE) { c0 += BK; if (c0 >= p.Cin) { c0 = 0; ++tap; } }
+#else
+    if (MODE != GM_DENSE) { if (++tap == 9) { tap = 0; c0 += BK; } }
+#endif
   };
   auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -644,15 +653,19 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 
 // plain [N][K] (K contiguous) -> tiled layout, for the test hooks (the engine tiles at load time)
 template <class T>
-__global__ void k_tile_weights(const T* src, T* dst, int N, int K) {
+__global__ void k_tile_weights(const T* src, T* dst, int N, int K, int conv_cin) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * K) return;
-  const int n = (int)(idx / K), k = (int)(idx - (size_t)n * K);
+  const int n = (int)(idx / K);
+  int k = (int)(idx - (size_t)n * K);
+#ifndef DH_CONV_TAP_MAJOR
+  if (conv_cin) { const int tap = k / conv_cin; k = conv_k_index(tap, k - tap * conv_cin); }
+#endif
   dst[wt_index(n, k, K)] = src[idx];
 }
-void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st) {
+void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st, int conv_cin) {
   const unsigned nb = (unsigned)(((size_t)N * K + 255) / 256);
-  hipLaunchKernelGGL((k_tile_weights<unsigned short>), dim3(nb), dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, N, K);
+  hipLaunchKernelGGL((k_tile_weights<unsigned short>), dim3(nb), dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, N, K, conv_cin);
 }
 
 template <class T>

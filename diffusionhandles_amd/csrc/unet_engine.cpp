@@ -464,8 +464,8 @@ int build(dh_unet& u) {
   return DH_OK;
 }
 
-// torch layout [N][C][taps] f32 -> forward matrix rows [row_off, row_off+N) x K = taps*C (k = tap*C + c) and
-// the input-gradient matrix rows c x K' = bwd_K (k' = (taps-1-tap)*Nb + col_off + n).  TILED = the swizzled
+// torch layout [N][C][taps] f32 -> forward matrix rows [row_off, row_off+N) x K = taps*C (k = tap*C + c; tiled 3x3:
+// conv_k_index(tap, c)) and the input-gradient matrix rows c x K' = bwd_K (k' = (taps-1-tap)*Nb + col_off + n, likewise).  TILED = the swizzled
 // 64x64-tile layout the GEMM streams (wt_index); otherwise plain row-major (the two tiny f32 convolutions).
 template <class D, bool TILED>
 __global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, long fwd_K, long row_off, D* bwd,
@@ -476,8 +476,11 @@ __global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, 
   const int cc = (int)((idx / taps) % C);
   const int nn = (int)(idx / ((size_t)taps * C));
   const D v = from_f32<D>(src[idx] * scale);
-  const int fr = (int)row_off + nn, fk = tap * C + cc;
-  const int bk = (taps - 1 - tap) * Nb + (int)col_off + nn;
+  int fk = tap * C + cc, bk = (taps - 1 - tap) * Nb + (int)col_off + nn;
+#ifndef DH_CONV_TAP_MAJOR
+  if (TILED && taps == 9) { fk = conv_k_index(tap, cc); bk = conv_k_index(taps - 1 - tap, (int)col_off + nn); }
+#endif
+  const int fr = (int)row_off + nn;
   if (TILED) {
     fwd[wt_index(fr, fk, (int)fwd_K)] = v;
     if (bwd) bwd[wt_index(cc, bk, (int)bwd_K)] = v;

@@ -52,12 +52,25 @@ void launch_splitk_reduce_ln_bwd(int dtype, const float* partial, int splits, co
 double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 bool gemm_profiling_on();   // HIP-event bracket active (bench roofline pass): graphs are bypassed
 // plain [N][K] -> tiled weight layout (test hooks); N, K multiples of 64
-void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st);
+// (conv_cin > 0: src is in the (tap, channel) order of a 3x3 kernel and lands in the conv_k_index order)
+void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st, int conv_cin = 0);
 // element offset of (n, k) in the tiled weight layout: [N/64][K/64] tiles of 64x64 halves (8 KiB,
 // contiguous), each stored as the swizzled LDS image (16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7))
 __host__ __device__ inline size_t wt_index(int n, int k, int K) {
   const int r = n & 63, c = (k & 63) >> 3;
   return ((size_t)(n >> 6) * (K >> 6) + (k >> 6)) * 4096 + (size_t)r * 64 + (size_t)((c ^ ((r >> 1) & 7)) << 3) + (k & 7);
+}
+
+// K index of (tap, channel) in a 3x3 implicit GEMM.  64-channel chunks outermost, the nine taps of a chunk on consecutive
+// K tiles, channel inside the chunk innermost: the shifted rows of a chunk are fetched again by the next eight K tiles while
+// they are still in the XCD's L2 (tap-major order re-read them one whole channel sweep later: 20 - 40 tiles of 24 - 56 KB per
+// workgroup in between, which does not fit the 4 MB once an XCD holds 20+ workgroups).  C must be a multiple of 64.
+__host__ __device__ inline int conv_k_index(int tap, int c) {
+#ifdef DH_CONV_TAP_MAJOR
+  return -1;      // resolved by the callers (tap * C + c)
+#else
+  return (c >> 6) * 576 + tap * 64 + (c & 63);
+#endif
 }
 
 // torch-layout f32 parameter [N][C][taps] -> weight storage (unet_engine.cpp): tiled 16-bit (dtype F16 / BF16) or plain f32
