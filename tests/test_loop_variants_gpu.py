@@ -17,7 +17,7 @@ from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
 pytestmark = pytest.mark.gpu
 
 VARIANTS = ["bg_erosion_10_local_avg", "local_avg_bg_loss", "linear_schedule", "quadratic_schedule", "no_depth", "bg_erosion",
-            "quadratic_schedule_local_avg"]
+            "quadratic_schedule_local_avg", "bg_erosion_15_local_avg", "bg_erosion_local_avg", "full_debug"]
 NT = 4
 
 
@@ -138,3 +138,49 @@ def test_guided_steps_under_variant_config(name, scene, golden):
     # (not for use_depth false: its first update sits on the L1 kink, see above -- there even two fp32 evaluations of the same
     # network disagree on the signs of the self-mapped cells, measured 0.26)
     assert (not conf.use_depth) or rel(up_here, up_ref) < 0.1, (name, rel(up_here, up_ref))
+
+
+def test_full_debug_saves_the_denoising_steps_like_the_reference(scene, golden):
+    """test/config/full_debug.yaml: save_denoising_steps.  The reference returns (image, {'opt': [[image after the optimisation
+    loop, image after the DDIM step] per timestep], 'post-opt': []}) with the images on the CPU
+    (guided_stable_diffuser.py:329-334, 385-386, 444-447, 477-479, 485-486), also for the unguided tail where the first image
+    is the unchanged latent."""
+    from diffusionhandles_amd import conf as C
+    from diffusionhandles_amd.guided_stable_diffuser import GuidedStableDiffuser
+    from diffusionhandles_amd.unet import HipUNet
+    from oracle import unet_torch as U
+    dev = scene.dev
+    g14 = golden("g14_loop_variants.npz")
+    raw = json.loads(str(g14["full_debug.conf"]))
+    assert raw["save_denoising_steps"] is True
+    conf = C.load_default().guided_diffuser
+    for k, v in raw.items():
+        setattr(conf, k, v)
+    cfg = dict(U.TINY)
+    ref = U.init_synthetic_(U.UNetTorch(cfg), seed=0).to(dev).eval()
+    hip = HipUNet(dict(cfg, text_len=77), dtype=torch.float16, max_batch=2)
+    hip.load_state_dict(ref.state_dict())
+    gd = GuidedStableDiffuser(conf, unet=hip, unet_config=dict(cfg, text_len=77), tokenizer=FixedTokenizer(),
+                              text_encoder=FixedTextEncoder(cfg["cross_attention_dim"])).to(dev)
+    prompt = "a sphere on a plane"
+    unc = gd._encode([""])[None].expand(50, -1, -1, -1).contiguous()
+    noise = torch.from_numpy(g14["noise"]).to(dev)
+    with torch.no_grad():
+        acts, _, _, _ = gd.initial_inference(noise, scene.disp, unc, prompt)
+    rec = {}
+    image, steps = gd.guided_inference(noise, scene.disp_e, unc, prompt, acts, scene.corr,
+                                       save_denoising_steps=conf.save_denoising_steps, record=rec)
+    assert sorted(steps) == ["opt", "post-opt"] and steps["post-opt"] == []
+    nt, it, gmax = conf.num_timesteps, conf.num_optsteps, conf.guidance_max_step
+    assert len(steps["opt"]) == nt and all(len(s) == 2 for s in steps["opt"])
+    assert len(rec["opt"]) == it * gmax and len(rec["step"]) == nt
+    assert all(im.device.type == "cpu" and im.shape == image.shape for s in steps["opt"] for im in s)
+    with torch.no_grad():
+        for t in (0, 1, gmax - 1, gmax, nt - 1):
+            before = rec["opt"][it * t + it - 1] if t < gmax else rec["step"][t - 1]       # unguided tail: the latent is untouched
+            assert torch.equal(steps["opt"][t][0], gd.decode_latent_image(before).cpu()), t
+            assert torch.equal(steps["opt"][t][1], gd.decode_latent_image(rec["step"][t]).cpu()), t
+    assert torch.equal(steps["opt"][-1][1], image.cpu())
+    # and the plain call returns the image alone
+    plain = gd.guided_inference(noise, scene.disp_e, unc, prompt, acts, scene.corr)
+    assert torch.is_tensor(plain) and torch.equal(plain, image)

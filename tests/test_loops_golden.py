@@ -79,7 +79,7 @@ def test_inversion_first_steps_match_reference(setup, golden):
     assert np.allclose(unc.numpy(), g7["inv_uncond_first"][:2], atol=1e-5)
 
 
-VARIANTS = ["bg_erosion_10_local_avg", "local_avg_bg_loss", "linear_schedule", "quadratic_schedule", "no_depth"]
+VARIANTS = ["bg_erosion_10_local_avg", "local_avg_bg_loss", "linear_schedule", "quadratic_schedule", "no_depth", "bg_erosion_15_local_avg"]
 
 
 @pytest.mark.parametrize("name", VARIANTS)

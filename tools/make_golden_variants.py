@@ -32,7 +32,9 @@ from oracle import unet_torch as U  # noqa: E402
 from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene  # noqa: E402
 
 VARIANTS = ["bg_erosion_10_local_avg", "local_avg_bg_loss", "linear_schedule", "quadratic_schedule", "no_depth",
-            "bg_erosion", "quadratic_schedule_local_avg"]
+            "bg_erosion", "quadratic_schedule_local_avg", "bg_erosion_15_local_avg", "bg_erosion_local_avg", "full_debug"]
+# (the eleventh file, mesh_depth_transform.yaml, has the default guided_diffuser block: it differs in depth_transform_mode only,
+#  which tools/make_golden_mesh.py pins)
 NT = 4            # timesteps of each loop that are run and stored (t_idx 0..3: every layer phase, schedule fall-off visible)
 IMG_GAIN = 0.05   # image = latent * IMG_GAIN / 2 + 0.5 stays inside (0, 1) for |latent| < 20
 

@@ -60,7 +60,12 @@ def run(log, manifest):
         dt = torch.float16
         if mode == 1:
             Cin = K // 9
-            H = int(round((M if M <= 4096 else M // 2) ** 0.5)); B = M // (H * H)
+            if os.environ.get("DH_SWEEP_BATCH"):                       # the batch the log was taken at (8 images, or 1 at the 96x96 latent)
+                B = int(os.environ["DH_SWEEP_BATCH"]); H = int(round((M // B) ** 0.5))
+            else:
+                H = int(round((M if M <= 4096 else M // 2) ** 0.5)); B = M // (H * H)
+            if B * H * H != M:
+                continue
             A = torch.randn(B * H * H, Cin, device=dev).to(dt); lda = Cin; geo = (H, H, Cin, H, H, 1, 0); gm = 1
         elif mode == 2:
             continue                                                  # stride-2 / upsampling convolutions: a handful of launches
@@ -113,7 +118,7 @@ def parse(manifest, trace):
     tot_pol = tot_best = 0.0
     for key, cands in sorted(by.items(), key=lambda kv: -kv[0][4]):
         pol = [c for c in cands if c[1] == 0][0]
-        best = min(c for c in cands if c[1] != 0)
+        best = min([c for c in cands if c[1] != 0] or [pol])
         tot_pol += pol[0] * key[4]; tot_best += min(best[0], pol[0]) * key[4]
         flag = "  <<<" if best[0] < 0.9 * pol[0] else ""
         print(f"M={key[0]:5d} N={key[1]:5d} K={key[2]:6d} mode={key[3]} x{key[4]:3d}: policy {pol[0]:7.1f} us   best {best[0]:7.1f} us "
