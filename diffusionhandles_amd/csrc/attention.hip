@@ -108,6 +108,53 @@ __device__ __forceinline__ uint4 tr_frag(const unsigned short* tptr, int cbase, 
   return make_uint4(l2.x, l2.y, u2.x, u2.y);
 }
 
+// ---- dense tiles filled by LDS-DMA (k_attn_fwd, DMA = true) -------------------------------------------------------
+// global_load_lds_dwordx4 writes 64 lanes x 16 bytes to CONSECUTIVE LDS addresses, so a staged tile has no row padding:
+// [64 rows][128 B], and the bank spread comes from the per-lane SOURCE address instead -- 16-byte chunk c of row r is stored at
+// chunk position c ^ dswz(r), dswz(r) = the three bits of (r >> 1) reversed.  Row-fragment reads (ds_read_b128, 16 lanes per
+// cycle = rows of all eight (r >> 1) & 7 classes and both parities, as in gemm.hip) hit 16 distinct slots of the 256-byte bank
+// row; the transposed reads (ds_read_b64_tr_b16: four consecutive rows x 64 bytes per cycle) need rows r and r + 2 in
+// different 64-byte quarters, which is why bit 0 of (r >> 1) lands on bit 2 of the chunk index.  SQ_LDS_BANK_CONFLICT of the
+// forward kernel: 0 (profiles/r03_pmc_attention.txt; the padded 144-byte rows of the register-staged tiles: 18 - 20 %).
+constexpr int DTILE = 64 * 64;                // halves
+__device__ uint4 g_attn_zero_page[8];         // source of the rows past the end of K / V
+#ifdef DH_ATTN_STAMP
+__device__ unsigned long long g_attn_ts[8];   // s_memtime stamps of wave 0 of block (0,0,0) (timing builds only, tools/attn_timeline.py)
+#define ATTN_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_attn_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+__device__ __forceinline__ int dswz(int r) {
+  const int y = r >> 1;
+  return ((y & 1) << 2) | (y & 2) | ((y >> 2) & 1);
+}
+__device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// acc = sum_kk mfma(A = rows (rowbase + lane&31) of a dense tile, B = register fragments); xk = hi ^ dswz(lane & 31)
+template <class T>
+__device__ __forceinline__ v16f dtile_times_frags(const unsigned short* tile, int rowbase, int ln, int xk, const uint4 (&f)[4]) {
+  v16f acc = zero16();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const uint4 a = *reinterpret_cast<const uint4*>(&tile[(rowbase + ln) * 64 + ((xk ^ (2 * kk)) << 3)]);
+    acc = Mma<T>::run(a, f[kk], acc);
+  }
+  return acc;
+}
+// transposed fragment of a dense tile: `trow` = tile + per-lane row offset, lo_c / up_c = the lane's chunk index of rows +0 / +8
+// already XORed with their dswz (the column half dt flips bit 2 of both)
+__device__ __forceinline__ uint4 dtr_frag(const unsigned short* trow, int lo_c, int up_c, int within, int dt, int r0) {
+  typedef __attribute__((address_space(3))) v4s* lp;
+  const unsigned short* a = trow + r0 * 64 + within;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a + ((lo_c ^ (4 * dt)) << 3)));
+  const v4s up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a + 8 * 64 + ((up_c ^ (4 * dt)) << 3)));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), u2 = __builtin_bit_cast(uint2, up);
+  return make_uint4(l2.x, l2.y, u2.x, u2.y);
+}
+
 // registers 8s..8s+7 of an accumulator -> B operand (16-bit)
 template <class T>
 __device__ __forceinline__ uint4 pack8(const v16f& p, int s);
@@ -157,7 +204,7 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // keys [ks, ks+1) * ceil(tiles / KS) and the groups' (m, l, O) are merged through LDS at the end.  A single
 // image has only Nq/128 * H query tiles (160 at 64x64 latents, 5 heads): splitting the keys inside the block
 // puts KS waves on every SIMD instead of one, so one wave's softmax VALU work hides under another's MFMAs.
-template <class T, int KS, int QW, bool DB>
+template <class T, int KS, int QW, bool DB, bool DMA = false>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
                                                        float* lse, int H, int Nq, int Nk, int causal) {
   // DB (key-split blocks of grids that fit the chip once or twice): the K/V tiles are double-buffered per wave group --
@@ -167,13 +214,20 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
   // second buffer's extra prologue step costs more than the barrier it saves (guided step -0.7 % when every shape was
   // double-buffered); so do big grids (batch 8: 1280 blocks), where 147 KB of LDS leaves one block per CU instead of two
   // (310 -> 352 us).
+  // DMA (the DB shapes): K/V tiles go global -> LDS directly (global_load_lds_dwordx4 into dense, source-swizzled tiles, see
+  // dswz above) instead of global -> registers -> ds_write_b128: no staging registers, no LDS store pass, 128 instead of 147 KB,
+  // no bank conflicts; the landing is ordered by vmcnt(0) in front of the one barrier per tile.  (Same speed as the register
+  // path, profiles/r03_ab_attn_dma.txt: the loop is bound by its VALU + MFMA issue)
+  static_assert(!DMA || DB, "the DMA path is the double-buffered one");
+  ATTN_STAMP(0);
   constexpr int NBUF = DB ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) unsigned short smem[KS * NBUF * 2 * TILE];
+  constexpr int TSZ = DMA ? DTILE : TILE;       // halves per staged tile
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[KS * NBUF * 2 * TSZ];
   constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
   const int ks = threadIdx.x / GT, tid = threadIdx.x - ks * GT;
   const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
-  unsigned short* sK0 = smem + ks * NBUF * 2 * TILE;     // buffer p: K at sK0 + 2 p TILE, V one TILE behind it
+  unsigned short* sK0 = smem + ks * NBUF * 2 * TSZ;     // buffer p: K at sK0 + 2 p TSZ, V one tile behind it
   const long qrow = (long)blockIdx.x * (32 * QW) + wave * 32 + ln;
   const bool qok = qrow < Nq;
   uint4 qf[4];
@@ -185,8 +239,30 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
   const int vt_off = (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const int tiles = (Nk + 63) >> 6, tps = (tiles + KS - 1) / KS;
   const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
-  TileRegs<GT> rk, rv;
+  TileRegs<GT> rk, rv;                           // (DMA: unused)
+  // DMA: the 16 one-KiB pieces of a K/V tile pair (8 rows each) are issued by the group's waves in turn; lane l of a piece
+  // fetches the chunk that belongs at position l & 7 of row l >> 3
+  const unsigned lds_grp = DMA ? (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + ks * NBUF * 2 * TSZ * 2 : 0u;
+  const int d_row = lane >> 3;
+  const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);      // chunk for even pieces; odd: ^ 1
+  const T* d_zero = reinterpret_cast<const T*>(g_attn_zero_page) + (lane & 7) * 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int key0, int buf) {
+#pragma unroll
+    for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
+      const int p = wave_u + j * QW;                 // wave-uniform
+      if (p < 16) {
+        const int pp = p & 7;
+        const long r = (long)key0 + 8 * pp + d_row;
+        const T* src = (p < 8 ? kp : vp) + r * ldk + ((d_c0 ^ (pp & 1)) << 3);
+        attn_dma16(r < Nk ? src : d_zero, __builtin_amdgcn_readfirstlane(lds_grp + (unsigned)(buf * 2 * TSZ * 2 + p * 1024)));
+      }
+    }
+  };
   if (t_begin < t_end) {
+    if (DMA) {
+      dma_tile(t_begin * 64, 0);
+    } else {
     fetch_tile<T, GT>(kp, ldk, t_begin * 64, Nk, rk, tid);
     fetch_tile<T, GT>(vp, ldk, t_begin * 64, Nk, rv, tid);
     if (DB) {
@@ -197,11 +273,20 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
         fetch_tile<T, GT>(vp, ldk, t_begin * 64 + 64, Nk, rv, tid);
       }
     }
+    }
   }
+  // dense-tile fragment addressing (per lane, hoisted)
+  const int xk = hi ^ dswz(ln);
+  const int d_rl = 4 * hi + (t16 >> 2), d_cl = 2 * ((lane >> 4) & 1) + ((t16 & 3) >> 1);
+  const int d_lo = d_cl ^ dswz(d_rl), d_up = d_cl ^ dswz(d_rl + 8), d_within = 4 * (t16 & 1);
+  ATTN_STAMP(1);
   for (int it = 0; it < tps; ++it) {
+    if (it == 1) ATTN_STAMP(2);
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;        // uniform per wave group; barriers are block-wide
-    __syncthreads();
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile `it` have landed ...
+    __syncthreads();                                               // ... and so have everyone's; tile it-1's buffer is free
+    if (DMA && act && t_begin + it + 1 < t_end) dma_tile(k0 + 64, (it + 1) & 1);
     if (!DB) {
       if (act) {
         commit_tile<GT>(rk, sK0, tid);
@@ -214,15 +299,20 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
       fetch_tile<T, GT>(kp, ldk, k0 + 64, Nk, rk, tid);
       fetch_tile<T, GT>(vp, ldk, k0 + 64, Nk, rv, tid);
     }
-    const unsigned short* sK = sK0 + (DB ? (it & 1) * 2 * TILE : 0);
-    const unsigned short* vt = sK + TILE + vt_off;
+    const unsigned short* sK = sK0 + (DB ? (it & 1) * 2 * TSZ : 0);
+    const unsigned short* vt = sK + TSZ + (DMA ? d_rl * 64 : vt_off);
     v16f s[2];
     if (DH_ATTN_ABL == 5) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[0][r] = __uint_as_float(qf[r & 3].x) * (float)(it + r); s[1][r] = __uint_as_float(qf[r & 3].y) * (float)(it - r); }
     } else {
-    s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
-    s[1] = tile_times_frags<T>(sK, 32, ln, hi, qf);
+    if (DMA) {
+      s[0] = dtile_times_frags<T>(sK, 0, ln, xk, qf);
+      s[1] = dtile_times_frags<T>(sK, 32, ln, xk, qf);
+    } else {
+      s[0] = tile_times_frags<T>(sK, 0, ln, hi, qf);
+      s[1] = tile_times_frags<T>(sK, 32, ln, hi, qf);
+    }
     }
     if (causal) {                  // text tower: key j is visible to query i only for j <= i (forward only)
       asm volatile("" ::: "memory");
@@ -275,10 +365,11 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           if (DH_ATTN_ABL == 4) { oacc[dt][st] += __uint_as_float(pf.x) + __uint_as_float(pf.y) + __uint_as_float(pf.z) + __uint_as_float(pf.w); continue; }
-          oacc[dt] = Mma<T>::run(tr_frag(vt, dt * 32, t2 * 32 + 16 * st), pf, oacc[dt]);
+          oacc[dt] = Mma<T>::run(DMA ? dtr_frag(vt, d_lo, d_up, d_within, dt, t2 * 32 + 16 * st) : tr_frag(vt, dt * 32, t2 * 32 + 16 * st), pf,
+                                 oacc[dt]);
         }
       }
-    if (DB && t_begin + it + 1 < t_end) {
+    if (DB && !DMA && t_begin + it + 1 < t_end) {
       unsigned short* nb = sK0 + ((it + 1) & 1) * 2 * TILE;
       commit_tile<GT>(rk, nb, tid);
       commit_tile<GT>(rv, nb + TILE, tid);
@@ -288,6 +379,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
       }
     }
   }
+  ATTN_STAMP(3);
   if (KS > 1) {
     // pairwise merge of the key ranges: group ks + step hands (O, m, l) to group ks through LDS (f32,
     // [34 values][64 lanes] per wave: conflict-free), halving the number of live groups per round
@@ -320,10 +412,15 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     }
     if (ks != 0) return;
   }
+  ATTN_STAMP(4);
   if (qok) {
     store_rows_t<T>(o + (long)b * Nq * ldo, ldo, qrow, h * HD, hi, oacc, 1.f / l_run);
     if (lse && hi == 0) lse[((long)b * H + h) * Nq + qrow] = (m_run * CEXP + log2f(l_run)) * LN2;
   }
+#ifdef DH_ATTN_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(5);
+#endif
 }
 
 template <class T>
@@ -420,7 +517,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = fast_exp2(__builtin_fmaf(s[r], CEXP, -lse_q));
-        s[r] = p * (dp[r] - del_q) * SCALE;
+        s[r] = p * (dp[r] - del_q);            // the 1/sqrt(d) of dS (a power of two) is applied once, to the finished dQ
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
@@ -454,7 +551,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
     }
     if (ks != 0) return;
   }
-  if (qok) store_rows_t<T>(dq + (long)b * Nq * lddq, lddq, qrow, h * HD, hi, dqacc, 1.f);
+  if (qok) store_rows_t<T>(dq + (long)b * Nq * lddq, lddq, qrow, h * HD, hi, dqacc, SCALE);
 }
 
 // ------------------------------------------------------------------------- backward dK, dV
@@ -533,7 +630,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
           const int r = 4 * g + i;
           const float p = fast_exp2(__builtin_fmaf(s[r], CEXP, -lv[i]));
           s[r] = p;
-          ds[r] = p * (dp[r] - dv4[i]) * SCALE;
+          ds[r] = p * (dp[r] - dv4[i]);        // the 1/sqrt(d) is applied once, to the finished dK
         }
       }
 #pragma unroll
@@ -572,6 +669,10 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
     }
     if (ks != 0) return;
   }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dkacc[dt][r] *= SCALE;
   if (qchunks > 1) {
     float* base = qpart + ((((size_t)chunk * gridDim.z + b) * H + h) * 2) * (32 * QW * 64) + (size_t)(wave * 32 + ln) * 64;
 #pragma unroll
@@ -653,8 +754,13 @@ static void attn_fwd_launch(int B, hipStream_t st, const void* q, long ldq, cons
   const dim3 grid(cdiv(Nq, 32 * QW), H, B);
   if constexpr (KS >= 2 && KS * QW < 16) {      // (the 16-wave block has no registers to spare for the second fetch)
     if ((long)grid.x * grid.y * grid.z <= 512) {
+#ifdef DH_ATTN_NO_DMA
       hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, true>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
                          ldk, (T*)o, ldo, lse, H, Nq, Nk, causal);
+#else
+      hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, true, true>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
+                         ldk, (T*)o, ldo, lse, H, Nq, Nk, causal);
+#endif
       return;
     }
   }
@@ -766,3 +872,9 @@ void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k,
 #undef DH_ATTN_QW
 
 }  // namespace dh
+
+#ifdef DH_ATTN_STAMP
+extern "C" int dh_dbg_attn_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dh::g_attn_ts), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
