@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     ntiles = ntiles < 0 ? 0 : (ntiles > loop_tiles ? loop_tiles : ntiles);
   }
   const T* Ag = reinterpret_cast<const T*>(p.A);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // scalar copy: the DMA destinations are scalar arithmetic
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all) + kg * (ST * STAGE);
   const int prow = lane >> 3;                       // row of this lane inside a piece
   // logical chunk this lane fetches (swizzle on the source): piece rows are 8 (wave + 4 j) + prow, so ((row >> 1) & 7)
@@ -274,7 +275,8 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     const int m = m0 + 8 * (wave + NWV * (j * WG + grp)) + prow;
     a_ok[j] = m < p.M;
     if (MODE == GM_DENSE) {
-      a_off[j] = (long)m * p.lda + lchunk * 8;
+      // rows past M read row M - 1 again (their products are never stored): no select in the loop
+      a_off[j] = (long)(a_ok[j] ? m : p.M - 1) * p.lda + lchunk * 8;
       a_oy[j] = a_ox[j] = 0;
     } else {
       const int hw = p.Hout * p.Wout;
@@ -283,6 +285,17 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
       a_ox[j] = r - a_oy[j] * p.Wout;
       if (MODE == GM_CONV_S1) a_off[j] = (((long)b * p.Hin + a_oy[j]) * p.Win + a_ox[j]) * p.lda + lchunk * 8;
       else a_off[j] = (long)b * p.Hin * p.Win;
+    }
+  }
+  // stride-1 3x3: which of the nine taps of this lane's pixel lie inside the image (bit = tap), decided once
+  unsigned a_taps[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    a_taps[j] = 0;
+    if (MODE == GM_CONV_S1 && a_ok[j]) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((unsigned)(a_oy[j] + t / 3 - 1) < (unsigned)p.Hin && (unsigned)(a_ox[j] + t % 3 - 1) < (unsigned)p.Win) a_taps[j] |= 1u << t;
     }
   }
   // W pieces: contiguous 1 KiB blocks of the tiled layout (rows 8*(wave+4j).. of the BN-row tile)
@@ -305,16 +318,16 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   // the conv (tap, c0) cursor belongs to the tile currently being issued and advances with next_tile()
   auto issue_piece = [&](int kt, int stage, int q) {
     const int k0 = kbeg + kt * BK;
-    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 1024);
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave_s * 1024);
     if (q < NPA) {
       const int j = q;
       if (MODE == GM_DENSE) {
         const T* ptr = Ag + a_off[j] + k0;
-        dma16(a_ok[j] ? ptr : zero, sbase + (j * WG + grp) * (NWV * 1024));
+        dma16(ptr, sbase + (j * WG + grp) * (NWV * 1024));
       } else if (MODE == GM_CONV_S1) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const long toff = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda + c0;
-        const bool ok = a_ok[j] && (unsigned)(a_oy[j] + ky - 1) < (unsigned)p.Hin && (unsigned)(a_ox[j] + kx - 1) < (unsigned)p.Win;
+        const bool ok = (a_taps[j] & (1u << tap)) != 0;
         const T* ptr = Ag + a_off[j] + toff;
         dma16(ok ? ptr : zero, sbase + (j * WG + grp) * (NWV * 1024));
       } else {
@@ -423,6 +436,18 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 
   constexpr int KK = BK / 16 / WG;                // k-steps of a tile multiplied by this wave group
   const int kk0 = grp * KK;
+  // The K loop carries as little VALU work as it can: a wave's own vector instructions (and those of the wave it shares a
+  // SIMD with) do not hide under its MFMAs (tools/ubench_coissue.hip).  The eight fragment addresses of a tile are a per-lane
+  // offset per k-step (hoisted: the swizzle is an XOR, so the four k-steps are four registers) plus a wave-uniform stage
+  // base kept in a scalar register and rotated without a division.
+  unsigned fa_off[BK / 16], fb_off[BK / 16];
+#pragma unroll
+  for (int kk = 0; kk < BK / 16; ++kk) {
+    const unsigned pc = (unsigned)(((2 * kk + hi) ^ ((ln >> 1) & 7)) << 4);
+    fa_off[kk] = (unsigned)((wm * (BM / (2 * MW)) + ln) * 128) + pc;
+    fb_off[kk] = (unsigned)(BM * 128 + (wn * (BN / 2) + ln) * 128) + pc;
+  }
+  int stg = 0;                     // kt % ST
   DH_STAMP(2);
   for (int kt = 0; kt < loop_tiles; ++kt) {
     // tile kt has landed once at most (ST-2) later tiles' loads are still outstanding
@@ -431,19 +456,19 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     if (kt == 0) DH_STAMP(3);
     if (KG > 1 && kt >= ntiles) continue;           // a group with a shorter K range only keeps the barrier count
     const bool more = ABL != 2 && kt + ST - 1 < ntiles;
-    const int nkt = kt + ST - 1, nstage = nkt % ST;
+    const int cur = __builtin_amdgcn_readfirstlane(stg);
+    const int nkt = kt + ST - 1, nstage = cur == 0 ? ST - 1 : cur - 1;        // (kt + ST - 1) % ST
+    stg = cur + 1 == ST ? 0 : cur + 1;
     if (ABL == 1) { if (more) issue(nkt, nstage); continue; }
-    const unsigned char* sa = smem + (kt % ST) * STAGE;
-    const unsigned char* sb = sa + BM * 128;
+    const unsigned char* st_base = smem + cur * STAGE;
     uint4 fw[2][TN], fx[2][TM];
     auto load_frags = [&](int kk, int buf) {
-      const int pc = ((2 * kk + hi) ^ ((ln >> 1) & 7)) << 4;
+      const unsigned char* pb = st_base + fb_off[kk];
+      const unsigned char* pa = st_base + fa_off[kk];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fw[buf][j] = *reinterpret_cast<const uint4*>(sb + (wn * (BN / 2) + j * 32 + ln) * 128 + pc);
+      for (int j = 0; j < TN; ++j) fw[buf][j] = *reinterpret_cast<const uint4*>(pb + j * (32 * 128));
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fx[buf][i] = *reinterpret_cast<const uint4*>(sa + (wm * (BM / (2 * MW)) + i * 32 + ln) * 128 + pc);
+      for (int i = 0; i < TM; ++i) fx[buf][i] = *reinterpret_cast<const uint4*>(pa + i * (32 * 128));
     };
     load_frags(kk0, 0);
 #pragma unroll
