@@ -771,8 +771,10 @@ template <class T, int KS, int QW>
 static void attn_dq_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
                            const void* o, long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq,
                            long lddq, int H, int Nq, int Nk) {
-  hipLaunchKernelGGL((k_attn_bwd_dq<T, KS, QW>), dim3(cdiv(Nq, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
-                     (const T*)k, (const T*)v, ldk, (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
+  // (the 16-wave shape is never chosen, launch_attention_bwd_dq: at 128 registers per lane it would spill; not instantiated)
+  if constexpr (KS * QW < 16)
+    hipLaunchKernelGGL((k_attn_bwd_dq<T, KS, QW>), dim3(cdiv(Nq, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
+                       (const T*)k, (const T*)v, ldk, (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
 }
 template <class T, int KS, int QW>
 static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
