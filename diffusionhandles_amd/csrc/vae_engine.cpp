@@ -11,6 +11,7 @@
 // attention has ONE head of dim 512, so it runs as two GEMMs around a row softmax (S = Q K^T with K tiled as the "weight",
 // O = P V with V^T tiled) instead of the head-dim-64 flash kernel.  Images are processed one at a time (512 x 512 x 128
 // channels is 262144 GEMM rows: one image fills the chip, and the row index arithmetic stays below its 2^21-row limit).
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -67,7 +68,7 @@ struct VTen { size_t off; int H, C; };     // [H*H][C] per image
 struct VWt { size_t off; int N, K, taps; bool f32; };
 struct VParam { std::string name; int ndim; int64_t shape[4]; int wt; int row_off; long f32_off; float scale; };
 struct VOpRec {
-  int type, in0, out, res = -1, wt = -1;
+  int type = 0, in0 = -1, out = -1, res = -1, wt = -1;
   long bias = -1, gamma = -1, beta = -1;
   int Hin = 0, Cin = 0, Hout = 0, up = 0, silu = 0, stride = 1, pad = 1;
   float eps = 1e-6f;
@@ -195,6 +196,55 @@ struct VB {
   }
 };
 
+// Activation arena with liveness reuse (the tape is straight-line and runs one image at a time): a tensor's region is
+// taken when the op that writes it is reached -- before that op's inputs are released, so an output never overlaps what
+// its op reads -- and returned to a first-fit free list after its last reader.  64x64 latents: 2.0 GB -> ~0.3 GB (decoder).
+void plan_arena(dh_vae_decoder& v) {
+  const int nt = (int)v.tens.size(), no = (int)v.ops.size();
+  std::vector<int> last(nt, -1);
+  for (int i = 0; i < no; ++i) {
+    const VOpRec& o = v.ops[i];
+    if (o.in0 >= 0) last[o.in0] = i;
+    if (o.res >= 0) last[o.res] = i;
+    if (o.out >= 0) last[o.out] = std::max(last[o.out], i);
+  }
+  std::vector<std::pair<size_t, size_t>> free_list;      // (offset, elements), sorted by offset
+  std::vector<char> placed(nt, 0);
+  size_t top = 0;
+  auto size_of = [&](int t) { return align_up((size_t)v.tens[t].H * v.tens[t].H * v.tens[t].C, 128); };
+  auto take = [&](int t) {
+    const size_t need = size_of(t);
+    for (size_t k = 0; k < free_list.size(); ++k)
+      if (free_list[k].second >= need) {
+        v.tens[t].off = free_list[k].first;
+        free_list[k].first += need; free_list[k].second -= need;
+        if (free_list[k].second == 0) free_list.erase(free_list.begin() + (long)k);
+        return;
+      }
+    if (!free_list.empty() && free_list.back().first + free_list.back().second == top) {      // grow the trailing hole
+      v.tens[t].off = free_list.back().first;
+      top = free_list.back().first + need;
+      free_list.pop_back();
+      return;
+    }
+    v.tens[t].off = top; top += need;
+  };
+  auto give = [&](int t) {
+    std::pair<size_t, size_t> blk(v.tens[t].off, size_of(t));
+    auto it = std::lower_bound(free_list.begin(), free_list.end(), blk);
+    it = free_list.insert(it, blk);
+    if (it + 1 != free_list.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; free_list.erase(it + 1); }
+    if (it != free_list.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; free_list.erase(it); }
+  };
+  for (int i = 0; i < no; ++i) {
+    const VOpRec& o = v.ops[i];
+    if (o.out >= 0 && !placed[o.out]) { take(o.out); placed[o.out] = 1; }
+    for (int t : {o.in0, o.res, o.out})
+      if (t >= 0 && placed[t] == 1 && last[t] == i) { give(t); placed[t] = 2; }
+  }
+  v.act_elems = top;
+}
+
 int build(dh_vae_decoder& v) {
   const dh_vae_config& c = v.cfg;
   VB b(v);
@@ -229,6 +279,7 @@ int build(dh_vae_decoder& v) {
   for (const VTen& t : v.tens) biggest = std::max(biggest, (size_t)t.H * t.H * t.C);
   v.partial_elems = std::max<size_t>((size_t)16 << 20, biggest);
   v.small_elems = (size_t)64 * 4096 + 4096;
+  plan_arena(v);
   return DH_OK;
 }
 
@@ -267,6 +318,7 @@ int build_encoder(dh_vae_decoder& v) {
   for (const VTen& t : v.tens) biggest = std::max(biggest, (size_t)t.H * t.H * t.C);
   v.partial_elems = std::max<size_t>((size_t)16 << 20, biggest);
   v.small_elems = (size_t)64 * 4096 + 4096;
+  plan_arena(v);
   return DH_OK;
 }
 }  // namespace
