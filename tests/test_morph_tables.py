@@ -76,3 +76,48 @@ def test_morphology_on_hand_worked_case():
     want2 = np.zeros_like(img)
     want2[4, 3] = want2[5, 3] = want2[4, 4] = 255
     assert np.array_equal(op, want2)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 10, 15])
+def test_oracle_morphology_against_scipy(k):
+    """The oracle's erode / dilate (its stand-in for cv2.erode / cv2.dilate: anchor (w//2, h//2), kernel not reflected,
+    pixels outside the image ignored) against scipy.ndimage's binary morphology, an implementation this repo did not write.
+    By definition  cv2.erode(A, B)(z)  = AND_b A(z + b - anchor) = scipy binary_erosion(A, B) with the pixels outside set,
+                   cv2.dilate(A, B)(z) = OR_b  A(z + b - anchor) = scipy binary_dilation (the Minkowski sum, which reflects B)
+                                         with B reflected; a reflected even-sized B has its anchor one to the left (origin -1)."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(k)
+    ker = D.ellipse_kernel(k, k)
+    org = -1 if k % 2 == 0 else 0
+    for density in (0.2, 0.5, 0.8, 0.97):
+        a = rng.random((48, 61)) < density
+        a[10:30, 5:40] |= density > 0.4                 # a solid block: something survives the big kernels
+        img = a.astype(np.uint8) * 255
+        er = ndi.binary_erosion(a, structure=ker.astype(bool), border_value=1)
+        di = ndi.binary_dilation(a, structure=ker[::-1, ::-1].astype(bool), origin=(org, org), border_value=0)
+        assert np.array_equal(D.erode(img, ker) > 0, er), (k, density)
+        assert np.array_equal(D.dilate(img, ker) > 0, di), (k, density)
+        cl = ndi.binary_erosion(ndi.binary_dilation(a, structure=ker[::-1, ::-1].astype(bool), origin=(org, org), border_value=0),
+                                structure=ker.astype(bool), border_value=1)
+        assert np.array_equal(D.morph_close(img, ker) > 0, cl), (k, density)
+
+
+def test_clean_mask_against_scipy_on_a_reprojected_mask():
+    """The whole clean-up (CLOSE with ellipse(res//50), OPEN with ellipse(res//250)) of the raw mask of a real re-projection."""
+    import scipy.ndimage as ndi
+    from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
+    res = 512
+    depth, bg, mask = make_scene(res)
+    raw = np.zeros((res, res), bool)
+    ys, xs = np.nonzero(mask[0, 0].numpy() > 0.5)
+    raw[np.clip(ys + 37, 0, res - 1), np.clip((xs * 1.07).astype(int) - 20, 0, res - 1)] = True      # a stretched copy: holes
+    def sd(a, k):
+        o = -1 if k.shape[0] % 2 == 0 else 0
+        return ndi.binary_dilation(a, structure=k[::-1, ::-1].astype(bool), origin=(o, o), border_value=0)
+    def se(a, k):
+        return ndi.binary_erosion(a, structure=k.astype(bool), border_value=1)
+    kc, ko = D.ellipse_kernel(res // 50, res // 50), D.ellipse_kernel(res // 250, res // 250)
+    want = sd(se(se(sd(raw, kc), kc), ko), ko)
+    got = D.clean_mask(raw, res) > 0
+    assert raw.sum() > 1000 and (got != raw).sum() > 50          # the clean-up does something on this mask
+    assert np.array_equal(got, want)
