@@ -852,11 +852,14 @@ void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k,
                               long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk, int B,
                               int H, int Nq, int Nk, hipStream_t st, float* scratch, size_t scratch_elems) {
   int ks = attn_key_split((Nq + 63) / 64, 2);
-  const int qw = attn_row_waves(Nk, H * B, Nq);
+  int qw = attn_row_waves(Nk, H * B, Nq);
   // cross-attention shape (77 keys, thousands of queries): the key blocks alone are H*B workgroups; split the queries
-  // over workgroups too and sum f32 partials
+  // over workgroups too and sum f32 partials.  (All keys in ONE block for that: the even-coverage rule above would pick two
+  // 64-key blocks for 77 keys and leave 10 workgroups streaming 4096 queries each -- 72 us per layer in the null-text
+  // backward, profiles/r03_invert_kernel_types.txt.)
   int qchunks = 1;
   float* qpart = nullptr;
+  if (scratch && Nk <= 128 && Nq >= 512) qw = cdiv(Nk, 32);
   if (scratch && Nk <= 32 * qw && Nq >= 512) {
     const int tiles_all = (Nq + 63) / 64;
     qchunks = 256 / (H * B);
