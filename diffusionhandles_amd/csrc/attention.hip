@@ -853,6 +853,12 @@ void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k,
                               int H, int Nq, int Nk, hipStream_t st, float* scratch, size_t scratch_elems) {
   int ks = attn_key_split((Nq + 63) / 64, 2);
   int qw = attn_row_waves(Nk, H * B, Nq);
+#ifdef DH_TUNING
+  { static const int fq = getenv("DH_ATTN_DKV_QW") ? atoi(getenv("DH_ATTN_DKV_QW")) : 0;
+    static const int fk = getenv("DH_ATTN_DKV_KS") ? atoi(getenv("DH_ATTN_DKV_KS")) : 0;
+    if (fq >= 1 && fq <= 4 && Nk > 128) qw = fq;
+    if ((fk == 1 || fk == 2) && Nk > 128) ks = fk; }
+#endif
   // cross-attention shape (77 keys, thousands of queries): the key blocks alone are H*B workgroups; split the queries
   // over workgroups too and sum f32 partials.  (All keys in ONE block for that: the even-coverage rule above would pick two
   // 64-key blocks for 77 keys and leave 10 workgroups streaming 4096 queries each -- 72 us per layer in the null-text
