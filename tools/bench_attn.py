@@ -30,6 +30,8 @@ def run(B, H, Nq, Nk, iters=20, bwd=True):
 CFGS = [(1, 5, 4096, 4096), (2, 5, 4096, 4096), (1, 10, 1024, 1024), (1, 20, 256, 256), (1, 5, 4096, 77), (1, 10, 1024, 77), (1, 5, 9216, 9216)]
 if os.environ.get("DH_ATTN_CFGS") == "b8":      # the batched-edits mode
     CFGS = [(8, 5, 4096, 4096), (8, 10, 1024, 1024), (8, 20, 256, 256), (8, 5, 4096, 77), (8, 10, 1024, 77)]
+if os.environ.get("DH_ATTN_CFGS") == "n1024":
+    CFGS = [(1, 10, 1024, 1024)]
 if os.environ.get("DH_ATTN_CFGS") == "n4096":   # one shape (counter passes)
     CFGS = [(1, 5, 4096, 4096)]
 for cfg in CFGS:
