@@ -108,7 +108,7 @@ __device__ __forceinline__ uint4 tr_frag(const unsigned short* tptr, int cbase, 
   return make_uint4(l2.x, l2.y, u2.x, u2.y);
 }
 
-// ---- dense tiles filled by LDS-DMA (k_attn_fwd, DMA = true) -------------------------------------------------------
+// ---- dense tiles filled by LDS-DMA (k_attn_fwd, DB = true) --------------------------------------------------------
 // global_load_lds_dwordx4 writes 64 lanes x 16 bytes to CONSECUTIVE LDS addresses, so a staged tile has no row padding:
 // [64 rows][128 B], and the bank spread comes from the per-lane SOURCE address instead -- 16-byte chunk c of row r is stored at
 // chunk position c ^ dswz(r), dswz(r) = the three bits of (r >> 1) reversed.  Row-fragment reads (ds_read_b128, 16 lanes per
@@ -204,24 +204,20 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // keys [ks, ks+1) * ceil(tiles / KS) and the groups' (m, l, O) are merged through LDS at the end.  A single
 // image has only Nq/128 * H query tiles (160 at 64x64 latents, 5 heads): splitting the keys inside the block
 // puts KS waves on every SIMD instead of one, so one wave's softmax VALU work hides under another's MFMAs.
-template <class T, int KS, int QW, bool DB, bool DMA = false>
+template <class T, int KS, int QW, bool DB>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq, const T* k, const T* v, long ldk, T* o, long ldo,
                                                        float* lse, int H, int Nq, int Nk, int causal) {
-  // DB (key-split blocks of grids that fit the chip once or twice): the K/V tiles are double-buffered per wave group --
-  // tile it+1, fetched one iteration ago, is committed to the other buffer after tile it has been multiplied, so ONE
-  // block-wide barrier per key tile orders both "tile it is visible" and "everyone has left tile it-1" (N = 4096, B = 1:
-  // 49.8 -> 45.3 us).  Short loops (KS = 1: at most 7 tiles, the 77-key cross-attention) keep the single buffer: there the
-  // second buffer's extra prologue step costs more than the barrier it saves (guided step -0.7 % when every shape was
-  // double-buffered); so do big grids (batch 8: 1280 blocks), where 147 KB of LDS leaves one block per CU instead of two
-  // (310 -> 352 us).
-  // DMA (the DB shapes): K/V tiles go global -> LDS directly (global_load_lds_dwordx4 into dense, source-swizzled tiles, see
-  // dswz above) instead of global -> registers -> ds_write_b128: no staging registers, no LDS store pass, 128 instead of 147 KB,
-  // no bank conflicts; the landing is ordered by vmcnt(0) in front of the one barrier per tile.  (Same speed as the register
-  // path, profiles/r03_ab_attn_dma.txt: the loop is bound by its VALU + MFMA issue)
-  static_assert(!DMA || DB, "the DMA path is the double-buffered one");
+  // DB (key-split blocks of grids that fit the chip once or twice): the K/V tiles are double-buffered per wave group and go
+  // global -> LDS directly (global_load_lds_dwordx4 into dense, source-swizzled tiles, see dswz above): tile it+1 is issued
+  // when everyone has left tile it-1 and lands under the work on tile it, so ONE block-wide barrier per key tile (behind
+  // vmcnt(0)) orders both (N = 4096, B = 1: 49.8 -> 45.3 us against the single buffer; no staging registers, no LDS store
+  // pass, no bank conflicts, 128 KB).  Short loops (KS = 1: at most 7 tiles, the 77-key cross-attention) keep the single
+  // register-staged buffer: there the second buffer's extra prologue step costs more than the barrier it saves (guided step
+  // -0.7 % when every shape was double-buffered); so do big grids (batch 8: 1280 blocks), where one block per CU instead of two
+  // loses (310 -> 352 us).
   ATTN_STAMP(0);
   constexpr int NBUF = DB ? 2 : 1;
-  constexpr int TSZ = DMA ? DTILE : TILE;       // halves per staged tile
+  constexpr int TSZ = DB ? DTILE : TILE;        // halves per staged tile
   __shared__ __attribute__((aligned(1024))) unsigned short smem[KS * NBUF * 2 * TSZ];
   constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
   const int ks = threadIdx.x / GT, tid = threadIdx.x - ks * GT;
@@ -239,10 +235,10 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
   const int vt_off = (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const int tiles = (Nk + 63) >> 6, tps = (tiles + KS - 1) / KS;
   const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
-  TileRegs<GT> rk, rv;                           // (DMA: unused)
-  // DMA: the 16 one-KiB pieces of a K/V tile pair (8 rows each) are issued by the group's waves in turn; lane l of a piece
+  TileRegs<GT> rk, rv;                           // (DB: unused)
+  // DB: the 16 one-KiB pieces of a K/V tile pair (8 rows each) are issued by the group's waves in turn; lane l of a piece
   // fetches the chunk that belongs at position l & 7 of row l >> 3
-  const unsigned lds_grp = DMA ? (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + ks * NBUF * 2 * TSZ * 2 : 0u;
+  const unsigned lds_grp = DB ? (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + ks * NBUF * 2 * TSZ * 2 : 0u;
   const int d_row = lane >> 3;
   const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);      // chunk for even pieces; odd: ^ 1
   const T* d_zero = reinterpret_cast<const T*>(g_attn_zero_page) + (lane & 7) * 8;
@@ -260,19 +256,11 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     }
   };
   if (t_begin < t_end) {
-    if (DMA) {
+    if (DB) {
       dma_tile(t_begin * 64, 0);
     } else {
-    fetch_tile<T, GT>(kp, ldk, t_begin * 64, Nk, rk, tid);
-    fetch_tile<T, GT>(vp, ldk, t_begin * 64, Nk, rv, tid);
-    if (DB) {
-      commit_tile<GT>(rk, sK0, tid);
-      commit_tile<GT>(rv, sK0 + TILE, tid);
-      if (t_begin + 1 < t_end) {
-        fetch_tile<T, GT>(kp, ldk, t_begin * 64 + 64, Nk, rk, tid);
-        fetch_tile<T, GT>(vp, ldk, t_begin * 64 + 64, Nk, rv, tid);
-      }
-    }
+      fetch_tile<T, GT>(kp, ldk, t_begin * 64, Nk, rk, tid);
+      fetch_tile<T, GT>(vp, ldk, t_begin * 64, Nk, rv, tid);
     }
   }
   // dense-tile fragment addressing (per lane, hoisted)
@@ -284,9 +272,9 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     if (it == 1) ATTN_STAMP(2);
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;        // uniform per wave group; barriers are block-wide
-    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile `it` have landed ...
+    if (DB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile `it` have landed ...
     __syncthreads();                                               // ... and so have everyone's; tile it-1's buffer is free
-    if (DMA && act && t_begin + it + 1 < t_end) dma_tile(k0 + 64, (it + 1) & 1);
+    if (DB && act && t_begin + it + 1 < t_end) dma_tile(k0 + 64, (it + 1) & 1);
     if (!DB) {
       if (act) {
         commit_tile<GT>(rk, sK0, tid);
@@ -300,13 +288,13 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
       fetch_tile<T, GT>(vp, ldk, k0 + 64, Nk, rv, tid);
     }
     const unsigned short* sK = sK0 + (DB ? (it & 1) * 2 * TSZ : 0);
-    const unsigned short* vt = sK + TSZ + (DMA ? d_rl * 64 : vt_off);
+    const unsigned short* vt = sK + TSZ + (DB ? d_rl * 64 : vt_off);
     v16f s[2];
     if (DH_ATTN_ABL == 5) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[0][r] = __uint_as_float(qf[r & 3].x) * (float)(it + r); s[1][r] = __uint_as_float(qf[r & 3].y) * (float)(it - r); }
     } else {
-    if (DMA) {
+    if (DB) {
       s[0] = dtile_times_frags<T>(sK, 0, ln, xk, qf);
       s[1] = dtile_times_frags<T>(sK, 32, ln, xk, qf);
     } else {
@@ -365,19 +353,10 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           if (DH_ATTN_ABL == 4) { oacc[dt][st] += __uint_as_float(pf.x) + __uint_as_float(pf.y) + __uint_as_float(pf.z) + __uint_as_float(pf.w); continue; }
-          oacc[dt] = Mma<T>::run(DMA ? dtr_frag(vt, d_lo, d_up, d_within, dt, t2 * 32 + 16 * st) : tr_frag(vt, dt * 32, t2 * 32 + 16 * st), pf,
+          oacc[dt] = Mma<T>::run(DB ? dtr_frag(vt, d_lo, d_up, d_within, dt, t2 * 32 + 16 * st) : tr_frag(vt, dt * 32, t2 * 32 + 16 * st), pf,
                                  oacc[dt]);
         }
       }
-    if (DB && !DMA && t_begin + it + 1 < t_end) {
-      unsigned short* nb = sK0 + ((it + 1) & 1) * 2 * TILE;
-      commit_tile<GT>(rk, nb, tid);
-      commit_tile<GT>(rv, nb + TILE, tid);
-      if (t_begin + it + 2 < t_end) {
-        fetch_tile<T, GT>(kp, ldk, k0 + 128, Nk, rk, tid);
-        fetch_tile<T, GT>(vp, ldk, k0 + 128, Nk, rv, tid);
-      }
-    }
   }
   ATTN_STAMP(3);
   if (KS > 1) {
@@ -756,13 +735,8 @@ static void attn_fwd_launch(int B, hipStream_t st, const void* q, long ldq, cons
   const dim3 grid(cdiv(Nq, 32 * QW), H, B);
   if constexpr (KS >= 2 && KS * QW < 16) {      // (the 16-wave block has no registers to spare for the second fetch)
     if ((long)grid.x * grid.y * grid.z <= 512) {
-#ifdef DH_ATTN_NO_DMA
       hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, true>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
                          ldk, (T*)o, ldo, lse, H, Nq, Nk, causal);
-#else
-      hipLaunchKernelGGL((k_attn_fwd<T, KS, QW, true, true>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
-                         ldk, (T*)o, ldo, lse, H, Nq, Nk, causal);
-#endif
       return;
     }
   }

@@ -308,11 +308,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     b_ptr[j] = Wg + ((size_t)((n0 + row) >> 6) * KT) * 4096 + (size_t)(row & 63) * 64 + lane * 8;
   }
   int tap = 0, c0 = 0;
-#ifdef DH_CONV_TAP_MAJOR
-  if (MODE != GM_DENSE) { tap = kbeg / p.Cin; c0 = kbeg - tap * p.Cin; }
-#else
   if (MODE != GM_DENSE) { const int kt0 = kbeg >> 6, ch = kt0 / 9; tap = kt0 - ch * 9; c0 = ch * BK; }    // conv_k_index order
-#endif
 
   // one 1-KiB piece q (0..NPA-1: A rows, NPA..NP-1: W rows) of K tile kt into ring slot `stage`;
   // the conv (tap, c0) cursor belongs to the tile currently being issued and advances with next_tile()
@@ -358,11 +354,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
   };
   auto next_tile = [&]() {
-#ifdef DH_CONV_TAP_MAJOR
-    if (MODE != GM_DENSE) { c0 += BK; if (c0 >= p.Cin) { c0 = 0; ++tap; } }
-#else
     if (MODE != GM_DENSE) { if (++tap == 9) { tap = 0; c0 += BK; } }
-#endif
   };
   auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -683,9 +675,7 @@ __global__ void k_tile_weights(const T* src, T* dst, int N, int K, int conv_cin)
   if (idx >= (size_t)N * K) return;
   const int n = (int)(idx / K);
   int k = (int)(idx - (size_t)n * K);
-#ifndef DH_CONV_TAP_MAJOR
   if (conv_cin) { const int tap = k / conv_cin; k = conv_k_index(tap, k - tap * conv_cin); }
-#endif
   dst[wt_index(n, k, K)] = src[idx];
 }
 void launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st, int conv_cin) {

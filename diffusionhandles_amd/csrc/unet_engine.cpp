@@ -477,9 +477,7 @@ __global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, 
   const int nn = (int)(idx / ((size_t)taps * C));
   const D v = from_f32<D>(src[idx] * scale);
   int fk = tap * C + cc, bk = (taps - 1 - tap) * Nb + (int)col_off + nn;
-#ifndef DH_CONV_TAP_MAJOR
   if (TILED && taps == 9) { fk = conv_k_index(tap, cc); bk = conv_k_index(taps - 1 - tap, (int)col_off + nn); }
-#endif
   const int fr = (int)row_off + nn;
   if (TILED) {
     fwd[wt_index(fr, fk, (int)fwd_K)] = v;

@@ -65,13 +65,7 @@ __host__ __device__ inline size_t wt_index(int n, int k, int K) {
 // K tiles, channel inside the chunk innermost: the shifted rows of a chunk are fetched again by the next eight K tiles while
 // they are still in the XCD's L2 (tap-major order re-read them one whole channel sweep later: 20 - 40 tiles of 24 - 56 KB per
 // workgroup in between, which does not fit the 4 MB once an XCD holds 20+ workgroups).  C must be a multiple of 64.
-__host__ __device__ inline int conv_k_index(int tap, int c) {
-#ifdef DH_CONV_TAP_MAJOR
-  return -1;      // resolved by the callers (tap * C + c)
-#else
-  return (c >> 6) * 576 + tap * 64 + (c & 63);
-#endif
-}
+__host__ __device__ inline int conv_k_index(int tap, int c) { return (c >> 6) * 576 + tap * 64 + (c & 63); }
 
 // torch-layout f32 parameter [N][C][taps] -> weight storage (unet_engine.cpp): tiled 16-bit (dtype F16 / BF16) or plain f32
 void launch_load_weight(int dtype, const float* src, int N, int C, int taps, void* fwd, long fwd_K, long row_off, void* bwd,
