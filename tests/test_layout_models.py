@@ -1,0 +1,72 @@
+"""CPU: bank arithmetic of the attention forward's dense LDS-DMA tiles (csrc/attention.hip, `dswz`): the claims in the kernel's
+comments checked against the LDS rules of the MI355X guide (64 banks of 4 bytes; ds_read_b128 serves the lane groups
+{0-3,12-15,20-27} / {4-11,16-19,28-31} / the same + 32, one LDS cycle each; ds_read_b64_tr_b16 serves lanes 0-31, then 32-63).
+The measured counterpart is SQ_LDS_BANK_CONFLICT = 0 in profiles/r03_pmc_attention.txt."""
+
+
+def dswz(r):
+    y = r >> 1
+    return ((y & 1) << 2) | (y & 2) | ((y >> 2) & 1)
+
+
+def banks(byte_addr, nbytes):
+    return {((byte_addr + 4 * i) // 4) % 64 for i in range(nbytes // 4)}
+
+
+B128_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+B128_GROUPS += [[l + 32 for l in g] for g in B128_GROUPS]
+
+
+def test_dswz_is_a_permutation_of_the_row_classes():
+    assert sorted(dswz(2 * c) for c in range(8)) == list(range(8))
+    assert all(dswz(r) == dswz(r ^ 1) for r in range(64))                    # rows 2c, 2c+1 share a class (they sit in different bank halves)
+    assert all(dswz(r) == dswz(r + 16) for r in range(48))                   # the swizzle has period 16 rows
+
+
+def test_row_fragment_reads_are_conflict_free():
+    """dtile_times_frags: lane (ln = lane & 31, hi = lane >> 5) reads 16 bytes of row rowbase + ln at chunk (2 kk + hi) ^ dswz(row)."""
+    for rowbase in (0, 32):
+        for kk in range(4):
+            for grp in B128_GROUPS:
+                seen = set()
+                for lane in grp:
+                    ln, hi = lane & 31, lane >> 5
+                    row = rowbase + ln
+                    b = banks(row * 128 + (((2 * kk + hi) ^ dswz(row)) << 4), 16)
+                    assert not (seen & b), (rowbase, kk, lane)
+                    seen |= b
+                assert len(seen) == 64
+
+
+def test_transposed_reads_are_conflict_free():
+    """dtr_frag: lane l (t = l & 15, g = (l >> 4) & 1, hi = l >> 5) reads 8 bytes of row r0 + 4 hi + (t >> 2) [+ 8] at column
+    32 dt + 16 g + 4 (t & 3) halves; 32 lanes per LDS cycle."""
+    for r0 in (0, 16, 32, 48):
+        for dt in (0, 1):
+            for up in (0, 8):
+                for half in (range(0, 32), range(32, 64)):
+                    seen = set()
+                    for lane in half:
+                        t, g, hi = lane & 15, (lane >> 4) & 1, lane >> 5
+                        row = r0 + 4 * hi + (t >> 2) + up
+                        col = 32 * dt + 16 * g + 4 * (t & 3)
+                        b = banks(row * 128 + (((col >> 3) ^ dswz(row)) << 4) + 2 * (col & 7), 8)
+                        assert not (seen & b), (r0, dt, up, lane)
+                        seen |= b
+                    assert len(seen) == 64
+
+
+def test_dma_pieces_cover_a_tile_exactly_once():
+    """dma_tile: lane l of one-KiB piece pp lands at LDS row 8 pp + (l >> 3), position l & 7, and fetches chunk
+    (l & 7) ^ dswz(row) -- every (row, chunk) of the 64 x 8 tile once; the per-lane chunk formula of the kernel
+    (d_c0 ^ (pp & 1)) equals it."""
+    got = set()
+    for pp in range(8):
+        for lane in range(64):
+            row = 8 * pp + (lane >> 3)
+            chunk = (lane & 7) ^ dswz(row)
+            l4 = lane >> 4
+            d_c0 = (lane & 7) ^ ((((l4 >> 1) & 1) << 1) | ((l4 & 1) << 2))
+            assert chunk == d_c0 ^ (pp & 1), (pp, lane)
+            got.add((row, chunk))
+    assert len(got) == 512
