@@ -70,3 +70,31 @@ def test_dma_pieces_cover_a_tile_exactly_once():
             assert chunk == d_c0 ^ (pp & 1), (pp, lane)
             got.add((row, chunk))
     assert len(got) == 512
+
+
+def test_gemm_fragment_reads_are_conflict_free():
+    """csrc/gemm.hip: staged rows are 128 bytes, chunk c of row r at c ^ ((r >> 1) & 7) (also the tiled weight layout, wt_index);
+    a fragment read is 16 bytes of row base + (lane & 31) at chunk 2 kk + (lane >> 5)."""
+    for base in (0, 32, 64, 96):
+        for kk in range(4):
+            for grp in B128_GROUPS:
+                seen = set()
+                for lane in grp:
+                    ln, hi = lane & 31, lane >> 5
+                    row = base + ln
+                    b = banks(row * 128 + (((2 * kk + hi) ^ ((row >> 1) & 7)) << 4), 16)
+                    assert not (seen & b), (base, kk, lane)
+                    seen |= b
+                assert len(seen) == 64
+
+
+def test_conv_k_index_is_a_bijection_with_taps_adjacent():
+    """csrc/unet_kernels.h conv_k_index: (tap, channel) -> K index, 64-channel chunks outermost, the nine taps of a chunk on
+    consecutive 64-wide K tiles."""
+    C = 320
+    idx = {(t, c): (c >> 6) * 576 + t * 64 + (c & 63) for t in range(9) for c in range(C)}
+    assert sorted(idx.values()) == list(range(9 * C))
+    for t in range(9):
+        for c0 in range(0, C, 64):
+            tiles = {idx[(t, c)] >> 6 for c in range(c0, c0 + 64)}
+            assert tiles == {(c0 >> 6) * 9 + t}
