@@ -64,6 +64,7 @@ SIGNATURES = {
     "dh_energy_fwd_bwd_planned": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_i, c_p, c_i, c_p, c_i, c_f, c_f, c_f,
                                         c_p, c_p, c_i, c_p, c_sz, c_p]),
     "dh_unet_create": (c_i, [ctypes.POINTER(UNetConfig), ctypes.POINTER(c_p)]),
+    "dh_unet_create_shared": (c_i, [c_p, c_i, c_p, ctypes.POINTER(c_p)]),
     "dh_unet_destroy": (None, [c_p]),
     "dh_unet_num_params": (c_i, [c_p]),
     "dh_unet_param_info": (c_i, [c_p, c_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i),
@@ -112,6 +113,7 @@ DEBUG_SIGNATURES = {
     "dh_dbg_gemm": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i,
                           c_p, c_l, c_p, c_l, c_i, c_p, c_sz, c_p]),
     "dh_dbg_gemm_lnfold": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
+    "dh_dbg_gemm_glu": (c_i, [c_i, c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dh_dbg_touch_tiled": (c_i, [c_sz, c_p]),
     "dh_dbg_groupnorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "dh_dbg_layernorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),

@@ -71,6 +71,31 @@ extern "C" int dh_dbg_gemm_lnfold(int dtype, const void* A, long lda, const void
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+// the GEGLU epilogues of the dense GEMM (engine: ff.net.0.proj forward, ff.net.2 input-gradient).  bwd = 0: W [N = 2F][K] and bias
+// in the PAIRED row order (unet_kernels.h glu_col), C (may be NULL) receives the pre-activations [M][2F] (paired), y [M][F] =
+// value * gelu(gate).  bwd = 1: the GEMM's tile A W^T [M][N = F] is dy of a GEGLU with saved pre-activations x [M][2F] (paired);
+// dx [M][2F] (paired) receives d_value | d_gate.
+extern "C" int dh_dbg_gemm_glu(int dtype, int bwd, const void* A, long lda, const void* W, int M, int N, int K, const float* bias,
+                               void* C, void* y, const void* x, void* dx, void* stream) {
+  DH_REQUIRE(A && W && K % 64 == 0 && N % 128 == 0, "bad arguments (K % 64, N % 128)");
+  DH_REQUIRE(bwd ? (x && dx) : (y != nullptr), "missing output");
+  static void* tiled = nullptr;
+  static size_t tiled_cap = 0;
+  const size_t need = (size_t)N * K * 2;
+  if (need > tiled_cap) {
+    if (tiled) (void)hipFree(tiled);
+    DH_CHECK_HIP(hipMalloc(&tiled, need));
+    tiled_cap = need;
+  }
+  launch_tile_weights(dtype, W, tiled, N, K, (hipStream_t)stream);
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = tiled; g.M = M; g.N = N; g.K = K; g.mode = A_DENSE; g.bias = bias;
+  if (bwd) { g.glub_x = x; g.glub_dx = dx; }
+  else { g.C = C; g.ldc = N; g.glu_y = y; g.glu_ldy = N / 2; }
+  launch_gemm(dtype, g, (hipStream_t)stream);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
 extern "C" int dh_dbg_groupnorm(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 const void* dy, void* dx, float* scratch, int B, int HW, int C, int G, float eps,
                                 int silu, int accumulate, void* stream) {

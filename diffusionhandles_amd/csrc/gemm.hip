@@ -81,6 +81,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
   const void* gnb_x; long gnb_ldx; const float *gnb_gamma, *gnb_beta, *gnb_stats; int gnb_silu;   // backward statistics
   const void* lnb_x; const float *lnb_gamma, *lnb_stats; const void* lnb_add; void* lnb_dx;        // LayerNorm backward on the reduce (host side only)
+  void* glu_y; long glu_ldy; const void* glub_x; void* glub_dx;                                    // GEGLU epilogues (GLU instantiations)
 };
 
 constexpr int BK = 64;
@@ -227,7 +228,11 @@ template <> __device__ __forceinline__ void frag_sums<bf16>(const uint4& f_in, f
 // MW = 2: eight waves laid out 4 (M) x 2 (N) over a 256-row tile, 64 x (BN/2) outputs per wave as before: the A and W
 // tiles are shared by twice the MFMA work, so the staging traffic per flop (the TA / LDS-DMA issue that bounds the
 // 4-wave kernel on big grids) drops by a quarter and two waves share every SIMD.  For grids that fill the machine.
-template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1, bool LNF = false>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
+// GLU = 1: the tile is the (paired-layout) pre-activation of a GEGLU: the epilogue also writes h * gelu(gate) (and the
+// pre-activations only when p.C is set); GLU = 2: the tile is dy of a GEGLU: the epilogue reads the saved pre-activations of its
+// rows and writes d_value / d_gate instead of dy.  Both keep the activation where the data already sits in registers
+// (reference model/attention.py:345-400; diffusers GEGLU [ext]).
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1, bool LNF = false, int GLU = 0>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
 __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) {
   static_assert((WG == 1) + (KG == 1) + (MW == 1) >= 2, "one kind of wave grouping per instantiation");
   static_assert(!LNF || (WG == 1 && MODE == GM_DENSE), "the folded LayerNorm needs every k-step of a row in one wave group");
@@ -577,6 +582,120 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
   }
 
+
+  if constexpr (GLU == 1) {
+    // GEGLU forward.  Lane (ln, hi) owns value columns {8 g + 4 hi ..+3} (g = 0, 1) of every 32-column block and their gates
+    // (g = 2, 3): 8 outputs per block, computed from the ROUNDED pre-activations (what the backward pass reads back), stored as
+    // one 16-byte chunk per lane after the lane-pair exchange.
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    const bool hb = p.bias != nullptr;
+    T* Y = reinterpret_cast<T*>(p.glu_y);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * (BN / 2) + j * 32;
+        if (nb >= p.N) continue;
+        uint2 w[4];
+        float pv[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+          if (hb) {
+            float4 b = bpre[j][g];
+            if (!pre_b) b = *reinterpret_cast<const float4*>(p.bias + nb + 8 * g + 4 * hi);
+            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+          }
+          T4 o;
+          o[0] = from_f32<T>(v0); o[1] = from_f32<T>(v1); o[2] = from_f32<T>(v2); o[3] = from_f32<T>(v3);
+          w[g] = __builtin_bit_cast(uint2, o);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pv[g][c] = to_f32<T>(o[c]);
+        }
+        if (p.C) {
+          T* out = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 8 * hi;
+          *reinterpret_cast<uint4*>(out) = half_exchange(w[0], w[1]);
+          *reinterpret_cast<uint4*>(out + 16) = half_exchange(w[2], w[3]);
+        }
+        uint2 y[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          T4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = from_f32<T>(pv[q][c] * gelu_f(pv[q + 2][c]));
+          y[q] = __builtin_bit_cast(uint2, o);
+        }
+        *reinterpret_cast<uint4*>(Y + (size_t)m * p.glu_ldy + (nb >> 1) + 8 * hi) = half_exchange(y[0], y[1]);
+      }
+    }
+    return;
+  }
+  if constexpr (GLU == 2) {
+    // GEGLU backward.  The tile holds dy (natural output columns o); the saved pre-activations of output columns
+    // [o0, o0 + 32) are the two paired 32-column blocks at 2 o0 + 32 q.  Per block the lane pair loads the value / gate chunks
+    // (16 bytes each), un-exchanges them to the (g, hi) ownership of the accumulators, and stores d_value / d_gate as
+    // 16-byte chunks after the inverse exchange.  Every load is issued before the first use.
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    const T* X = reinterpret_cast<const T*>(p.glub_x);
+    T* DX = reinterpret_cast<T*>(p.glub_dx);
+    const size_t ldx = 2 * (size_t)p.N;
+    uint4 Hc[TM][TN][2], Gc[TM][TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int nb = n0 + wn * (BN / 2) + j * 32;
+        if (nb >= p.N) nb = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const T* src = X + (size_t)mc * ldx + 2 * nb + 32 * q + 8 * hi;
+          Hc[i][j][q] = *reinterpret_cast<const uint4*>(src);
+          Gc[i][j][q] = *reinterpret_cast<const uint4*>(src + 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * (BN / 2) + j * 32;
+        if (nb >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint4 hc = Hc[i][j][q], gc = Gc[i][j][q];
+          const uint4 hx = half_exchange(make_uint2(hc.x, hc.y), make_uint2(hc.z, hc.w));
+          const uint4 gx = half_exchange(make_uint2(gc.x, gc.y), make_uint2(gc.z, gc.w));
+          uint2 dh[2], dg[2];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int g = 2 * q + s2;
+            const T4 hh = __builtin_bit_cast(T4, s2 ? make_uint2(hx.z, hx.w) : make_uint2(hx.x, hx.y));
+            const T4 gg = __builtin_bit_cast(T4, s2 ? make_uint2(gx.z, gx.w) : make_uint2(gx.x, gx.y));
+            T4 oh, og;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float dy = acc[i][j][4 * g + c], gate = to_f32<T>(gg[c]);
+              const GeluParts gp = gelu_parts(gate);
+              oh[c] = from_f32<T>(dy * gate * gp.Phi);
+              og[c] = from_f32<T>(dy * to_f32<T>(hh[c]) * fmaf(gate, gp.pdf, gp.Phi));
+            }
+            dh[s2] = __builtin_bit_cast(uint2, oh);
+            dg[s2] = __builtin_bit_cast(uint2, og);
+          }
+          T* dst = DX + (size_t)m * ldx + 2 * nb + 32 * q + 8 * hi;
+          *reinterpret_cast<uint4*>(dst) = half_exchange(dh[0], dh[1]);
+          *reinterpret_cast<uint4*>(dst + 16) = half_exchange(dg[0], dg[1]);
+        }
+      }
+    }
+    return;
+  }
   DH_STAMP(5);
   // the common epilogue as straight-line code: bias and residual already sit in registers (prefetched under the K loop), no
   // per-image vector, no SiLU.  The general path below carries a fallback load and a ~90-instruction SiLU block per 4-column
@@ -862,8 +981,15 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
     else hipLaunchKernelGGL(KERNEL, grid, dim3(TH), 0, st, k);                                              \
   } while (0)
 template <class T, int BM, int BN, int ST, int WG, int KG, int MW>
-static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k) {
+static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k, int glu = 0) {
   constexpr int TH = 256 * WG * KG * MW;
+  // the tiles that carry the GEGLU epilogues (gemm_dispatch picks only these when glu != 0)
+  constexpr bool GLUOK = WG == 1 && KG == 1 && ((BM == 256 && BN == 128 && MW == 2) || (BM == 128 && BN == 128 && MW == 2 && ST == 4) || (BM == 64 && BN == 64));
+  if constexpr (GLUOK) {
+    if (glu == 1 && lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true, 1>)); return; }
+    if (glu == 1) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 1>)); return; }
+    if (glu == 2) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 2>)); return; }
+  }
   if (gm == GM_DENSE) {
     if constexpr (WG == 1) {
       if (lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true>)); return; }
@@ -922,9 +1048,12 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && tiles256 >= kMwBlocks &&
                    !(k.M <= 256 && k.M > 128 && cdiv(k.N, 128) < 128) && (tiles256 >= kMwShortK || ktiles >= kSplitMinK);
   if (mw2) { BM = 256; BN = 128; }
+  // GEGLU epilogues (dense, N a multiple of 128, never split): 64x64, 128x128 or 256x128 tiles only
+  const int glu = k.glu_y ? 1 : (k.glub_x ? 2 : 0);
+  if (glu && !(BM == 64 && BN == 64)) { BM = mw2 ? 256 : 128; BN = 128; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
-  if (k.partial && !lnf && tiles < kSplitTiles && ktiles >= kSplitMinK) {
+  if (k.partial && !lnf && !glu && tiles < kSplitTiles && ktiles >= kSplitMinK) {
     splits = kSplitTarget / tiles;
     if (splits > ktiles / 4) splits = ktiles / 4;
     if (splits > 32) splits = 32;
@@ -939,7 +1068,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   const int kForceTile = getenv("DH_FORCE_TILE") ? atoi(getenv("DH_FORCE_TILE")) : 0;          // (re-read per dispatch: one process sweeps)
   const int kForceSplits = getenv("DH_FORCE_SPLITS") ? atoi(getenv("DH_FORCE_SPLITS")) : 0;
   int force_tile = 0;
-  if (kForceTile) {
+  if (kForceTile && !(k.glu_y || k.glub_x)) {
     const int fbm = kForceTile == 1 ? 64 : (kForceTile == 6 ? 256 : 128), fbn = (kForceTile <= 3) ? 64 : 128;
     if (k.N % fbn == 0 || fbn == 64) { BM = fbm; BN = fbn; force_tile = kForceTile; }
   }
@@ -1002,13 +1131,13 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (force_tile == 6) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k);
   else
 #endif
-  if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k);
-  else if (kMw128 && BM == 128 && BN == 128 && tiles_per_split >= kMw128) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k);
+  if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k, glu);
+  else if (BM == 128 && BN == 128 && (glu || (kMw128 && tiles_per_split >= kMw128))) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k, glu);
   // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
   // x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge; 64x64 tiles: no K grouping wins in situ)
   else if (BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k);
   else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 1>(gm, lnf, grid, st, k);
-  else if (BM == 64) launch_tile<T, 64, 64, 4, 1, 1, 1>(gm, lnf, grid, st, k);      // (rings of 6 / 8 stages: pass 2 % SLOWER; round 3, eight stages only on the <= 256-workgroup long-K launches: guided step -1.1 %)
+  else if (BM == 64) launch_tile<T, 64, 64, 4, 1, 1, 1>(gm, lnf, grid, st, k, glu);      // (rings of 6 / 8 stages: pass 2 % SLOWER; round 3, eight stages only on the <= 256-workgroup long-K launches: guided step -1.1 %)
   else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) launch_tile<T, 128, 128, 2, 1, 1, 1>(gm, lnf, grid, st, k);   // 64 KiB: two workgroups per CU
   else if (BN == 128) launch_tile<T, 128, 128, 4, 1, 1, 1>(gm, lnf, grid, st, k);
   else launch_tile<T, 128, 64, 5, 1, 1, 1>(gm, lnf, grid, st, k);
@@ -1049,6 +1178,7 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
   k.gnb_x = a.gnb_x; k.gnb_ldx = a.gnb_ldx; k.gnb_gamma = a.gnb_gamma; k.gnb_beta = a.gnb_beta; k.gnb_stats = a.gnb_stats;
   k.gnb_silu = a.gnb_silu;
   k.lnb_x = a.lnb_x; k.lnb_gamma = a.lnb_gamma; k.lnb_stats = a.lnb_stats; k.lnb_add = a.lnb_add; k.lnb_dx = a.lnb_dx;
+  k.glu_y = a.glu_y; k.glu_ldy = a.glu_ldy; k.glub_x = a.glub_x; k.glub_dx = a.glub_dx;
   if (a.gn_done) *a.gn_done = 0;
   if (a.lnb_done) *a.lnb_done = 0;
   if (dtype == DH_DTYPE_F16) gemm_dispatch<f16>(k, a.partial_elems, st, a.gn_done, a.lnb_done, dtype);

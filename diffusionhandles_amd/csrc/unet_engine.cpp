@@ -36,6 +36,7 @@ struct Wt {
   size_t fwd_off = 0, bwd_off = 0;   // element offsets (16-bit arena, or f32 arena when f32)
   int N = 0, K = 0, taps = 1;
   bool has_bwd = true, f32 = false;
+  int glu_F = 0;                     // > 0: the rows are the [2F] value | gate rows of a GEGLU projection, stored in the paired order (glu_col)
 };
 
 struct ParamInfo {
@@ -46,6 +47,7 @@ struct ParamInfo {
   size_t f32_off = 0;   // PK_F32
   int wt = -1;          // PK_MAT
   int row_off = 0;      // rows [row_off, row_off + shape[0]) of the (fused) weight
+  int glu_F = 0;        // PK_F32: a [2F] GEGLU bias, stored in the paired order
 };
 
 struct Op {
@@ -70,6 +72,10 @@ struct Op {
   // on the LayerNorm op, folded = 1 (the forward skips it: its statistics come out of the GEMM)
   int ln_fold = -1, folded = 0;
   long ln_s_off = -1, ln_t_off = -1;
+  // GEGLU fused into the GEMMs around it: on the ff.net.0.proj GEMM, glu_op = index of the OP_GEGLU op that consumes its output
+  // (the epilogue writes that op's output as well); on the ff.net.2 GEMM, glub_op = the OP_GEGLU op that produced its input (its
+  // input-gradient GEMM writes the gradient of the pre-activations directly)
+  int glu_op = -1, glub_op = -1;
 };
 
 }  // namespace dh
@@ -116,6 +122,8 @@ struct dh_unet {
   bool use_graphs = true;
   long ones_off = -1, zeros_off = -1;   // f32 vectors of the widest LayerNorm: gamma = 1 / beta = 0 for the unfolded large-batch path
   bool fold_dirty = true;           // a parameter was (re)loaded: W * gamma and the s / t vectors of the folded LayerNorms are stale
+  bool owns_weights = true;         // false: w16 / pf belong to the engine this one was shared from (dh_unet_create_shared)
+  int n_shared = 0;                 // engines ever shared from this one (its parameters stay frozen once > 0)
   // run state
   int saved_batch = 0;
   const float* saved_sample = nullptr;
@@ -323,10 +331,18 @@ struct Builder {
     int n3 = ln(t2, b + ".norm3");
     int gg = linear(n3, b + ".ff.net.0.proj", 8 * C, true, -1);
     fold_ln_into_last_gemm();
+    // value | gate rows in the paired order of the GEMM's lane ownership (unet_kernels.h glu_col): weight rows, bias and the
+    // columns of `gg` / its gradient all use it, nothing outside this block sees that tensor
+    const int ff1 = (int)u.ops.size() - 1;
+    u.wts[u.ops[ff1].wt].glu_F = 4 * C;
+    u.params[u.pindex[b + ".ff.net.0.proj.weight"]].glu_F = 4 * C;
+    u.params[u.pindex[b + ".ff.net.0.proj.bias"]].glu_F = 4 * C;
     Op g;
     g.type = OP_GEGLU; g.in0 = gg; g.out = tensor(N, 4 * C);
     u.ops.push_back(g);
+    u.ops[ff1].glu_op = (int)u.ops.size() - 1;
     int t3 = linear(g.out, b + ".ff.net.2", C, true, t2);
+    u.ops.back().glub_op = u.ops[ff1].glu_op;
     return linear(t3, pre + ".proj_out", C, true, x);
   }
 };
@@ -469,12 +485,13 @@ int build(dh_unet& u) {
 // 64x64-tile layout the GEMM streams (wt_index); otherwise plain row-major (the two tiny f32 convolutions).
 template <class D, bool TILED>
 __global__ void k_load_weight(const float* src, int N, int C, int taps, D* fwd, long fwd_K, long row_off, D* bwd,
-                              long bwd_K, long col_off, int Nb, float scale = 1.f) {
+                              long bwd_K, long col_off, int Nb, float scale = 1.f, int glu_F = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * C * taps) return;
   const int tap = (int)(idx % taps);
   const int cc = (int)((idx / taps) % C);
-  const int nn = (int)(idx / ((size_t)taps * C));
+  int nn = (int)(idx / ((size_t)taps * C));
+  if (glu_F) nn = glu_col(nn >= glu_F ? nn - glu_F : nn, nn >= glu_F ? 1 : 0);      // GEGLU projection: paired row order
   const D v = from_f32<D>(src[idx] * scale);
   int fk = tap * C + cc, bk = (taps - 1 - tap) * Nb + (int)col_off + nn;
   if (TILED && taps == 9) { fk = conv_k_index(tap, cc); bk = conv_k_index(taps - 1 - tap, (int)col_off + nn); }
@@ -530,6 +547,12 @@ __global__ void __launch_bounds__(256) k_fold_ln(const D* bwd, int bwd_K, const 
   if (threadIdx.x == 0) { s_out[n] = s; t_out[n] = t + (bias ? bias[n] : 0.f); }
 }
 
+// [2F] GEGLU bias (value | gate) -> the paired order of the stored weight rows
+__global__ void k_load_glu_bias(const float* src, float* dst, int F) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < 2 * F) dst[n] = src[glu_src_row(n, F)];
+}
+
 // (re)compute the folded weights and vectors of every LayerNorm-consuming GEMM; runs on `st` before the pass that needs them
 __global__ void k_fill_f32(float* p, int n, float v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,6 +597,7 @@ static void fold_layernorms(dh_unet* u, hipStream_t st) {
 }  // namespace
 
 // =============================================================================================
+static int create_engine(const dh_unet_config* cfg, dh_unet* parent, dh_unet** out);
 extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
   DH_REQUIRE(cfg && out, "null pointer");
   DH_REQUIRE(cfg->n_levels == 4, "n_levels must be 4");
@@ -589,6 +613,10 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
     DH_REQUIRE(cfg->block_out_channels[i] == cfg->heads[i] * 64, "head dim must be 64");
     DH_REQUIRE(cfg->block_out_channels[i] % cfg->norm_groups == 0, "channels must divide into norm groups");
   }
+  return create_engine(cfg, nullptr, out);
+}
+
+static int create_engine(const dh_unet_config* cfg, dh_unet* parent, dh_unet** out) {
   dh_unet* u = new dh_unet();
   u->cfg = *cfg;
   u->dtype = cfg->dtype;
@@ -600,8 +628,20 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
     return DH_ERR_HIP;
   };
   hipError_t e;
-  if ((e = hipMalloc((void**)&u->w16, u->w16_elems * 2 + 256)) != hipSuccess) return fail(e, "hipMalloc weights");
-  if ((e = hipMalloc((void**)&u->pf, u->pf_elems * 4 + 256)) != hipSuccess) return fail(e, "hipMalloc f32 params");
+  if (parent) {
+    // the parameter arenas are laid out by the architecture alone (build() never sizes them by max_batch)
+    if (u->w16_elems != parent->w16_elems || u->pf_elems != parent->pf_elems) {
+      set_error("internal: shared engine lays its parameters out differently");
+      delete u;
+      return DH_ERR_STATE;
+    }
+    u->owns_weights = false;
+    u->w16 = parent->w16; u->pf = parent->pf;
+    u->fold_dirty = false;
+  } else {
+    if ((e = hipMalloc((void**)&u->w16, u->w16_elems * 2 + 256)) != hipSuccess) return fail(e, "hipMalloc weights");
+    if ((e = hipMalloc((void**)&u->pf, u->pf_elems * 4 + 256)) != hipSuccess) return fail(e, "hipMalloc f32 params");
+  }
   if ((e = hipMalloc((void**)&u->act, u->act_elems * 2 + 256)) != hipSuccess) return fail(e, "hipMalloc activations");
   if ((e = hipMalloc((void**)&u->grad, u->grad_elems * 2 + 256)) != hipSuccess) return fail(e, "hipMalloc gradients");
   if ((e = hipMalloc((void**)&u->f32a, u->f32_elems * 4 + 256)) != hipSuccess) return fail(e, "hipMalloc f32 arena");
@@ -620,8 +660,10 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
     if ((e = hipMalloc((void**)&u->t_dev, 64)) != hipSuccess) return fail(e, "hipMalloc staging");
     u->use_graphs = !(getenv("DH_GRAPH") && atoi(getenv("DH_GRAPH")) == 0);
   }
-  (void)hipMemset(u->w16, 0, u->w16_elems * 2);
-  (void)hipMemset(u->pf, 0, u->pf_elems * 4);
+  if (!parent) {
+    (void)hipMemset(u->w16, 0, u->w16_elems * 2);
+    (void)hipMemset(u->pf, 0, u->pf_elems * 4);
+  }
   u->gready.assign(u->tens.size(), 0);
   u->galias.resize(u->tens.size());
   std::iota(u->galias.begin(), u->galias.end(), 0);
@@ -629,9 +671,26 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
   return DH_OK;
 }
 
+extern "C" int dh_unet_create_shared(dh_unet* parent, int max_batch, void* stream, dh_unet** out) {
+  DH_REQUIRE(parent && out, "null pointer");
+  DH_REQUIRE(parent->owns_weights, "share from the engine that owns the weights");
+  dh_unet_config cfg = parent->cfg;
+  if (max_batch > 0) cfg.max_batch = max_batch;
+  DH_REQUIRE(cfg.max_batch < 4096 && (long)cfg.max_batch * cfg.sample_size * cfg.sample_size < (1L << 21), "bad max_batch");
+  // W * gamma and the s / t vectors of the folded LayerNorms live in the shared arenas: finalise them before anyone reads
+  if (parent->fold_dirty) {
+    fold_layernorms(parent, (hipStream_t)stream);
+    DH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
+  int rc = create_engine(&cfg, parent, out);
+  if (rc == DH_OK) ++parent->n_shared;
+  return rc;
+}
+
 extern "C" void dh_unet_destroy(dh_unet* u) {
   if (!u) return;
-  (void)hipFree(u->w16); (void)hipFree(u->pf); (void)hipFree(u->act); (void)hipFree(u->grad);
+  if (u->owns_weights) { (void)hipFree(u->w16); (void)hipFree(u->pf); }      // (a shared engine never touches its parent here: destruction order at process exit is not ours)
+  (void)hipFree(u->act); (void)hipFree(u->grad);
   (void)hipFree(u->f32a); (void)hipFree(u->partial); (void)hipFree(u->scratch); (void)hipFree(u->small);
   (void)hipFree(u->in_sample); (void)hipFree(u->in_text); (void)hipFree(u->io_eps); (void)hipFree(u->out_dsample);
   (void)hipFree(u->out_dtext); (void)hipFree(u->t_dev);
@@ -651,11 +710,20 @@ extern "C" int dh_unet_param_info(const dh_unet* u, int i, const char** name, in
 }
 
 extern "C" int dh_unet_load_param(dh_unet* u, int i, const float* src, void* stream) {
-  if (u) { u->temb_rows = 0; u->fold_dirty = true; u->kv_key = 0; }     // cached time-embedding projections / folded LayerNorm weights belong to the old parameters
   DH_REQUIRE(u && src && i >= 0 && i < (int)u->params.size(), "bad arguments");
+  if (!u->owns_weights || u->n_shared > 0) {
+    set_error("dh_unet_load_param: the weights are shared (dh_unet_create_shared): load every parameter before sharing");
+    return DH_ERR_STATE;
+  }
+  u->temb_rows = 0; u->fold_dirty = true; u->kv_key = 0;     // cached time-embedding projections / folded LayerNorm weights belong to the old parameters
   hipStream_t st = (hipStream_t)stream;
   const ParamInfo& p = u->params[i];
   if (p.kind == PK_F32) {
+    if (p.glu_F) {
+      hipLaunchKernelGGL(k_load_glu_bias, dim3(cdiv((int)p.shape[0], 256)), dim3(256), 0, st, src, u->pf + p.f32_off, p.glu_F);
+      DH_LAUNCH_CHECK();
+      return DH_OK;
+    }
     DH_CHECK_HIP(hipMemcpyAsync(u->pf + p.f32_off, src, (size_t)p.shape[0] * 4, hipMemcpyDeviceToDevice, st));
     return DH_OK;
   }
@@ -674,18 +742,18 @@ extern "C" int dh_unet_load_param(dh_unet* u, int i, const float* src, void* str
     f16* f = (f16*)(u->w16 + w.fwd_off);
     f16* b = w.has_bwd ? (f16*)(u->w16 + w.bwd_off) : nullptr;
     hipLaunchKernelGGL((k_load_weight<f16, true>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
-                       bwd_ld, (long)p.row_off, w.N);
+                       bwd_ld, (long)p.row_off, w.N, 1.f, w.glu_F);
   } else {
     bf16* f = (bf16*)(u->w16 + w.fwd_off);
     bf16* b = w.has_bwd ? (bf16*)(u->w16 + w.bwd_off) : nullptr;
     hipLaunchKernelGGL((k_load_weight<bf16, true>), dim3(nb), dim3(256), 0, st, src, N, C, taps, f, fwd_ld, (long)p.row_off, b,
-                       bwd_ld, (long)p.row_off, w.N);
+                       bwd_ld, (long)p.row_off, w.N, 1.f, w.glu_F);
   }
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
 
-extern "C" size_t dh_unet_weight_bytes(const dh_unet* u) { return u ? u->w16_elems * 2 + u->pf_elems * 4 : 0; }
+extern "C" size_t dh_unet_weight_bytes(const dh_unet* u) { return u && u->owns_weights ? u->w16_elems * 2 + u->pf_elems * 4 : 0; }   // (a shared engine holds none)
 extern "C" size_t dh_unet_workspace_bytes(const dh_unet* u) {
   return u ? (u->act_elems + u->grad_elems + u->scratch_elems) * 2 + (u->f32_elems + u->partial_elems + u->small_elems) * 4 : 0;
 }
@@ -718,7 +786,7 @@ static void fill_gemm(dh_unet* u, const Op& o, int B, GemmArgs& g) {
   }
 }
 
-static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit, hipStream_t st) {
+static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit, bool save, hipStream_t st) {
   const int dt = u->dtype;
   const dh_unet_config& c = u->cfg;
   u->flops_fwd = 0;
@@ -755,6 +823,12 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit,
         if (o.gn_next >= 0 && oi + 1 < n_ops) {        // the next op normalises this output: statistics ride along
           const Ten& to = u->tens[o.out];
           g.gn_part = u->small; g.gn_HW = to.rows; g.gn_G = u->ops[o.gn_next].groups; g.gn_done = &gn_have;
+        }
+        if (o.glu_op >= 0 && o.glu_op < n_ops) {
+          // the GEGLU that follows runs in this GEMM's epilogue; the pre-activations go to memory only for a backward pass
+          const Op& ge = u->ops[o.glu_op];
+          g.glu_y = u->aptr(ge.out); g.glu_ldy = u->tens[ge.out].C;
+          if (!save) g.C = nullptr;
         }
         u->flops_fwd += launch_gemm(dt, g, st);
         break;
@@ -793,6 +867,7 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit,
         break;
       }
       case OP_GEGLU: {
+        if (oi > 0 && u->ops[oi - 1].glu_op == oi) break;      // done in the epilogue of the GEMM in front of it
         const Ten& t = u->tens[o.out];
         launch_geglu_fwd(dt, u->aptr(o.in0), u->aptr(o.out), B * t.rows, t.C, st);
         break;
@@ -817,9 +892,11 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit,
 
 // run `body` through a cached hipGraph (captured on first use of `key`) or eagerly
 // graph cache keys: batch in bits 0-11 (max_batch < 2^12 by dh_unet_create), the tape length in 12-27, the
-// backward's activation mask in 28-30, its flags in 31-33, time-embedding hit in 34, forward / backward in 35, text K|V hit in 36
-static uint64_t graph_key_fwd(int B, int n_ops, bool temb_hit, bool kv_hit) {
-  return (uint64_t)B | ((uint64_t)n_ops << 12) | ((uint64_t)(temb_hit ? 1 : 0) << 34) | ((uint64_t)(kv_hit ? 1 : 0) << 36);
+// backward's activation mask in 28-30, its flags in 31-33, time-embedding hit in 34, forward / backward in 35, text K|V hit in 36,
+// forward saved for a backward pass in 37 (a forward nobody differentiates does not write the GEGLU pre-activations)
+static uint64_t graph_key_fwd(int B, int n_ops, bool temb_hit, bool kv_hit, bool save) {
+  return (uint64_t)B | ((uint64_t)n_ops << 12) | ((uint64_t)(temb_hit ? 1 : 0) << 34) | ((uint64_t)(kv_hit ? 1 : 0) << 36) |
+         ((uint64_t)(save ? 1 : 0) << 37);
 }
 static uint64_t graph_key_bwd(int B, unsigned mask, bool eps, bool sample, bool text) {
   return (uint64_t)B | ((uint64_t)(mask & 7u) << 28) | ((uint64_t)(eps ? 1 : 0) << 31) | ((uint64_t)(sample ? 1 : 0) << 32) |
@@ -874,8 +951,9 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
   if (!kv_hit && text != u->in_text)
     DH_CHECK_HIP(hipMemcpyAsync(u->in_text, text, (size_t)B * c.text_len * c.cross_attention_dim * 4, hipMemcpyDeviceToDevice, st));
   if (!temb_hit) launch_set_scalar(u->t_dev, timestep, st);
-  int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit, kv_hit), st, &u->flops_fwd,
-                       [&]() { forward_ops(u, B, n_ops, first_op, kv_hit, st); });
+  const bool save = save_for_backward != 0;
+  int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit, kv_hit, save), st, &u->flops_fwd,
+                       [&]() { forward_ops(u, B, n_ops, first_op, kv_hit, save, st); });
   if (rc != DH_OK) { u->temb_rows = 0; u->kv_key = 0; return rc; }      // nothing cached after a failed capture / launch
   if (!temb_hit) { u->temb_t = timestep; u->temb_rows = B; u->temb_stream = st; }
   if (!kv_hit) { u->kv_key = u->text_key; u->kv_rows = B; u->kv_stream = st; }   // key 0: the buffer now holds an unnamed text
@@ -928,6 +1006,7 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
   int gnb_have = 0, gnb_for = -1;       // the split-K reduce just run left the backward statistics of GroupNorm op gnb_for
   int lnb_have = 0, lnb_for = -1;       // the split-K reduce just run applied the backward of LayerNorm op lnb_for
   int cat_done = -1;                    // the GroupNorm backward just run wrote the gradient of concatenation op cat_done to its sources
+  int glub_done = -1;                   // the input-gradient GEMM just run wrote the pre-activation gradient of GEGLU op glub_done
   for (int oi = (int)u->ops.size() - 1; oi >= 0; --oi) {
     const Op& o = u->ops[oi];
     // only the text gradient is wanted (null-text optimisation): nothing below the first cross-attention contributes to it
@@ -981,6 +1060,14 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
             g.lnb_add = u->gready[ln.in0] ? u->gptr(ln.in0) : nullptr; g.lnb_dx = u->gptr(ln.in0);
             g.lnb_done = &lnb_have;
             lnb_for = oi - 1;
+          }
+          if (o.glub_op >= 0 && o.glub_op == oi - 1 && !u->gready[o.in0] && o.in_col == 0 && w.K == ti.C) {
+            // the gradient being written is dy of the GEGLU processed next and this GEMM is its only consumer: the epilogue
+            // applies the GEGLU backward to its tile and writes the gradient of the pre-activations (dy never goes to memory)
+            const Op& ge = u->ops[o.glub_op];
+            g.glub_x = u->aptr(ge.in0); g.glub_dx = u->gptr(ge.in0); g.C = nullptr;
+            u->gready[ge.in0] = 1;
+            glub_done = o.glub_op;
           }
           u->flops_bwd += launch_gemm(dt, g, st);
           u->gready[o.in0] = 1;
@@ -1057,6 +1144,7 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
       }
       case OP_GEGLU: {
         if (!u->gready[o.out]) break;
+        if (glub_done == oi) { glub_done = -1; break; }
         const Ten& t = u->tens[o.out];
         launch_geglu_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->gptr(o.in0), B * t.rows, t.C, st);
         u->gready[o.in0] = 1;

@@ -10,6 +10,30 @@ __device__ inline float silu_grad(float z) {
   return s * (1.f + z * (1.f - s));
 }
 
+// GEGLU (reference model/attention.py:345-400 FeedForward with diffusers' GEGLU [ext]: h * gelu(gate), erf form).
+// Phi(g) = 0.5 erfc(-g / sqrt 2) from the Abramowitz-Stegun 7.1.26 rational form (|error| <= 1.5e-7, far below a 16-bit
+// rounding): one v_exp, one v_rcp and five FMAs, and the SAME exponential exp(-g^2 / 2) is the density the derivative
+// needs -- about a third of erff()'s instruction count, which is what lets the activation live in a GEMM epilogue.
+// The negative tail uses 0.5 erfc(|x|) directly (no 1 - erf cancellation).
+struct GeluParts { float Phi, pdf; };      // Phi(g), exp(-g^2/2) / sqrt(2 pi)
+__device__ __forceinline__ GeluParts gelu_parts(float g) {
+  const float x = fabsf(g) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+  const float e = __expf(-x * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float q = 0.5f * poly * e;                       // 0.5 erfc(|x|)
+  return {g < 0.f ? q : 1.f - q, e * 0.3989422804014327f};
+}
+__device__ __forceinline__ float gelu_f(float g) { return g * gelu_parts(g).Phi; }
+__device__ __forceinline__ float gelu_grad(float g) { const GeluParts p = gelu_parts(g); return fmaf(g, p.pdf, p.Phi); }
+// Column layout of a GEGLU pre-activation tensor [rows][2F] (and of its gradient): "paired" -- every 32-column block holds
+// the 16 value columns of outputs 16b .. 16b+15 followed by their 16 gate columns, so that the lane of the GEMM epilogue that
+// owns value columns {8g + 4hi ..+3} (g = 0, 1) also owns their gates (g = 2, 3): the activation is lane-local, and the
+// value / gate rows of ff.net.0.proj are permuted accordingly at load time (glu_col).  F % 16 == 0.
+__host__ __device__ inline int glu_col(int o, int gate) { return 32 * (o >> 4) + 16 * gate + (o & 15); }
+// fused-weight row (= stored column) n' -> row of the torch parameter [2F][K] (value rows first, then gate rows)
+__host__ __device__ inline int glu_src_row(int n, int F) { return ((n >> 4) & 1) * F + 16 * (n >> 5) + (n & 15); }
+
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONVT2 = 2 };
 
 struct GemmArgs {
@@ -43,6 +67,13 @@ struct GemmArgs {
   // the summed rows and writes lnb_dx (+ lnb_add) instead of C; *lnb_done is set to 1 and the caller skips the LayerNorm op.
   const void* lnb_x = nullptr; const float *lnb_gamma = nullptr, *lnb_stats = nullptr; const void* lnb_add = nullptr;
   void* lnb_dx = nullptr; int* lnb_done = nullptr;
+  // GEGLU in the epilogue (dense, no split-K; N = 2F in the paired column layout, see glu_col):
+  //   glu_y != NULL (forward, the ff.net.0.proj GEMM): y[m][o] = h * gelu(gate) of the ROUNDED pre-activations goes to glu_y
+  //   ([M][F], row stride glu_ldy); C may be NULL then (pre-activations not saved: no backward follows);
+  //   glub_x != NULL (the input-gradient GEMM of ff.net.2, N = F): the tile is dy of the GEGLU whose saved pre-activations are
+  //   glub_x [M][2F]; d_value = dy gelu(gate), d_gate = dy h gelu'(gate) go to glub_dx [M][2F] (paired layout), C is not written
+  void* glu_y = nullptr; long glu_ldy = 0;
+  const void* glub_x = nullptr; void* glub_dx = nullptr;
 };
 // split-K reduce + LayerNorm backward in one pass over the slabs (f32 [splits][rows][C]); dy is rounded to the storage type
 // before it is used, exactly as the reduce + k_ln_bwd pair does
@@ -103,7 +134,7 @@ void launch_layernorm_fwd(int dtype, const void* x, const float* gamma, const fl
 // dx = ln_bwd(dy) (+ add)   (add may alias nothing; dx written)
 void launch_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
                           const void* add, void* dx, int rows, int C, hipStream_t st);
-// GEGLU: y[m][j] = h * gelu(g), h = x[m][j], g = x[m][F + j]
+// GEGLU: y[m][j] = h * gelu(g), h = x[m][glu_col(j, 0)], g = x[m][glu_col(j, 1)] (paired column layout)
 void launch_geglu_fwd(int dtype, const void* x, void* y, int rows, int F, hipStream_t st);
 void launch_geglu_bwd(int dtype, const void* x, const void* dy, void* dx, int rows, int F, hipStream_t st);
 // misc

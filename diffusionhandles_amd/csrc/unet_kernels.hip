@@ -856,10 +856,6 @@ void launch_layernorm_bwd(int dtype, const void* x, const void* dy, const float*
 }
 
 // --------------------------------------------------------------------------------- GEGLU
-__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad(float g) {
-  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
-}
 
 template <class T>
 __global__ void k_geglu_fwd(const T* x, T* y, size_t rows, int F) {
@@ -869,8 +865,8 @@ __global__ void k_geglu_fwd(const T* x, T* y, size_t rows, int F) {
   const unsigned row32 = (unsigned)idx / (unsigned)fch;          // the grid (a 32-bit count of 256-thread blocks) bounds idx below 2^40; tensors here are < 2^32 elements: 32-bit division
   const size_t row = row32;
   const int j0 = (int)((unsigned)idx - row32 * (unsigned)fch) * 8;
-  uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + j0);
-  uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + F + j0);
+  uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + glu_col(j0, 0));     // (paired layout: 8 outputs lie inside one half block)
+  uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + glu_col(j0, 1));
   const T* h = reinterpret_cast<const T*>(&rh);
   const T* g = reinterpret_cast<const T*>(&rg);
   T o[8];
@@ -887,8 +883,8 @@ __global__ void k_geglu_bwd(const T* x, const T* dy, T* dx, size_t rows, int F) 
   const unsigned row32 = (unsigned)idx / (unsigned)fch;          // the grid (a 32-bit count of 256-thread blocks) bounds idx below 2^40; tensors here are < 2^32 elements: 32-bit division
   const size_t row = row32;
   const int j0 = (int)((unsigned)idx - row32 * (unsigned)fch) * 8;
-  uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + j0);
-  uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + F + j0);
+  uint4 rh = *reinterpret_cast<const uint4*>(x + row * 2 * F + glu_col(j0, 0));
+  uint4 rg = *reinterpret_cast<const uint4*>(x + row * 2 * F + glu_col(j0, 1));
   uint4 rd = *reinterpret_cast<const uint4*>(dy + row * F + j0);
   const T* h = reinterpret_cast<const T*>(&rh);
   const T* g = reinterpret_cast<const T*>(&rg);
@@ -900,8 +896,8 @@ __global__ void k_geglu_bwd(const T* x, const T* dy, T* dx, size_t rows, int F) 
     oh[i] = from_f32<T>(dv * gelu_f(gv));
     og[i] = from_f32<T>(dv * to_f32<T>(h[i]) * gelu_grad(gv));
   }
-  *reinterpret_cast<uint4*>(dx + row * 2 * F + j0) = *reinterpret_cast<uint4*>(oh);
-  *reinterpret_cast<uint4*>(dx + row * 2 * F + F + j0) = *reinterpret_cast<uint4*>(og);
+  *reinterpret_cast<uint4*>(dx + row * 2 * F + glu_col(j0, 0)) = *reinterpret_cast<uint4*>(oh);
+  *reinterpret_cast<uint4*>(dx + row * 2 * F + glu_col(j0, 1)) = *reinterpret_cast<uint4*>(og);
 }
 
 void launch_geglu_fwd(int dtype, const void* x, void* y, int rows, int F, hipStream_t st) {

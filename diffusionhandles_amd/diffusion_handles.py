@@ -43,15 +43,30 @@ class DiffusionHandles:
         return laplacian_depth_blend(depth, bg_depth, fg_mask, dilate_iterations=15)
 
     def transform_foreground_batch(self, depth, prompt, fg_mask, bg_depth, null_text_emb, init_noise, activations,
-                                   transforms, fg_weight=None, bg_weight=None, use_input_depth_normalization=False):
-        """K edits of one image in one batched pass (not in the reference; BASELINE config 3).
-        transforms: list of (rot_angle_deg, rot_axis[3], translation[3]).  Returns (images [K,3,H,W], [K disparities])."""
+                                   transforms, fg_weight=None, bg_weight=None, use_input_depth_normalization=False,
+                                   streams=1, batch=None):
+        """K edits of one image in batched passes (not in the reference; BASELINE config 3).
+        transforms: list of (rot_angle_deg, rot_axis[3], translation[3]).  Returns (images [K,3,H,W], [K disparities]).
+        streams > 1: the K edits are cut into chunks of `batch` (default ceil(K / streams)) and the chunks run on `streams`
+        concurrent lanes that share the U-Net weights (GuidedStableDiffuser.fork); batch = 1 runs single (B = 1) edits on the
+        lanes.  Images are bit-identical to the one-stream result at the same batch."""
         from .depth_transform import reproject_edits
+        K = len(transforms)
         with torch.no_grad():
             edits = reproject_edits(depth, bg_depth, fg_mask, self.diffuser.get_depth_intrinsics(device=depth.device),
                                     transforms, use_input_depth_normalization, device_correspondences=True)
-            imgs = self.diffuser.guided_inference_batch(init_noise, [d for d, _ in edits], null_text_emb, prompt,
-                                                        activations, [c for _, c in edits], fg_weight, bg_weight)
+            per = K if batch is None and streams <= 1 else int(batch or -(-K // max(1, int(streams))))
+            if streams <= 1 and per >= K:
+                imgs = self.diffuser.guided_inference_batch(init_noise, [d for d, _ in edits], null_text_emb, prompt,
+                                                            activations, [c for _, c in edits], fg_weight, bg_weight)
+            elif per <= 1:
+                imgs = torch.cat(self.diffuser.guided_inference_lanes(init_noise, edits, null_text_emb, prompt, activations,
+                                                                      max(1, int(streams)), fg_weight, bg_weight))
+            else:
+                chunks = [([d for d, _ in edits[i:i + per]], [c for _, c in edits[i:i + per]]) for i in range(0, K, per)]
+                imgs = torch.cat(self.diffuser.guided_inference_batch_lanes(init_noise, chunks, null_text_emb, prompt,
+                                                                            activations, max(1, int(streams)), fg_weight,
+                                                                            bg_weight))
         return imgs, [d for d, _ in edits]
 
     def transform_foreground(self, depth, prompt, fg_mask, bg_depth, null_text_emb, init_noise, activations,

@@ -308,16 +308,18 @@ class GuidedStableDiffuser(GuidedDiffuser):
         activations = [a.permute(0, 3, 1, 2) for a in store]      # [T,C,h,w] views of channels-last storage
         return activations, x.permute(0, 3, 1, 2), uncond_embeddings, init_latents
 
-    def prepare_guidance(self, depth, prompt, activations_orig, correspondences, fg_weight=None, bg_weight=None, orig=None):
+    def prepare_guidance(self, depth, prompt, activations_orig, correspondences, fg_weight=None, bg_weight=None, orig=None,
+                         cond=None):
         """Everything of guided_inference that is constant over the denoising loop.  `orig`: the channels-last copies of
-        the original activations of another guidance state of the SAME image (K edits of one image share them)."""
+        the original activations of another guidance state of the SAME image (K edits of one image share them); `cond`: the
+        prompt embedding when the caller already has it (lanes: the text tower is not run concurrently with itself)."""
         from types import SimpleNamespace
         fg_weight = self.conf.fg_weight if fg_weight is None else fg_weight
         bg_weight = self.conf.bg_weight if bg_weight is None else bg_weight
         st = SimpleNamespace()
         st.pc = self.process_correspondences(correspondences, img_res=depth.shape[-1], bg_erosion=self.conf.bg_erosion)
         st.depth_nhwc = _nhwc(self.init_depth(depth.to(self.device, torch.float32))) if self.conf.use_depth else None
-        st.cond = self._encode([prompt]).contiguous()
+        st.cond = self._encode([prompt]).contiguous() if cond is None else cond
         GuidedStableDiffuser._text_keys += 1
         st.cond_key = GuidedStableDiffuser._text_keys          # names st.cond for the engine's text K|V cache
         st.schedule = build_weight_schedule(fg_weight, bg_weight, self.conf.guidance_max_step,
@@ -418,26 +420,169 @@ class GuidedStableDiffuser(GuidedDiffuser):
         eps, _ = self.unet.forward(sample2, float(t), text2, save_for_backward=False, want_acts=False, inplace=True)
         return self.ddim_step(x, eps[:K], eps[K:], t)
 
+    def _batch_edit_steps(self, latents, depths, uncond_embeddings, prompt, activations_orig, correspondences_list,
+                          fg_weight=None, bg_weight=None, cond=None, orig=None):
+        """The batched edit as a generator: yields after the preparation and after every denoising step (everything is only
+        ENQUEUED on the current stream by then), returns the final latents [K,4,H,W] through StopIteration.  One body for the
+        one-stream call below and for the lanes of guided_inference_batch_lanes."""
+        K = len(depths)
+        if self.unet.max_batch < 2 * K:
+            raise RuntimeError(f"engine max_batch {self.unet.max_batch} < 2*K = {2 * K}")
+        torch.manual_seed(self.conf.seed)
+        self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
+        timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
+        sts = []
+        for d, c in zip(depths, correspondences_list):
+            sts.append(self.prepare_guidance(d, prompt, activations_orig, c, fg_weight, bg_weight,
+                                             orig=sts[0].orig if sts else orig, cond=sts[0].cond if sts else cond))
+        x = _nhwc(latents.to(self.device, torch.float32)).expand(K, -1, -1, -1).contiguous()
+        yield None
+        for t_idx, t in enumerate(timesteps):
+            x = self.guided_step_batch(sts, x, t_idx, t, uncond_embeddings[t_idx])
+            yield None
+        return x.permute(0, 3, 1, 2)
+
     def guided_inference_batch(self, latents, depths, uncond_embeddings, prompt, activations_orig, correspondences_list,
                                fg_weight=None, bg_weight=None):
         """K edits of one image at once.  depths: list of K edited disparities [1,1,H,W]; correspondences_list:
         K [N_k,4] tensors.  Needs an engine built with max_batch >= 2K.  Returns images [K,3,H,W]."""
-        K = len(depths)
-        if self.unet.max_batch < 2 * K:
-            raise RuntimeError(f"engine max_batch {self.unet.max_batch} < 2*K = {2 * K}")
         with torch.no_grad(), self.on_stream():
-            torch.manual_seed(self.conf.seed)
-            self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
-            timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
-            sts = []
-            for d, c in zip(depths, correspondences_list):
-                sts.append(self.prepare_guidance(d, prompt, activations_orig, c, fg_weight, bg_weight,
-                                                 orig=sts[0].orig if sts else None))
-            x = _nhwc(latents.to(self.device, torch.float32)).expand(K, -1, -1, -1).contiguous()
-            for t_idx, t in enumerate(timesteps):
-                x = self.guided_step_batch(sts, x, t_idx, t, uncond_embeddings[t_idx])
-            self.last_latents = x.permute(0, 3, 1, 2)
+            gen = self._batch_edit_steps(latents, depths, uncond_embeddings, prompt, activations_orig, correspondences_list,
+                                         fg_weight, bg_weight)
+            try:
+                while True:
+                    next(gen)
+            except StopIteration as done:
+                self.last_latents = done.value
             return self.decode_latent_image(self.last_latents)
+
+    # ---- lanes: concurrent edit streams on ONE copy of the weights --------------------------------------------------------
+    def fork(self, max_batch=None):
+        """A lane of this diffuser: the same configuration, VAE, text tower and U-Net WEIGHTS (HipUNet.share: resident once),
+        with its own engine arenas, hipGraphs, stream and scheduler, so that a second edit can run next to the first one in the
+        same process.  A single edit's passes are thousands of dependent launches of at most a few hundred workgroups: two
+        independent edits interleave on the chip (two processes on one GPU measured 1.4x the steps/s of one,
+        profiles/r03_bench_gloo2_one_gpu.json); lanes give that without a second copy of the weights."""
+        import copy
+        if self.unet is None:
+            raise RuntimeError("fork() needs the diffuser on its device first (.to(device))")
+        lane = copy.copy(self)
+        lane.unet = self.unet.share(max_batch)
+        lane._stream = torch.cuda.Stream(device=self.device)
+        lane.scheduler = DDIMScheduler()
+        lane._root = getattr(self, "_root", self)
+        return lane
+
+    def lanes(self, n, max_batch=None):
+        """[self, fork, ...]: n lanes on this diffuser's weights (cached per (n, max_batch))."""
+        key = (int(n), max_batch)
+        cache = self.__dict__.setdefault("_lane_cache", {})
+        if key not in cache:
+            cache[key] = [self] + [self.fork(max_batch) for _ in range(int(n) - 1)]
+        return cache[key]
+
+    def _decode_serialized(self, latents):
+        """VAE decode of a lane's result on the ROOT diffuser's decode stream: the decoder engine has one activation arena, so
+        the lanes' decodes run one after the other (in host issue order) while the other lane keeps denoising."""
+        root = getattr(self, "_root", self)
+        if not hasattr(root, "_decode_stream"):
+            root._decode_stream = torch.cuda.Stream(device=root.device)
+        cur = torch.cuda.current_stream(self.device)
+        root._decode_stream.wait_stream(cur)
+        with torch.cuda.stream(root._decode_stream):
+            img = root.decode_latent_image(latents)
+        latents.record_stream(root._decode_stream)
+        cur.wait_stream(root._decode_stream)
+        return img
+
+    @staticmethod
+    def run_lanes(lanes, jobs):
+        """Drive generator jobs on lanes from ONE host thread.  jobs: callables lane -> generator (a *_edit_steps body); job i
+        runs on lanes[i % len(lanes)], a lane's jobs one after the other.  The host only enqueues: it advances every lane by one
+        yield in turn, so the lanes' streams always hold work and the GPU interleaves them; nothing synchronises the lanes with
+        each other.  Returns the generators' return values in job order (tensors produced on the lanes' streams; the caller's
+        current stream is made to wait for every lane before this returns)."""
+        outer = torch.cuda.current_stream(lanes[0].device)
+        for ln in lanes:
+            ln._stream.wait_stream(outer)
+        queues = [[(i, job) for i, job in enumerate(jobs) if i % len(lanes) == li] for li in range(len(lanes))]
+        running = [None] * len(lanes)
+        results = [None] * len(jobs)
+        with torch.no_grad():
+            while any(q for q in queues) or any(r is not None for r in running):
+                for li, ln in enumerate(lanes):
+                    with torch.cuda.stream(ln._stream):
+                        if running[li] is None and queues[li]:
+                            i, job = queues[li].pop(0)
+                            running[li] = (i, job(ln))
+                        if running[li] is None:
+                            continue
+                        i, gen = running[li]
+                        try:
+                            next(gen)
+                        except StopIteration as done:
+                            results[i] = done.value
+                            running[li] = None
+        for ln in lanes:
+            outer.wait_stream(ln._stream)
+        return results
+
+    def guided_inference_batch_lanes(self, latents, chunks, uncond_embeddings, prompt, activations_orig, streams=2,
+                                     fg_weight=None, bg_weight=None):
+        """Batched edits of one image on `streams` concurrent lanes.  chunks: list of (depths, correspondences_list), each the
+        argument pair of one guided_inference_batch call; chunk i runs on lane i % streams.  Every lane executes exactly the
+        passes the one-stream call executes for its chunk (same batch, same kernels, private arenas), so the images are
+        bit-identical to guided_inference_batch chunk by chunk.  Returns one image tensor [K_i,3,H,W] per chunk."""
+        kmax = max(len(d) for d, _ in chunks)
+        lanes = self.lanes(min(int(streams), len(chunks)), None if self.unet.max_batch >= 2 * kmax else 2 * kmax)
+        with torch.no_grad(), self.on_stream():
+            cond = self._encode([prompt]).contiguous()
+            orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
+
+            def make(depths, corrs):
+                def job(lane):
+                    def body():
+                        lat = yield from lane._batch_edit_steps(latents, depths, uncond_embeddings, prompt, activations_orig,
+                                                                corrs, fg_weight, bg_weight, cond=cond, orig=orig)
+                        return lane._decode_serialized(lat)
+                    return body()
+                return job
+            return GuidedStableDiffuser.run_lanes(lanes, [make(d, c) for d, c in chunks])
+
+    def _edit_steps(self, latents, depth, uncond_embeddings, prompt, activations_orig, correspondences, fg_weight=None,
+                    bg_weight=None, cond=None, orig=None):
+        """One edit as a generator (see _batch_edit_steps): yields after the preparation and after every denoising step,
+        returns the final latents [1,4,H,W]."""
+        torch.manual_seed(self.conf.seed)
+        self.scheduler.set_timesteps(self.conf.num_timesteps, device=self.device)
+        timesteps, _ = self.get_timesteps(self.conf.num_timesteps, 1.0)
+        st = self.prepare_guidance(depth, prompt, activations_orig, correspondences, fg_weight, bg_weight, orig=orig, cond=cond)
+        x = _nhwc(latents.to(self.device, torch.float32))
+        yield None
+        for t_idx, t in enumerate(timesteps):
+            x = self.guided_step(st, x, t_idx, t, uncond_embeddings[t_idx])
+            yield None
+        return x.permute(0, 3, 1, 2)
+
+    def guided_inference_lanes(self, latents, edits, uncond_embeddings, prompt, activations_orig, streams=2, fg_weight=None,
+                               bg_weight=None):
+        """Single (B = 1) edits of one image on `streams` concurrent lanes.  edits: list of (depth, correspondences), the
+        argument pair of guided_inference; edit i runs on lane i % streams with exactly the passes guided_inference runs, so
+        the images are bit-identical to the one-stream calls.  Returns a list of images [1,3,H,W]."""
+        lanes = self.lanes(min(int(streams), len(edits)))
+        with torch.no_grad(), self.on_stream():
+            cond = self._encode([prompt]).contiguous()
+            orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]
+
+            def make(depth, corr):
+                def job(lane):
+                    def body():
+                        lat = yield from lane._edit_steps(latents, depth, uncond_embeddings, prompt, activations_orig, corr,
+                                                          fg_weight, bg_weight, cond=cond, orig=orig)
+                        return lane._decode_serialized(lat)
+                    return body()
+                return job
+            return GuidedStableDiffuser.run_lanes(lanes, [make(d, c) for d, c in edits])
 
     def guided_inference(self, latents, depth, uncond_embeddings, prompt, activations_orig, correspondences,
                          fg_weight=None, bg_weight=None, save_denoising_steps=False, record=None):

@@ -65,16 +65,22 @@ def broadcast_identity(identity, src=0, device=None, group=None):
     return out[0], out[1], out[2:]
 
 
-def run_edits(dh, image_identity, edits, depth, fg_mask, bg_depth, prompt, batch=8):
+def run_edits(dh, image_identity, edits, depth, fg_mask, bg_depth, prompt, batch=8, streams=1):
     """This rank's share of `edits` (list of dicts with rot_angle / rot_axis / translation) on one image identity
     (null_text_emb, init_noise, activations), executed `batch` edits at a time as ONE batched pass
     (DiffusionHandles.transform_foreground_batch; BASELINE config 4: 64 edits, 8 per GPU).  batch <= 1 runs them one by
-    one through transform_foreground.  Returns [(global_index, image [3,H,W] cpu, disparity [1,1,H,W] cpu)]; no
-    collective is involved."""
+    one through transform_foreground.  streams > 1: the rank's chunks of `batch` edits run on that many concurrent lanes of
+    one process (two engine arenas and streams on ONE copy of the weights; images bit-identical to streams = 1 at the same
+    batch).  Returns [(global_index, image [3,H,W] cpu, disparity [1,1,H,W] cpu)]; no collective is involved."""
     rank, world = rank_world()
     null_text, noise, acts = image_identity
     mine = shard_edits(list(enumerate(edits)), rank, world)
     out = []
+    if streams > 1 and mine:
+        tfs = [(e.get("rot_angle"), e.get("rot_axis"), e.get("translation")) for _, e in mine]
+        imgs, disps = dh.transform_foreground_batch(depth, prompt, fg_mask, bg_depth, null_text, noise, acts, tfs,
+                                                    streams=streams, batch=max(1, batch))
+        return [(gi, imgs[k].cpu(), disps[k].cpu()) for k, (gi, _) in enumerate(mine)]
     if batch <= 1:
         for gi, e in mine:
             img, disp = dh.transform_foreground(depth, prompt, fg_mask, bg_depth, null_text, noise, acts,

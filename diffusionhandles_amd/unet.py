@@ -62,6 +62,24 @@ class HipUNet:
         except Exception:
             pass
 
+    def share(self, max_batch=None):
+        """A second engine that reads THIS engine's weights (resident once) and owns everything a pass writes
+        (dh_unet_create_shared): two of them on two streams run two edits concurrently in one process.  Load the parameters
+        first; loading into either engine afterwards raises.  The returned handle keeps this one alive."""
+        mb = self.max_batch if max_batch is None else int(max_batch)
+        child = object.__new__(HipUNet)
+        child.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_h", "_views", "_table")})
+        child.max_batch = mb
+        child._table = self._table
+        child._saved_batch = 0
+        child._text_key = 0
+        child._parent = self
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.dh_unet_create_shared(self._h, mb, _lib.stream_ptr(), ctypes.byref(h)), "dh_unet_create_shared")
+        child._h = h
+        return child
+
     # ---- parameters ---------------------------------------------------------------------
     def param_table(self):
         if self._table is None:

@@ -187,6 +187,14 @@ typedef struct dh_unet_config {
 } dh_unet_config;
 
 int dh_unet_create(const dh_unet_config* cfg, dh_unet** out);
+/* A second engine on the SAME weights: `parent`'s 16-bit weight arena and f32 parameter arena are used read-only (3.4 GB at
+ * fp16, resident once), everything a pass writes -- activations, gradients, split-K slabs, statistics, I/O buffers, graphs --
+ * is private (dh_unet_workspace_bytes).  Two such engines driven on two HIP streams run two independent edits concurrently in
+ * one process (the reference runs one process per device and one edit at a time, webapp/start_webapps_in_tmux.sh:21-43; a
+ * single edit's passes leave most of the chip idle at any instant).  Load every parameter into `parent` BEFORE sharing: the
+ * folded LayerNorm weights are finalised here (on `stream`, synchronised), and dh_unet_load_param on a shared engine is an
+ * error.  `parent` must outlive the engines that share its weights.  max_batch <= 0: the parent's. */
+int dh_unet_create_shared(dh_unet* parent, int max_batch, void* stream, dh_unet** out);
 void dh_unet_destroy(dh_unet* u);
 /* parameter table: diffusers state-dict names, torch shapes */
 int dh_unet_num_params(const dh_unet* u);

@@ -101,8 +101,9 @@ def test_guided_loop_teacher_forced_all_steps(rig):
     """Every one of the 50 steps of the guided loop (38 guided: all three layer phases, all iteration multipliers; 12
     unguided: t_idx >= guidance_max_step) held tightly: the product's step i is started from the ORACLE's latent after step
     i - 1, so the chaotic divergence of the free-running trajectories (an L1 energy: its gradient is a sign) cannot hide an
-    error in a late step.  Per step: the latent after the step rel-L2 < 2e-2, the first optimisation iteration's update (the
-    guidance gradient) rel-L2 < 6e-2, the update of all three iterations < 0.2 (flipped signs accumulate)."""
+    error in a late step.  Per step: the latent after the step rel-L2 < 5e-3 (measured 9.5e-4), the first optimisation
+    iteration's update (the guidance gradient) rel-L2 < 6e-2 (measured 1.8e-2), the update of all three iterations < 0.2
+    (flipped signs accumulate)."""
     if not hasattr(rig, "rec_o"):
         test_guided_inference_matches_oracle(rig)
     gd, rec_o = rig.gd, rig.rec_o
@@ -118,13 +119,13 @@ def test_guided_loop_teacher_forced_all_steps(rig):
             x_out = gd.guided_step(st, x_in.permute(0, 2, 3, 1).contiguous(), i, ts[i], unc[i], record=rec)
             e = rel(x_out.permute(0, 3, 1, 2), rec_o["step"][i])
             worst_step = max(worst_step, e)
-            assert e < 2e-2, (i, e)
+            assert e < 5e-3, f"step {i}: latent after the step rel-L2 {e:.3e} >= gate 5e-3 (worst so far {worst_step:.3e})"
             if i < 38:
                 assert len(rec["opt"]) == 3
                 eu = rel(rec["opt"][0] - x_in, rec_o["opt"][3 * i] - x_in)               # first iteration: the guidance gradient
                 eu3 = rel(rec["opt"][2] - x_in, rec_o["opt"][3 * i + 2] - x_in)          # all three (signs of an L1 energy flip)
                 worst_upd, worst_upd3 = max(worst_upd, eu), max(worst_upd3, eu3)
-                assert eu < 6e-2 and eu3 < 0.2, (i, eu, eu3)
+                assert eu < 6e-2 and eu3 < 0.2, f"step {i}: first-iteration update rel-L2 {eu:.3e} (gate 6e-2), three-iteration update {eu3:.3e} (gate 0.2)"
             else:
                 assert "opt" not in rec or len(rec["opt"]) == 0
     print("teacher-forced guided loop: worst step rel err", worst_step, "worst first-iteration update rel err", worst_upd,

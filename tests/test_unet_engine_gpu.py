@@ -43,7 +43,7 @@ def run_case(cfg, dtype, B, t, tol_f, tol_b, check_text=True):
         errs[f"act{k}"] = rel(acts[k].permute(0, 3, 1, 2), out[4 + k])
     print("forward rel errors", errs)
     for k, v in errs.items():
-        assert v < tol_f, (k, v)
+        assert v < tol_f, f"forward {k}: measured rel-L2 {v:.3e} >= gate {tol_f:.1e} (all: {errs})"
     # backward: random cotangents on the three activations and on eps
     gs = [torch.randn(o.shape, generator=g, device=dev()) * 0.05 for o in (out[4], out[5], out[6])]
     ge = torch.randn(out[0].shape, generator=g, device=dev()) * 0.05
@@ -54,11 +54,11 @@ def run_case(cfg, dtype, B, t, tol_f, tol_b, check_text=True):
     d_sample, d_text = hip.backward(d_acts, ge.permute(0, 2, 3, 1).contiguous(), True, check_text)
     e1 = rel(d_sample.permute(0, 3, 1, 2), gx)
     print("backward rel errors: d_sample", e1)
-    assert e1 < tol_b, e1
+    assert e1 < tol_b, f"backward d_sample: measured rel-L2 {e1:.3e} >= gate {tol_b:.1e}"
     if check_text:
         e2 = rel(d_text, gt)
         print("d_text", e2)
-        assert e2 < tol_b, e2
+        assert e2 < tol_b, f"backward d_text: measured rel-L2 {e2:.3e} >= gate {tol_b:.1e}"
     # activation-only cotangent (the guided-inference case: d_eps = None, only act2 seeded)
     loss2 = (out[6] * gs16[2].float()).sum()
     gx2, = torch.autograd.grad(loss2, xs)
@@ -66,7 +66,7 @@ def run_case(cfg, dtype, B, t, tol_f, tol_b, check_text=True):
     d2, _ = hip.backward([None, None, d_acts[2]], None, True, False)
     e3 = rel(d2.permute(0, 3, 1, 2), gx2)
     print("act2-only d_sample", e3)
-    assert e3 < tol_b, e3
+    assert e3 < tol_b, f"backward (act2 only) d_sample: measured rel-L2 {e3:.3e} >= gate {tol_b:.1e}"
     # determinism
     d3, _ = hip.backward([None, None, d_acts[2]], None, True, False)
     assert torch.equal(d2, d3)
@@ -100,27 +100,27 @@ def test_engine_sd2_depth_full_size_fp16():
     """The full SD-2-depth configuration (865.7 M parameters), B=1, forward + backward."""
     from oracle import unet_torch as U
     names = None
-    run_case(U.SD2_DEPTH, torch.float16, 1, 500.0, 2e-2, 6e-2)
+    run_case(U.SD2_DEPTH, torch.float16, 1, 500.0, 4e-3, 6e-3)          # measured 1.2e-3 / 1.8e-3: gates <= 3x measured
 
 
 def test_engine_sd2_depth_full_size_bf16_batch2():
     """BASELINE config 5 computes the U-Net in bf16: full configuration, B=2 (the CFG pass shape), bf16 tolerance."""
     from oracle import unet_torch as U
-    run_case(U.SD2_DEPTH, torch.bfloat16, 2, 261.0, 3e-2, 5e-2, check_text=False)   # measured 1.1e-2 / 1.5e-2
+    run_case(U.SD2_DEPTH, torch.bfloat16, 2, 261.0, 3e-2, 4.5e-2, check_text=False)   # measured 1.1e-2 / 1.5e-2
 
 
 def test_engine_sd2_depth_latent96_fp16():
     """768x768 images: 96x96 latents, so 9216 / 2304 / 576 / 144 rows per image (not powers of two) through the
     reciprocal index arithmetic, the GroupNorm slices and the split-K policy."""
     from oracle import unet_torch as U
-    run_case(dict(U.SD2_DEPTH, sample_size=96), torch.float16, 1, 740.0, 2e-2, 6e-2, check_text=False)
+    run_case(dict(U.SD2_DEPTH, sample_size=96), torch.float16, 1, 740.0, 4e-3, 6e-3, check_text=False)
 
 
 def test_engine_sd2_depth_batch8_fp16():
     """Eight images per pass (the batched-edits mode): 256 row tiles per 64x64 layer, i.e. the 128x320 GEMM tile and the
     16-slice GroupNorm statistics, against the torch restatement."""
     from oracle import unet_torch as U
-    run_case(U.SD2_DEPTH, torch.float16, 8, 120.0, 2e-2, 6e-2, check_text=False)
+    run_case(U.SD2_DEPTH, torch.float16, 8, 120.0, 4e-3, 6e-3, check_text=False)
 
 
 def test_engine_truncated_forward_matches_full():

@@ -182,6 +182,13 @@ def test_layernorm(dtype, rows, C):
     close(dx, gref + add.float(), tol, tol * 2, "ln bwd")
 
 
+def glu_paired_index(Fd):
+    """Stored column n' of a GEGLU pre-activation tensor [rows][2F] -> column of the torch layout (value | gate): every 32-column
+    block holds the 16 value columns of outputs 16b .. 16b+15, then their 16 gate columns (csrc/unet_kernels.h glu_src_row)."""
+    n = torch.arange(2 * Fd)
+    return ((n >> 4) & 1) * Fd + 16 * (n >> 5) + (n & 15)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_geglu(dtype):
     g = torch.Generator(device=dev()).manual_seed(5)
@@ -191,10 +198,59 @@ def test_geglu(dtype):
     h, gt = xr.chunk(2, dim=-1)
     ref = h * F.gelu(gt)
     gref, = torch.autograd.grad(ref, xr, dy.float())
-    y = torch.empty(rows, Fd, dtype=dtype, device=dev()); dx = torch.empty_like(x)
-    L().check(L().lib().dh_dbg_geglu(DT[dtype], P(x), P(y), P(dy), P(dx), rows, Fd, L().stream_ptr()))
+    idx = glu_paired_index(Fd).to(dev())
+    xp = x[:, idx].contiguous()                      # the engine keeps this tensor in the paired column order
+    y = torch.empty(rows, Fd, dtype=dtype, device=dev()); dxp = torch.empty_like(xp)
+    L().check(L().lib().dh_dbg_geglu(DT[dtype], P(xp), P(y), P(dy), P(dxp), rows, Fd, L().stream_ptr()))
+    dx = torch.empty_like(dxp); dx[:, idx] = dxp
     tol = 4e-3 if dtype == torch.float16 else 2.5e-2
     close(y, ref, tol, tol, "geglu fwd"); close(dx, gref, tol, tol, "geglu bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,Fd,K", [(4096, 1280, 320), (1024, 2560, 640), (256, 5120, 1280), (64, 5120, 1280), (77, 256, 64),
+                                      (8192, 1280, 320)])
+def test_gemm_geglu_epilogues(dtype, M, Fd, K):
+    """GEGLU in the GEMM epilogues (reference model/attention.py:345-400 FeedForward: ff.net.0 = GEGLU(dim, 4 dim), ff.net.2 =
+    Linear): forward y = value * gelu(gate) out of the ff.net.0.proj GEMM (+ the paired-layout pre-activations when asked for),
+    backward d_value | d_gate out of the input-gradient GEMM of ff.net.2, against torch fp32 autograd.  Shapes = the three tile
+    families of the SD-2 levels (256x128, 128x128, 64x64), a ragged M and a batch-2 M."""
+    g = torch.Generator(device=dev()).manual_seed(M + Fd + K)
+    lib = L().lib()
+    A = torch.randn(M, K, generator=g, device=dev()).to(dtype)
+    W = (torch.randn(2 * Fd, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+    bias = 0.5 * torch.randn(2 * Fd, generator=g, device=dev())
+    idx = glu_paired_index(Fd).to(dev())
+    Wp, bp = W[idx].contiguous(), bias[idx].contiguous()
+    pre_ref = A.float() @ W.float().t() + bias
+    pre16 = pre_ref.to(dtype).float()
+    y_ref = pre16[:, :Fd] * F.gelu(pre16[:, Fd:])
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    for save in (True, False):
+        pre = torch.zeros(M, 2 * Fd, dtype=dtype, device=dev()) if save else None
+        y = torch.empty(M, Fd, dtype=dtype, device=dev())
+        L().check(lib.dh_dbg_gemm_glu(DT[dtype], 0, P(A), K, P(Wp), M, 2 * Fd, K, P(bp), P(pre), P(y), P(None), P(None),
+                                      L().stream_ptr()), "dh_dbg_gemm_glu fwd")
+        # (the activation is computed from the ROUNDED pre-activations: a pre-activation one 16-bit ulp off moves y by ~|h| ulp)
+        close(y, y_ref, 2 * tol, 2 * tol, f"geglu-epilogue y {M}x{Fd}x{K} save={save}")
+        if save:
+            nat = torch.empty_like(pre); nat[:, idx] = pre
+            close(nat, pre_ref, tol, tol, "geglu-epilogue pre-activations")
+    # backward: dy = dT W2^T comes out of the GEMM (A2 [M][K2] x Wb [F][K2]); x = saved pre-activations (paired)
+    K2 = K
+    A2 = torch.randn(M, K2, generator=g, device=dev()).to(dtype)
+    Wb = (torch.randn(Fd, K2, generator=g, device=dev()) / K2 ** 0.5).to(dtype)
+    x = torch.randn(M, 2 * Fd, generator=g, device=dev()).to(dtype)
+    xr = x.float().requires_grad_(True)
+    out = xr[:, :Fd] * F.gelu(xr[:, Fd:])
+    dy = A2.float() @ Wb.float().t()
+    gref, = torch.autograd.grad(out, xr, dy)
+    xp = x[:, idx].contiguous()
+    dxp = torch.zeros_like(xp)
+    L().check(lib.dh_dbg_gemm_glu(DT[dtype], 1, P(A2), K2, P(Wb), M, Fd, K2, P(None), P(None), P(None), P(xp), P(dxp),
+                                  L().stream_ptr()), "dh_dbg_gemm_glu bwd")
+    dx = torch.empty_like(dxp); dx[:, idx] = dxp
+    close(dx, gref, tol, tol, f"geglu-epilogue backward {M}x{Fd}x{K2}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
