@@ -10,7 +10,9 @@ synthetic scene, seeded random weights of the exact architecture, the per-image 
 N > 1: one process per GPU, each an independent edit, no collective on the data path
 (weak scaling); torch.distributed is used only for the timing barriers and the MAX reductions.
 `python bench.py --gpus N` with no launcher in front starts the N ranks itself (launch_ranks: the parent never touches
-the GPU); under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are used as given.
+the GPU; --launch-timeout bounds the job); under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are used as
+given.  Profiling: put a profiler in front of a `--gpus 1` run (or of one rank) only -- `rocprofv3 ... -- python3 bench.py --gpus N`
+would make the profiler-initialised parent spawn the ranks.
 
 Next to the headline the same run reports (rank 0 unless stated; none of it inside the timed region):
   roofline        dominant kernel (k_gemm_dma) by HIP events on its stream, + committed PMC traffic
@@ -48,10 +50,15 @@ def parse():
     ap.add_argument("--res", type=int, default=512, help="image resolution of the headline (512 = BASELINE config 2)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps run with the HIP-event GEMM bracket")
     ap.add_argument("--batch-edits", type=int, default=8, help="K edits of one image per U-Net batch (config 3 / 4); 0 = skip")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="concurrent edit lanes per GPU for the edits.concurrent record (engine arenas + streams on one copy of "
+                         "the weights; never the single-edit headline); <= 1 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", dest="phases", action="store_false", help="skip inversion / initial inference / whole-edit timing")
     ap.add_argument("--no-res768", dest="res768", action="store_false", help="skip the 768x768 bf16 record (config 5)")
     ap.add_argument("--no-time-edit", dest="phases", action="store_false", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-timeout", type=float, default=3600.0,
+                    help="--gpus N launcher: seconds after which still-running ranks are killed and the job returns 124 (0 = no limit)")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="print the per-rank environment / command the N-rank launcher would start (one JSON line) and exit")
     return ap.parse_args()
@@ -68,38 +75,56 @@ def rank_environments(n, port, base=None):
     return envs
 
 
-def launch_ranks(args, argv, script=None):
+def launch_ranks(args, argv, script=None, plan=None):
     """`python bench.py --gpus N` without a launcher in front (RANK unset): start N copies of this script, one rank per GPU
     (the reference's own multi-GPU shape is one process per device too, webapp/start_webapps_in_tmux.sh:21-43).  The parent
     never touches the GPU - no torch.cuda call, no library load - and nothing is exec'd: children are ordinary
     subprocesses, rank 0's stdout (the one JSON line) passes through, the worst child return code is returned."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     cmd = [sys.executable, os.path.abspath(script or __file__)] + argv
-    envs = rank_environments(args.gpus, port)
-    if args.dry_run_launch:
-        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
-        print(json.dumps({"launch": [{"cmd": cmd, "env": {k: e[k] for k in keys}} for e in envs]}))
-        return 0
-    procs = [subprocess.Popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL) for r, e in enumerate(envs)]
-    rcs = []
-    deadline = None
-    while procs:
-        for p in list(procs):
-            rc = p.poll()
-            if rc is not None:
-                procs.remove(p)
-                rcs.append(rc)
-                if rc != 0 and deadline is None:       # a rank died: the others wait at a barrier; give them a minute, then end them
-                    deadline = time.time() + 60
-        if deadline is not None and time.time() > deadline:
-            for p in procs:
-                p.kill()
-        time.sleep(0.2)
-    return max((abs(rc) for rc in rcs), default=0)
+    launch_timeout = getattr(args, "launch_timeout", 0) or 0
+    # the rendezvous port is found by bind / close, so another process can take it before rank 0 listens: a job whose rank 0
+    # (the rendezvous host) fails inside the first seconds is started again on a fresh port (twice at most)
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        envs = rank_environments(args.gpus, port)
+        if args.dry_run_launch:
+            keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+            print(json.dumps(dict({"launch": [{"cmd": cmd, "env": {k: e[k] for k in keys}} for e in envs],
+                                   "launch_timeout_s": launch_timeout}, **(plan or {}))))
+            return 0
+        started = time.time()
+        procs = [subprocess.Popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL) for r, e in enumerate(envs)]
+        rank0 = procs[0]
+        rank0_failed_at = None
+        rcs = []
+        deadline = started + launch_timeout if launch_timeout > 0 else None      # overall limit: a rank that hangs ends the job
+        first_failure = None
+        while procs:
+            for p in list(procs):
+                rc = p.poll()
+                if rc is not None:
+                    procs.remove(p)
+                    rcs.append(rc)
+                    if rc != 0 and p is rank0 and rank0_failed_at is None:
+                        rank0_failed_at = time.time()
+                    if rc != 0 and first_failure is None:   # a rank died: the others wait at a barrier; give them a minute, then end them
+                        first_failure = time.time()
+                        deadline = min(deadline, first_failure + 60) if deadline else first_failure + 60
+            if deadline is not None and time.time() > deadline:
+                for p in procs:
+                    p.kill()
+                if first_failure is None:
+                    rcs.append(124)                          # timed out (the value `timeout` returns)
+            time.sleep(0.2)
+        worst = max((abs(rc) for rc in rcs), default=0)
+        if worst != 0 and rank0_failed_at is not None and rank0_failed_at - started < 20 and attempt < 2:
+            continue                                         # rank 0 (the rendezvous host) died at once: most likely the port; once more on another
+        return worst
+    return worst
 
 
 def cpu_baseline():
@@ -173,6 +198,11 @@ def main():
     if "RANK" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
         argv = [a for a in sys.argv[1:] if a != "--dry-run-launch"]
         raise SystemExit(launch_ranks(args, argv))
+    # rank 0's stdout carries ONLY the one JSON line, in every backend: whatever the libraries print to fd 1 while the job runs
+    # (gloo's "[Gloo] Rank 0 is connected ..." banner, MIOpen notes) goes to stderr; the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     global torch
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -359,9 +389,33 @@ def main():
             te = max_over_ranks(time.perf_counter() - te)
             assert torch.isfinite(imgs).all()
             edits_info = {"edits_per_gpu": K, "edits_per_s": round(world * K / te, 4), "s_per_batch": round(te, 3),
+                          "concurrent_streams": 1,
                           "what": f"{K} edits of one image per GPU as one batch: re-projection of {K} transforms, 38 guided + 12 "
                                   "unguided batched steps, AutoencoderKL decode (native decoder, random weights); identity cached; MAX over ranks"}
             del imgs
+            # the same unit on concurrent lanes of ONE process: `streams` engine arenas + HIP streams on one copy of the weights,
+            # streams x K edits per GPU, every lane running batches of K (bit-identical to the one-stream batches,
+            # tests/test_loops_gpu.py::test_lanes_are_bit_identical_to_one_stream).  Its own record, never the headline.
+            S = max(1, args.streams)
+            if S > 1:
+                tfs2 = [(TRANSFORMS[(i + rank) % 8][0], Y, torch.tensor(TRANSFORMS[(i + rank) % 8][1])) for i in range(S * K)]
+                dh.transform_foreground_batch(depth, prompt, mask, bg_depth, uncond, init_noise, acts, tfs2, streams=S, batch=K)   # captures the lanes' graphs
+                barrier()
+                tc = time.perf_counter()
+                imgs2, _ = dh.transform_foreground_batch(depth, prompt, mask, bg_depth, uncond, init_noise, acts, tfs2, streams=S, batch=K)
+                barrier()
+                tc = max_over_ranks(time.perf_counter() - tc)
+                assert torch.isfinite(imgs2).all()
+                lanes = gd.lanes(S)
+                edits_info["concurrent"] = {
+                    "concurrent_streams": S, "edits_per_gpu": S * K, "batch_per_stream": K,
+                    "edits_per_s": round(world * S * K / tc, 4), "s_total": round(tc, 3),
+                    "hbm_weights_bytes": int(gd.unet.weight_bytes()), "hbm_weights_copies": 1,
+                    "hbm_arena_bytes_per_lane": int(lanes[-1].unet.workspace_bytes()),
+                    "what": f"{S} lanes in one process per GPU (GuidedStableDiffuser.fork: private activation / gradient arenas, hipGraphs "
+                            f"and stream per lane; U-Net weights resident once), {S * K} edits per GPU as {S} concurrent batches of {K}; "
+                            "images bit-identical to the one-stream batches; MAX over ranks"}
+                del imgs2
 
     if K > 1:
         if world > 1:
@@ -483,7 +537,8 @@ def main():
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu, "phases": phases, "batched_edits": batch_info,
             "edits": edits_info, "res768_bf16": res768,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

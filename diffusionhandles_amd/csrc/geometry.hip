@@ -449,7 +449,13 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
 // are per-workgroup partials written before the seam and added by everyone in workgroup order afterwards: identical in every
 // workgroup (the convergence test must agree: it decides whether the next seam is entered) and deterministic.
 constexpr int CGM_WGS = 16, CGM_EPT = 4;       // unknowns per thread <= 4: n <= 16 * 4 * 1024 (8 registers of A p; 8 x 8 spilled)
-struct CgSync { unsigned arrive; unsigned pad[31]; double red[2][CGM_WGS]; };
+struct CgSync { unsigned arrive; unsigned fail; unsigned pad[30]; double red[2][CGM_WGS]; };
+// Forward progress of the seams needs the CGM_WGS workgroups of a system co-resident.  In-order dispatch gives that on an
+// otherwise idle chip (a system's workgroups are consecutive blocks, and the chip holds >= 256 of them), but nothing enforces
+// it: CU masks, other streams or processes holding the slots.  So every spin is BOUNDED: after CG_SPIN_CAP polls (seconds; a
+// normal seam waits microseconds) the poller raises `fail`, every workgroup of the system leaves at its next seam, and the
+// iteration count comes back as -1, which the host turns into an error instead of a hung GPU (advisor, round 3).
+constexpr unsigned CG_SPIN_CAP = 1u << 21;
 typedef __attribute__((address_space(1))) unsigned cg_gu32;
 // FENCED: the payload went through plain stores (release: L2 write-back) and is read with plain loads (acquire: stale lines
 // dropped).  Otherwise everything shared was stored write-through and is loaded past the caches (agent-scope relaxed atomics on
@@ -461,18 +467,29 @@ __device__ __forceinline__ void cg_put(double* p, double v) {
 __device__ __forceinline__ double cg_get(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load((cg_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// returns false when the system has failed (a bounded spin ran out here or in another workgroup): the caller leaves the kernel
 template <bool FENCED>
-__device__ __forceinline__ void cg_seam(CgSync* s, unsigned epoch) {
+__device__ __forceinline__ bool cg_seam(CgSync* s, unsigned epoch) {
+  __shared__ unsigned seam_ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     if (FENCED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cg_gu32* ctr = (cg_gu32*)&s->arrive;
+    cg_gu32* fail = (cg_gu32*)&s->fail;
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * CGM_WGS) __builtin_amdgcn_s_sleep(1);
+    unsigned spins = 0, ok = 1;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * CGM_WGS) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+      if (spins > CG_SPIN_CAP) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+    }
+    if (ok && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
     if (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    seam_ok = ok;
   }
   __syncthreads();
+  return seam_ok != 0;
 }
 __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, const uint8_t* inpaint, const int* unk,
                                                         const int* counts, int count_stride, int slot_n, int slot_it, double* vx,
@@ -497,7 +514,8 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
   const int per = (n + CGM_WGS - 1) / CGM_WGS, i0 = wg * per, i1 = i0 + per < n ? i0 + per : n;
   unsigned epoch = 0;
   for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) map[U[i]] = i;
-  cg_seam<true>(sy, ++epoch);                                        // every workgroup's part of the pixel -> unknown map (plain stores / loads)
+  bool alive = cg_seam<true>(sy, ++epoch);                           // every workgroup's part of the pixel -> unknown map (plain stores / loads)
+  if (!alive) { if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = -1; return; }
   double part = 0.0;
   for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) {
     const int pix = U[i], y = pix / res, xx = pix - y * res;
@@ -517,7 +535,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
     v = block_sum(v, sm);
     if (threadIdx.x == 0) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)&sy->red[slot][wg],
                                               (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cg_seam<false>(sy, ++epoch);
+    if (!cg_seam<false>(sy, ++epoch)) alive = false;
     double t = 0.0;
     for (int k = 0; k < CGM_WGS; ++k)
       t += __longlong_as_double((long long)__hip_atomic_load((__attribute__((address_space(1))) unsigned long long*)&sy->red[slot][k],
@@ -525,6 +543,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
     return t;
   };
   double rs = all_sum(part, 0);
+  if (!alive) { if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = -1; return; }
   const double bnorm = rs;
   double beta = 0.0;
   int cur = 0, it = 0;
@@ -552,6 +571,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
       }
     }
     const double pq = all_sum(part, 1);          // (slots alternate: a workgroup still adding slot 0 cannot be overtaken by the next write to it)
+    if (!alive) break;
     const double alpha = rs / pq;
     part = 0.0;
 #pragma unroll
@@ -565,10 +585,12 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
       }
     }
     const double rsn = all_sum(part, 0);
+    if (!alive) break;
     beta = rsn / rs;
     rs = rsn;
     cur ^= 1;
   }
+  if (!alive) { if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = -1; return; }     // (every workgroup of the system agrees: the flag is sticky)
   for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) d[U[i]] = (float)x[i];
   if (threadIdx.x == 0 && wg == 0) counts_out[e * count_stride + slot_it] = it;
 }

@@ -104,6 +104,9 @@ __global__ void k_adam_scaled(float* p, const float* g, float* m, float* v, floa
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float gi = g[i] / g_scale[0];
+  // an overflowed 16-bit backward pass (inf / NaN in the text gradient) must not poison the embedding for every later
+  // timestep: such an element keeps its parameter and moments for this step
+  if (!isfinite(gi)) return;
   float mi = m[i] + (1.f - b1) * (gi - m[i]);
   float vi = b2 * v[i] + (1.f - b2) * gi * gi;
   m[i] = mi;

@@ -607,6 +607,7 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
   DH_REQUIRE((long)cfg->max_batch * cfg->sample_size * cfg->sample_size < (1L << 21), "max_batch * sample_size^2 must stay below 2^21 rows");
   DH_REQUIRE(cfg->norm_groups >= 1 && cfg->norm_groups <= 32, "1..32 GroupNorm groups");
   DH_REQUIRE(cfg->in_channels <= 8 && cfg->out_channels <= 8, "in/out channels must be <= 8");
+  DH_REQUIRE(cfg->block_out_channels[0] <= 2048, "block_out_channels[0] must be <= 2048 (few-channel convolutions)");
   DH_REQUIRE(cfg->cross_attention_dim % 64 == 0, "cross_attention_dim must be a multiple of 64");
   for (int i = 0; i < 4; ++i) {
     DH_REQUIRE(cfg->block_out_channels[i] % 64 == 0, "block_out_channels must be multiples of 64");

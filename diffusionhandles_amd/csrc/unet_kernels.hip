@@ -116,6 +116,14 @@ __global__ void __launch_bounds__(256) k_conv_few_out(const T* x, const float* w
   }
 }
 static inline unsigned conv_few_out_blocks(int pixels, int Ci) { return (unsigned)cdiv(pixels, 256 / (Ci >> 3)); }
+// k_conv_few_out's shape limits (advisor, round 3): 16-byte channel chunks, 256 / (Ci / 8) >= 1 pixels per block and
+// pixels-per-block x Co <= 256 reducing threads.  The engines' create calls enforce them (dh_unet_create, dh_vae_*_create);
+// a call outside them is refused here instead of dividing by zero or leaving pixels unwritten.
+static inline bool conv_few_out_ok(int Ci, int Co, const void* w) {
+  const bool ok = Ci % 8 == 0 && Ci >= 64 && Ci <= 2048 && Co >= 1 && Co <= 8 && ((size_t)w & 15) == 0;
+  if (!ok) set_error("few-output convolution: needs 64 <= Cin <= 2048, Cin % 8 == 0, Cout <= 8, 16-byte aligned weights");
+  return ok;
+}
 
 void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* w, const float* bias, void* y,
                            int y_is_f32, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
@@ -125,6 +133,7 @@ void launch_conv_small_fwd(int dtype, const void* x, int x_is_f32, const float* 
     else
       hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)x, w, bias, (bf16*)y, B, H, W, Cin, Cout);
   } else {
+    if (!conv_few_out_ok(Cin, Cout, w)) return;
     if (dtype == DH_DTYPE_F16)
       hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(conv_few_out_blocks(B * H * W, Cin)), dim3(256), 0, st, (const f16*)x, w, bias, (float*)y, B, H, W, Cin, Cout, 0);
     else
@@ -142,6 +151,7 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
     else
       hipLaunchKernelGGL((k_conv_few_in<bf16>), dim3(cdiv(B * H * W, CF_PIX)), dim3(256), 0, st, (const float*)dy, w, (const float*)nullptr, (bf16*)dx, B, H, W, Cin, Cout);
   } else {
+    if (!conv_few_out_ok(Cin, Cout, w)) return;
     if (dtype == DH_DTYPE_F16)
       hipLaunchKernelGGL((k_conv_few_out<f16>), dim3(conv_few_out_blocks(B * H * W, Cin)), dim3(256), 0, st, (const f16*)dy, w, (const float*)nullptr, (float*)dx, B, H, W, Cin, Cout, accumulate);
     else

@@ -154,6 +154,7 @@ def reproject_edits(depth, bg_depth, fg_mask, intrinsics, transforms, use_input_
         _lib.ptr(zmap), _lib.ptr(raw), _lib.ptr(clean), _lib.ptr(disp), _lib.ptr(vis), _lib.ptr(txy),
         _lib.ptr(corr), _lib.ptr(counts), _lib.ptr(ws), nbytes.value, st), "dh_reproject_edits")
     counts_h = counts.cpu()
+    _check_infill(counts_h[:, 3])
     out = []
     for e in range(K):
         n = int(counts_h[e, 0])
@@ -163,6 +164,14 @@ def reproject_edits(depth, bg_depth, fg_mask, intrinsics, transforms, use_input_
                    fg_pix=fg_pix[:n_fg], corr_dev=corr)
         return out, dbg
     return out
+
+
+def _check_infill(iterations):
+    """counts[..., 3] = CG iterations of the harmonic in-fill; -1 = the multi-workgroup solver's bounded grid barrier ran out
+    (its workgroups were not co-resident: CU masks, another process holding the chip) -- an error, never a hang."""
+    if bool((iterations < 0).any()):
+        raise RuntimeError("harmonic in-fill: the multi-workgroup CG's grid barrier timed out (workgroups not co-resident); "
+                           "the result is not valid")
 
 
 def transform_depth_pc(depth, bg_depth, fg_mask, intrinsics, rot_angle=None, rot_axis=None, translation=None,
@@ -290,4 +299,5 @@ def laplacian_depth_blend(depth, bg_depth, fg_mask, dilate_iterations=15):
     ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     _lib.check(L.dh_laplacian_blend(_lib.ptr(d), _lib.ptr(bg), _lib.ptr(m), res, int(dilate_iterations), _lib.ptr(out),
                                     _lib.ptr(counts), _lib.ptr(ws), nbytes.value, _lib.stream_ptr()), "dh_laplacian_blend")
+    _check_infill(counts[3:4].cpu())
     return out[None, None].to(out_dev)

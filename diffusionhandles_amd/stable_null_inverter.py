@@ -20,11 +20,14 @@ class StableNullInverter(NullInverter):
         self.guidance_scale = guidance_scale
         self.model.scheduler.set_timesteps(self.num_ddim_steps)
         # the eps cotangent is ~1e-6 and shrinks as the optimisation converges: every inner step scales it by the power of
-        # two that brings its largest element to (128, 256] before the 16-bit backward pass and divides the text gradient
+        # two that brings its largest element to (8, 16] before the 16-bit backward pass and divides the text gradient
         # by the same factor (dh_mse_cotangent / dh_adam_step_scaled; the backward is linear, the factor cancels exactly).
         # Measured at the full SD-2-depth size (tools/probe_text_grad.py): fp16 text-gradient error 2.4e-3 for
         # max |cotangent| in [1, 4096], 1.9e-2 at 2^-4, 9e-2 at 2^-8 (fp16 subnormals); bf16 2.2e-2 at any amplitude.
-        self.cotangent_amp = 256.0
+        # 16 sits at the low end of that plateau: the accuracy of 256 with four more bits of fp16 overflow headroom for the
+        # intermediate gradients (advisor, round 3); a gradient element that overflows anyway is skipped by the Adam kernel
+        # (k_adam_scaled) instead of poisoning the embedding.
+        self.cotangent_amp = 16.0
 
     def to(self, device):
         self.model.to(device)

@@ -254,6 +254,31 @@ def test_set_foreground_laplacian_blend_vs_oracle():
     assert torch.equal(out.cpu()[0, 0][~torch.from_numpy(m)], depth[0, 0][~torch.from_numpy(m)])
 
 
+@pytest.mark.parametrize("side,path", [(60, "on-chip (<= 8192 unknowns)"), (150, "16 workgroups (<= 65536)"),
+                                       (290, "single workgroup in global memory (> 65536)")])
+def test_laplacian_blend_every_cg_kernel_vs_oracle(side, path):
+    """The three CG kernels behind the harmonic in-fill / set_foreground (k_cg_fill_lds, k_cg_fill_multi with its bounded
+    grid barrier, k_cg_fill: the fallback nothing else in the suite reaches, advisor round 3) on square holes sized for each,
+    res 512, against the oracle's sparse direct solve of the same system (utils.solve_laplacian_depth, pinned by g9)."""
+    from oracle import depth_ref as D
+    from diffusionhandles_amd import depth_transform as DT
+    res = 512
+    depth, bg, _ = make_scene(res)
+    bg = bg + 0.05 * torch.sin(torch.arange(res, dtype=torch.float32) / 9.0)[None, None, None, :]
+    mask = torch.zeros(1, 1, res, res, dtype=torch.bool)
+    a = (res - side) // 2
+    mask[0, 0, a:a + side, a:a + side] = True
+    import scipy.ndimage
+    n_unknown = int(scipy.ndimage.binary_dilation(mask[0, 0].numpy(), iterations=15).sum())
+    lo, hi = {60: (0, 8192), 150: (8193, 65536), 290: (65537, res * res)}[side]
+    assert lo <= n_unknown <= hi, (n_unknown, path)
+    out = DT.laplacian_depth_blend(depth.to(_dev()), bg.to(_dev()), mask.to(_dev()))
+    ref = D.set_foreground(depth, mask, bg)
+    err = float((out.cpu() - ref).abs().max())
+    print(f"laplacian blend, {n_unknown} unknowns, {path}: max abs err {err:.2e}")
+    assert err < 2e-4, (path, err)
+
+
 def test_real_scene_edits_bit_exact_vs_reference_golden(golden):
     """A scene of the reference's own test data (estimated depth, PIZ OpenEXR; tests/golden/scene_banana_fruits) with
     its three transforms (identity, 91 degrees + shift, pure translation): integer maps bit-exact against what the

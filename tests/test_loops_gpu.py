@@ -446,6 +446,43 @@ def test_batched_edits_match_single_edits(rig):
         assert err < 5e-2
 
 
+def test_lanes_are_bit_identical_to_one_stream(rig):
+    """Two concurrent edit lanes in one process (GuidedStableDiffuser.fork: private engine arenas / graphs / streams on ONE
+    copy of the weights, dh_unet_create_shared): four edits as two batches of two on two lanes, and three single (B = 1) edits on
+    two lanes (a ragged last round), give images that are bit for bit those of the one-stream calls; the shared engine holds no
+    weights of its own and refuses parameter loads."""
+    from diffusionhandles_amd import _lib
+    from diffusionhandles_amd.depth_transform import reproject_edits
+    from diffusionhandles_amd.guided_stable_diffuser import GuidedStableDiffuser
+    from diffusionhandles_amd.unet import HipUNet
+    from oracle import unet_torch as U
+    if not hasattr(rig, "acts"):
+        test_initial_inference_matches_oracle(rig)
+    hip4 = HipUNet(dict(U.TINY, text_len=77), dtype=torch.float16, max_batch=4)
+    hip4.load_state_dict(rig.ref.state_dict())
+    gd4 = GuidedStableDiffuser(rig.conf, unet=hip4, unet_config=dict(U.TINY, text_len=77)).to(dev())
+    Kint = rig.gd.get_depth_intrinsics()
+    tfs = [(TRANSFORMS[i][0], torch.tensor([0.0, 1.0, 0.0]), torch.tensor(TRANSFORMS[i][1])) for i in (2, 3, 4, 5)]
+    edits = reproject_edits(rig.depth.to(dev()), rig.bg.to(dev()), rig.mask.to(dev()), Kint, tfs, device_correspondences=True)
+    unc = rig.unc0[None].expand(50, -1, -1, -1).contiguous()
+    noise = rig.noise.to(dev())
+    chunks = [([d for d, _ in edits[i:i + 2]], [c for _, c in edits[i:i + 2]]) for i in (0, 2)]
+    one = [gd4.guided_inference_batch(noise, d, unc, rig.prompt, rig.acts, c).clone() for d, c in chunks]
+    two = gd4.guided_inference_batch_lanes(noise, chunks, unc, rig.prompt, rig.acts, streams=2)
+    torch.cuda.synchronize()
+    assert len(two) == 2 and all(torch.equal(a, b) for a, b in zip(one, two)), "batched lanes differ from the one-stream batches"
+    lanes = gd4.lanes(2)
+    assert lanes[0] is gd4 and lanes[1].unet is not gd4.unet and lanes[1].vae is gd4.vae
+    assert lanes[1].unet.weight_bytes() == 0 and lanes[1].unet.workspace_bytes() > 0 and gd4.unet.weight_bytes() > 0
+    with pytest.raises(RuntimeError):
+        p0 = torch.zeros(hip4.param_table()[0][1], device=dev())
+        _lib.check(_lib.lib().dh_unet_load_param(lanes[1].unet._h, 0, _lib.ptr(p0), _lib.stream_ptr()), "load into a shared engine")
+    singles = [gd4.guided_inference(noise, d, unc, rig.prompt, rig.acts, c).clone() for d, c in edits[:3]]
+    laned = gd4.guided_inference_lanes(noise, edits[:3], unc, rig.prompt, rig.acts, streams=2)
+    torch.cuda.synchronize()
+    assert len(laned) == 3 and all(torch.equal(a, b) for a, b in zip(singles, laned)), "single-edit lanes differ"
+
+
 def test_guided_inference_is_bit_deterministic(rig):
     """No float atomics anywhere on the path (split-K slabs in slice order, integer sign sums, fixed-tree GroupNorm /
     attention merges): two runs of the whole 50-step guided loop give identical latents, bit for bit."""

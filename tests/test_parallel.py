@@ -177,3 +177,54 @@ def test_sharded_edit_driver_launch_plan():
     plan = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
     assert [p["env"]["RANK"] for p in plan] == [str(r) for r in range(8)]
     assert all(p["env"]["WORLD_SIZE"] == "8" and p["cmd"][1].endswith("run_edits_sharded.py") and "--edits" in p["cmd"] for p in plan)
+
+
+def test_config4_edit_plan_is_eight_batches_of_eight():
+    """BASELINE config 4 (64 edits, 8 per GPU): `run_edits_sharded.py --gpus 8 --edits 64 --batch 8 --dry-run-launch` prints, next
+    to the launch plan, which edits every rank runs and in which batches -- 8 ranks x ONE batch of 8, every edit exactly once,
+    the round-robin split of parallel.shard_edits; with --streams 2 --batch 4 every rank runs two batches of 4 on two lanes."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    tool = os.path.join(ROOT, "tools", "run_edits_sharded.py")
+    out = subprocess.run([sys.executable, tool, "--gpus", "8", "--edits", "64", "--batch", "8", "--dry-run-launch"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert len(out.stdout.strip().splitlines()) == 1, "stdout must carry the one JSON line only"
+    rep = json.loads(out.stdout)
+    assert len(rep["launch"]) == 8 and rep["launch_timeout_s"] > 0
+    plan = rep["plan"]
+    assert [p["rank"] for p in plan] == list(range(8))
+    assert all(len(p["batches"]) == 1 and len(p["batches"][0]["edits"]) == 8 and p["batches"][0]["lane"] == 0 for p in plan)
+    assert sorted(e for p in plan for e in p["edits"]) == list(range(64))
+    assert plan[3]["edits"] == [3 + 8 * i for i in range(8)]
+    out = subprocess.run([sys.executable, tool, "--gpus", "8", "--edits", "64", "--batch", "4", "--streams", "2",
+                          "--dry-run-launch"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    plan = json.loads(out.stdout)["plan"]
+    assert all([b["lane"] for b in p["batches"]] == [0, 1] and [len(b["edits"]) for b in p["batches"]] == [4, 4] for p in plan)
+    assert "--streams" in json.loads(out.stdout)["launch"][0]["cmd"]
+
+
+def test_run_edits_with_streams_hands_the_whole_share_to_the_lanes():
+    """parallel.run_edits(streams > 1) passes the rank's whole share to ONE transform_foreground_batch call with streams / batch
+    (the lanes cut it into chunks of `batch`), and restores the global indices."""
+    import torch
+    from diffusionhandles_amd import parallel
+    calls = []
+
+    class FakeDH:
+        def transform_foreground_batch(self, depth, prompt, fg_mask, bg_depth, null_text, noise, acts, tfs, streams=1, batch=None):
+            calls.append((len(tfs), streams, batch))
+            return torch.stack([torch.full((3, 2, 2), float(t[0])) for t in tfs]), [torch.full((1, 1, 2, 2), float(t[0])) for t in tfs]
+
+    edits = [dict(rot_angle=float(i), rot_axis=None, translation=None) for i in range(10)]
+    old = dict(os.environ)
+    try:
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = "1", "2"
+        res = parallel.run_edits(FakeDH(), (None, None, None), edits, None, None, None, "p", batch=2, streams=2)
+    finally:
+        os.environ.clear()
+        os.environ.update(old)
+    assert calls == [(5, 2, 2)]
+    assert [gi for gi, _, _ in res] == [1, 3, 5, 7, 9] and all(float(im[0, 0, 0]) == gi for gi, im, _ in res)

@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+set -eu
+cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out/b8 gpurun_out/l96
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/b8 -- python3 tools/time_unet.py 8 > gpurun_out/b8/log.txt 2>&1

@@ -41,6 +41,20 @@ def make_transforms(n):
     return out
 
 
+def edit_plan(n_edits, world, batch, streams):
+    """Which edits every rank runs, in which batches, on which lane: exactly what parallel.run_edits does with
+    parallel.shard_edits (round-robin over ranks, then chunks of `batch` in order, chunk i on lane i % streams).  Pure
+    arithmetic: the --dry-run-launch output and its CPU test (config 4: 64 edits on 8 GPUs = 8 x one batch of 8)."""
+    from diffusionhandles_amd import parallel
+    plan = []
+    for r in range(world):
+        mine = parallel.shard_edits(list(range(n_edits)), r, world)
+        b = max(1, batch)
+        chunks = [mine[i:i + b] for i in range(0, len(mine), b)]
+        plan.append({"rank": r, "edits": mine, "batches": [{"lane": i % max(1, streams), "edits": c} for i, c in enumerate(chunks)]})
+    return plan
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--edits", type=int, default=64)
@@ -51,8 +65,14 @@ def main():
     ap.add_argument("--invert", action="store_true", help="null-text inversion of the input image for the identity")
     ap.add_argument("--recompute-identity", action="store_true", help="every rank computes the identity (no broadcast)")
     ap.add_argument("--no-images", action="store_true", help="do not write PNGs (timing runs)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="concurrent edit lanes per GPU process (engine arenas + streams on one copy of the weights): a rank's "
+                         "batches of --batch edits run on this many lanes; images are bit-identical to --streams 1")
     ap.add_argument("--gpus", type=int, default=1, help="without a launcher in front (RANK unset): start this many ranks")
-    ap.add_argument("--dry-run-launch", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-timeout", type=float, default=7200.0, help="--gpus N launcher: kill still-running ranks after this many seconds")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="print the launch plan (per-rank environment) and the edit plan (which edits, in which batches, on which "
+                         "lane, on every rank) as one JSON line and exit")
     args = ap.parse_args()
     if "RANK" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
         # one process per GPU, started before anything here touches the GPU (the same launcher as bench.py)
@@ -62,7 +82,7 @@ def main():
         bench = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(bench)
         argv = [a for a in sys.argv[1:] if a != "--dry-run-launch"]
-        raise SystemExit(bench.launch_ranks(args, argv, script=__file__))
+        raise SystemExit(bench.launch_ranks(args, argv, script=__file__, plan={"plan": edit_plan(args.edits, args.gpus, args.batch, args.streams)}))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -112,7 +132,7 @@ def main():
     t_identity = time.perf_counter() - t0
     # ---- the edits: this rank's share, `batch` at a time ------------------------------------------------------------
     t0 = time.perf_counter()
-    local = parallel.run_edits(dh, identity, edits, depth, mask, bg_depth, prompt, batch=args.batch)
+    local = parallel.run_edits(dh, identity, edits, depth, mask, bg_depth, prompt, batch=args.batch, streams=args.streams)
     barrier()
     t_edits = time.perf_counter() - t0
     if world > 1:
@@ -128,6 +148,7 @@ def main():
                 write_png(os.path.join(args.out, f"{edits[gi]['name']}.png"), (im.permute(1, 2, 0).clamp(0, 1) * 255).round().byte().numpy())
                 write_png(os.path.join(args.out, f"{edits[gi]['name']}_disparity.png"), dp[0, 0].clamp(0, 255).round().byte().numpy())
         rep = {"edits": len(edits), "n_gpus": world, "edits_per_gpu": -(-len(edits) // world), "batch": args.batch,
+               "concurrent_streams": args.streams,
                "resolution": args.res, "identity_s": round(t_identity, 3), "identity": ("inversion + " if args.invert else "") +
                "initial inference on " + ("every rank" if args.recompute_identity else "rank 0, broadcast"),
                "edits_s": round(t_edits, 3), "edits_per_s": round(len(edits) / t_edits, 4),
