@@ -51,7 +51,7 @@ __device__ __forceinline__ v16f zero16() {
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #ifndef DH_ATTN_ABL
-#define DH_ATTN_ABL 0      // timing-only ablations of the forward loop (tools/attn_ablate.sh): never set in the product build
+#define DH_ATTN_ABL 0      // timing-only ablations of the forward loop (tools/lab.sh ablate-attn): never set in the product build
 #endif
 
 // 4 register fragments (k = d) of row `row` of a [rows][ld] matrix at column col0: B-operand layout

@@ -85,7 +85,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
 };
 
 constexpr int BK = 64;
-// experiment switches (tools/build_tuning.sh DH_DEFS=...): never defined in the product build
+// experiment switches (tools/lab.sh build-tuning DH_DEFS=...): never defined in the product build
 #ifdef DH_EXP_SETPRIO
 #define DH_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -1004,7 +1004,7 @@ static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK
 #undef DH_GEMM_LAUNCH
 
 // Tile / split-K policy.  The constants are the round-1/2 bench.py A/B winners; a tuning build (-DDH_TUNING,
-// tools/build_tuning.sh) reads them from the environment instead, the product library carries no knobs.
+// tools/lab.sh build-tuning) reads them from the environment instead, the product library carries no knobs.
 #ifdef DH_TUNING
 #define DH_KNOB(name, env, dflt) static const int name = getenv(env) ? atoi(getenv(env)) : (dflt)
 #else

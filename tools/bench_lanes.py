@@ -38,7 +38,10 @@ def tfs(n):
 print("weights GB", gd.unet.weight_bytes() / 1e9, "workspace GB (max_batch 16)", gd.unet.workspace_bytes() / 1e9, flush=True)
 # whole edits: (edits, batch, streams)
 ref = {}
-for n, batch, streams in ((8, 8, 1), (8, 4, 1), (8, 4, 2), (16, 8, 1), (16, 8, 2), (8, 2, 2), (8, 1, 2), (8, 1, 1), (12, 4, 3)):
+CASES = ((8, 8, 1), (8, 4, 1), (8, 4, 2), (16, 8, 1), (16, 8, 2), (8, 2, 2), (8, 1, 2), (8, 1, 1), (12, 4, 3))
+if os.environ.get("DH_LANES_CASES") == "wide":      # more lanes of full batches
+    CASES = ((24, 8, 1), (24, 8, 3), (32, 8, 1), (32, 8, 4), (16, 8, 2))
+for n, batch, streams in CASES:
     with torch.no_grad():
         dh.transform_foreground_batch(depth, prompt, mask, bg_depth, uncond, init_noise, acts, tfs(min(n, 2 * batch)), streams=streams, batch=batch)
         torch.cuda.synchronize()
@@ -59,7 +62,7 @@ for n, batch, streams in ((8, 8, 1), (8, 4, 1), (8, 4, 2), (16, 8, 1), (16, 8, 2
 # guided steps/s of single edits on 1..3 lanes
 disp_e, corr = transform_depth(depth, bg_depth, mask, gd.get_depth_intrinsics(), rot_angle=TRANSFORMS[2][0], rot_axis=Y,
                                translation=torch.tensor(TRANSFORMS[2][1]))
-for nl in (1, 2, 3):
+for nl in ((1, 2, 3, 4) if os.environ.get("DH_LANES_CASES") == "wide" else (1, 2, 3)):
     lanes = gd.lanes(nl)
     x0 = init_noise.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous()
     with torch.no_grad():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE / WRITE_SIZE per launch of the k_gemm_dma kernels from the two tools/pmc_passes.sh passes
+"""FETCH_SIZE / WRITE_SIZE per launch of the k_gemm_dma kernels from the two tools/lab.sh pmc-traffic passes
 (gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}.tsv: kernel name, launches, counter sum in KiB) -> profiles-style JSON."""
 import json
 import sys
@@ -24,5 +24,5 @@ print(json.dumps({
     "launches": int(launches), "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w,
     "fetch_correction": "x2 (gfx950 FETCH_SIZE under-count, MI355X_MICROARCH.md HBM section)",
     "traffic_bytes_per_launch": (2 * f + w) * 1024,
-    "command": "tools/pmc_passes.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/time_unet.py 1 ; "
+    "command": "tools/lab.sh pmc-traffic: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/time_unet.py 1 ; "
                "same with --pmc WRITE_SIZE (separate passes); tools/pmc_summarise.py gpurun_out/pmc"}, indent=1))
