@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--res", type=int, default=512, help="image resolution of the headline (512 = BASELINE config 2)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps run with the HIP-event GEMM bracket")
     ap.add_argument("--batch-edits", type=int, default=8, help="K edits of one image per U-Net batch (config 3 / 4); 0 = skip")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="concurrent edit lanes per GPU for the edits.concurrent record (engine arenas + streams on one copy of "
                          "the weights; never the single-edit headline); <= 1 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")

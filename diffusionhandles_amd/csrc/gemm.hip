@@ -1136,7 +1136,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
   // x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge; 64x64 tiles: no K grouping wins in situ)
   else if (BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k);
+#ifdef DH_EXP_N320_MW2
+  else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 2>(gm, lnf, grid, st, k);      // experiment: eight waves (32 x 160 outputs each) halve the DMA pieces a wave issues per tile
+#else
   else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 1>(gm, lnf, grid, st, k);
+#endif
   else if (BM == 64) launch_tile<T, 64, 64, 4, 1, 1, 1>(gm, lnf, grid, st, k, glu);      // (rings of 6 / 8 stages: pass 2 % SLOWER; round 3, eight stages only on the <= 256-workgroup long-K launches: guided step -1.1 %)
   else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) launch_tile<T, 128, 128, 2, 1, 1, 1>(gm, lnf, grid, st, k);   // 64 KiB: two workgroups per CU
   else if (BN == 128) launch_tile<T, 128, 128, 4, 1, 1, 1>(gm, lnf, grid, st, k);
