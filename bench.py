@@ -334,12 +334,14 @@ def main():
                 one_step()
             ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
             _lib.check(L.dh_gemm_profile_end(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+            alg = ctypes.c_double()
+            _lib.check(L.dh_gemm_profile_bytes(ctypes.byref(alg)))
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         # HBM traffic per k_gemm launch: PMC counters cannot be read from inside the process, so this is the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, gfx950 x2 fetch
         # correction) of the same U-Net fwd+bwd launch mix; null when the workload differs from the measured one.
         traffic = None
-        for name in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+        for name in ("r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.res == 512 and args.dtype == "fp16":
                 with open(pmc) as fh:
@@ -349,6 +351,10 @@ def main():
         roof = {"bound": "mfma", "kernel": "k_gemm_dma (MFMA implicit GEMM: conv3x3 + linear, fwd + input-gradient)",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "bytes/launch (offline PMC)", "launches_per_step": int(n.value // max(1, args.profile_steps)),
+                "algorithmic_bytes_per_launch": round(alg.value / max(1, n.value)),
+                "traffic_over_algorithmic": round(traffic / (alg.value / max(1, n.value)), 2) if traffic and alg.value > 0 else None,
+                "algorithmic_bytes_note": "every operand once in 16-bit storage (A source, W, output, residual; include/diffhandles_hip.h "
+                                          "dh_gemm_profile_bytes), live over the profiled guided steps; traffic = PMC of the U-Net fwd+bwd launch mix",
                 "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
                 "flops_per_launch": round(fl.value / max(1, n.value) / 1e9, 3),
                 "step_tflop_algorithmic": step_tf,

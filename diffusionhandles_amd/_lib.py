@@ -96,6 +96,7 @@ SIGNATURES = {
     "dh_text_encoder_encode": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "dh_gemm_profile_begin": (c_i, []),
     "dh_gemm_profile_end": (c_i, [ctypes.POINTER(c_d), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(c_d)]),
+    "dh_gemm_profile_bytes": (c_i, [ctypes.POINTER(c_d)]),
     "dh_ddim_cfg_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_p]),
     "dh_latent_update": (c_i, [c_p, c_p, c_p, c_f, c_f, c_i, c_p]),
     "dh_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_p]),

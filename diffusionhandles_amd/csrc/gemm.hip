@@ -31,6 +31,7 @@ struct GemmProf {
   std::vector<hipEvent_t> ev;
   size_t used = 0;
   double flops = 0;
+  double bytes = 0;                           // algorithmic HBM bytes of the bracketed launches (see dh_gemm_profile_bytes)
   hipEvent_t e0 = nullptr, e1 = nullptr;      // start / stop events of the launch being issued (hipExtLaunchKernelGGL)
 };
 static GemmProf g_prof;
@@ -390,15 +391,18 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   // so the counted vmcnt waits below can only become stricter)
   constexpr bool PRE = TM * TN <= 8;               // the prefetched tiles cost 8 registers per 32x32 output tile
   const bool pre_r = PRE && p.R != nullptr && p.pre_r && p.splits == 1 && (WG == 1 || grp == 0) && (KG == 1 || kg == 0);
-  const bool pre_b = PRE && p.bias != nullptr && p.pre_r && p.splits == 1;
-  float4 bpre[TN][4];
+  // (the eight-wave 128x320 tile holds five column blocks per wave: 80 registers of prefetched bias would push it over the
+  //  256-register budget of two waves per SIMD; its bias is read in the epilogue, a warm 1.3 KB vector)
+  constexpr bool PRE_B = PRE && !(MW == 2 && BN == 320);
+  const bool pre_b = PRE_B && p.bias != nullptr && p.pre_r && p.splits == 1;
+  float4 bpre[PRE_B ? TN : 1][4];
   if (pre_b) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
-        bpre[j][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bpre[PRE_B ? j : 0][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
   // folded LayerNorm: the per-column vectors are fetched under the K loop as well (their loads were the exposed tail)
@@ -604,7 +608,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         for (int g = 0; g < 4; ++g) {
           float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
           if (hb) {
-            float4 b = bpre[j][g];
+            float4 b = bpre[PRE_B ? j : 0][g];
             if (!pre_b) b = *reinterpret_cast<const float4*>(p.bias + nb + 8 * g + 4 * hi);
             v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
           }
@@ -716,7 +720,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
-          if (hb) { v0 += bpre[j][g].x; v1 += bpre[j][g].y; v2 += bpre[j][g].z; v3 += bpre[j][g].w; }
+          if (hb) {
+            float4 b = bpre[PRE_B ? j : 0][g];
+            if (!PRE_B) b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi);
+            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+          }
           if (hr) {
             const T4 rv = __builtin_bit_cast(T4, rpre[i][j][g]);
             v0 += to_f32<T>(rv[0]); v1 += to_f32<T>(rv[1]); v2 += to_f32<T>(rv[2]); v3 += to_f32<T>(rv[3]);
@@ -752,7 +760,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           w[g] = epilogue_pack<T>(p, m, nb + 8 * g + 4 * hi, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
-                                  acc[i][j][4 * g + 3], pre_r, rpre[i][j][g], pre_b, bpre[j][g]);
+                                  acc[i][j][4 * g + 3], pre_r, rpre[i][j][g], pre_b, bpre[PRE_B ? j : 0][g]);
         const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
         T* out = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 8 * hi;
         *reinterpret_cast<uint4*>(out) = ca;
@@ -781,7 +789,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
           *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = o;
         } else {
           epilogue_store<T>(p, m, n, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], pre_r,
-                            rpre[i][j][g], pre_b, bpre[j][g]);
+                            rpre[i][j][g], pre_b, bpre[PRE_B ? j : 0][g]);
         }
       }
   }
@@ -991,7 +999,7 @@ static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK
     if (glu == 2) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 2>)); return; }
   }
   if (gm == GM_DENSE) {
-    if constexpr (WG == 1) {
+    if constexpr (WG == 1 && BN != 320) {      // (the 128x320 tile is never asked for the folded LayerNorm: large batches run it as a kernel)
       if (lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true>)); return; }
     }
     DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW>));
@@ -1035,7 +1043,9 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   if (k.M <= 64 || (cdiv(k.M, 128) * cdiv(k.N, BN) < kBigTiles && ktiles < kSplitMinK)) { BM = 64; BN = 64; }
   // N = 320 (the 64x64-latent convolutions and linears) with enough rows to fill the chip: one 128x320 tile per 128 rows,
   // so the A tile is staged once instead of five times (batched edits; a single image has only 32 such tiles)
-  const bool n320 = kN320 > 0 && k.N == 320 && BM == 128 && BN == 64 && cdiv(k.M, 128) >= kN320;
+  // (also N = 640 / 960 -- the fused q|k|v projection of the 64x64-latent level -- as two / three such column tiles: the A tile is
+  //  staged three times instead of fifteen)
+  const bool n320 = kN320 > 0 && k.N % 320 == 0 && k.N <= 960 && !lnf && BM == 128 && BN == 64 && cdiv(k.M, 128) >= kN320;
   if (n320) BN = 320;
   // grids that fill the machine: 256x128 tiles, eight waves (see MW)
   // (not when M <= 256 leaves a single row of 256-row tiles on fewer than half of the CUs: two rows of 128x128 eight-wave
@@ -1108,6 +1118,15 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
     e0 = g_prof.ev[g_prof.used++];
     e1 = g_prof.ev[g_prof.used++];
     g_prof.flops += 2.0 * (double)k.M * (double)k.N * (double)k.K;
+    // every operand once, in its storage type: the A source (dense rows; for a convolution the source image, not its im2col
+    // view), the weights, the output (the GEGLU forms: what they read and write instead), the residual
+    const double esz = 2.0;
+    double a_elems = (double)k.M * k.K;
+    if (k.mode != A_DENSE && k.Hout > 0 && k.Wout > 0) a_elems = (double)k.M / ((double)k.Hout * k.Wout) * k.Hin * k.Win * k.Cin;
+    double c_elems = (double)k.M * k.N * (k.C ? 1.0 : 0.0) + (k.R ? (double)k.M * k.N : 0.0);
+    if (k.glu_y) c_elems += 0.5 * (double)k.M * k.N;
+    if (k.glub_x) c_elems += 4.0 * (double)k.M * k.N;      // saved pre-activations read [M][2N], their gradient written [M][2N]
+    g_prof.bytes += esz * (a_elems + (double)k.N * k.K + c_elems);
     g_prof.e0 = e0; g_prof.e1 = e1;
   }
   int gm = GM_GENERIC;
@@ -1136,11 +1155,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
   // x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge; 64x64 tiles: no K grouping wins in situ)
   else if (BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k);
-#ifdef DH_EXP_N320_MW2
-  else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 2>(gm, lnf, grid, st, k);      // experiment: eight waves (32 x 160 outputs each) halve the DMA pieces a wave issues per tile
-#else
-  else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 1>(gm, lnf, grid, st, k);
-#endif
+  // eight waves (4 x 2, 32 x 160 outputs each): the two-stage ring has one 57-KB tile in flight and its 56 one-KiB DMA pieces were
+  // issued by four waves, 14 each at 60 - 185 cycles apiece -- the issue, not the latency, bounded the tile; with seven pieces per
+  // wave: M = 32768, N = 320 dense K = 320 20.6 -> 14.9 us, K = 1280 40.1 -> 34.6 us, conv K = 2880 76.8 -> 67.3 us, batch-8
+  // forward 13.55 -> 13.15 ms (profiles/r04_ab_n320_eight_waves.txt)
+  else if (BN == 320) launch_tile<T, 128, 320, 2, 1, 1, 2>(gm, false, grid, st, k);
   else if (BM == 64) launch_tile<T, 64, 64, 4, 1, 1, 1>(gm, lnf, grid, st, k, glu);      // (rings of 6 / 8 stages: pass 2 % SLOWER; round 3, eight stages only on the <= 256-workgroup long-K launches: guided step -1.1 %)
   else if (BN == 128 && kManyBlocks > 0 && tiles * splits >= kManyBlocks) launch_tile<T, 128, 128, 2, 1, 1, 1>(gm, lnf, grid, st, k);   // 64 KiB: two workgroups per CU
   else if (BN == 128) launch_tile<T, 128, 128, 4, 1, 1, 1>(gm, lnf, grid, st, k);
@@ -1201,6 +1220,11 @@ extern "C" int dh_gemm_profile_begin(void) {
   dh::g_prof.on = true;
   dh::g_prof.used = 0;
   dh::g_prof.flops = 0;
+  dh::g_prof.bytes = 0;
+  return DH_OK;
+}
+extern "C" int dh_gemm_profile_bytes(double* bytes) {
+  if (bytes) *bytes = dh::g_prof.bytes;
   return DH_OK;
 }
 extern "C" int dh_gemm_profile_end(double* ms_total, int64_t* launches, double* flops) {

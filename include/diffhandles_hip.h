@@ -235,6 +235,13 @@ int dh_unet_io_ptr(dh_unet* u, int which, int index, void** ptr, size_t* bytes);
  * Used by bench.py for the roofline figure; not on the product path. */
 int dh_gemm_profile_begin(void);
 int dh_gemm_profile_end(double* ms_total, int64_t* launches, double* flops);
+/* ALGORITHMIC HBM bytes of the launches bracketed since the last dh_gemm_profile_begin (valid after _end as well): every
+ * operand once in its 16-bit storage type -- the A source (dense rows [M][K]; for a convolution the source image
+ * [B][Hin][Win][Cin], not its im2col view), the weights [N][K], the output [M][N] and the residual [M][N] when there is one
+ * (GEGLU epilogues: the [M][N/2] activation on top, or the [M][2N] pre-activations read and their gradient written in place of
+ * the output).  Split-K slabs, im2col tap re-reads and per-XCD re-fetches are NOT in it: `roofline.traffic` (PMC) divided by
+ * this figure is the wasted-traffic ratio.  Not on the product path. */
+int dh_gemm_profile_bytes(double* bytes);
 /* per-kernel-class accumulated launch counts / algorithmic flops of the last forward */
 /* Names the text embedding of the following dh_unet_forward calls (0 = unnamed, the default).  The K|V projections of every
  * cross-attention layer depend on the text only; a forward that finds those of the same key, batch and stream already in the

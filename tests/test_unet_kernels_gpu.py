@@ -48,7 +48,8 @@ def run_gemm(dtype, A, lda, W, M, N, K, mode=0, geo=(0, 0, 0, 0, 0, 1, 0), bias=
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (1024, 640, 2560), (256, 1280, 1280), (64, 1280, 1280),
-                                     (77, 2560, 1024), (3, 1280, 320), (4096, 2560, 320), (200, 128, 6400)])
+                                     (77, 2560, 1024), (3, 1280, 320), (4096, 2560, 320), (200, 128, 6400),
+                                     (28800, 960, 320), (28700, 320, 640)])      # >= 224 row tiles: the eight-wave 128x320 tile (N = 3 x 320; ragged M)
 def test_gemm_dense(dtype, M, N, K):
     g = torch.Generator(device=dev()).manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g, device=dev()).to(dtype)

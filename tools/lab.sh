@@ -378,6 +378,7 @@ recipe_evidence() { (
   recipe_pmc_sq
   recipe_pmc_traffic
   python3 tools/pmc_summarise.py gpurun_out/pmc > gpurun_out/pmc/gemm_traffic.json
+  DH_ALG_BYTES=1 python3 tools/time_unet.py 1 2>&1 | grep "^ALG" > gpurun_out/pmc/gemm_algorithmic_bytes.txt
   python3 tools/step_by_level.py gpurun_out/final/step_breakdown_by_grid.txt > gpurun_out/final/step_by_level.txt
   cat gpurun_out/pmc/gemm_traffic.json
 ) }

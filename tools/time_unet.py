@@ -38,3 +38,18 @@ for B in BATCHES:
     tb = (time.time() - t0) / n
     s = u.stats()
     print(f"B={B}: fwd {tf*1e3:.2f} ms ({s['flops_fwd']/tf/1e12:.1f} TF/s)  bwd {tb*1e3:.2f} ms ({s['flops_bwd']/tb/1e12:.1f} TF/s)  ops {s['ops']}")
+    # algorithmic HBM bytes of the pass's GEMM launches (every operand once: dh_gemm_profile_bytes) -- the denominator of the
+    # wasted-traffic ratio whose numerator is the PMC traffic of this same launch mix (tools/lab.sh pmc-traffic)
+    if os.environ.get("DH_ALG_BYTES"):
+        import ctypes
+        from diffusionhandles_amd import _lib
+        L = _lib.lib()
+        _lib.check(L.dh_gemm_profile_begin())
+        u.forward(x, 500.0, txt, save_for_backward=True)
+        u.backward(da, None)
+        ms, nl, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(L.dh_gemm_profile_end(ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
+        _lib.check(L.dh_gemm_profile_bytes(ctypes.byref(by)))
+        print(f"ALG B={B}: k_gemm_dma launches {nl.value}, algorithmic bytes per launch {by.value / max(1, nl.value):.0f}, "
+              f"flops per launch {fl.value / max(1, nl.value):.4g}, event time per launch {ms.value * 1e3 / max(1, nl.value):.2f} us")
+
