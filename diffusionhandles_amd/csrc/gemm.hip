@@ -1031,6 +1031,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   DH_KNOB(kKg2MinKt, "DH_KG2_MINKT", 4);            // K tiles per split from which the 128x64 tile splits K over two wave groups (16 -> 4: +1.4 % step)
   DH_KNOB(kManyBlocks, "DH_GEMM_MANY", 512);        // 128x128 grids from this size use two stages (two workgroups per CU)
   DH_KNOB(kMw128, "DH_GEMM_MW128", 1);              // min K tiles for eight waves on the 128x128 tile
+  DH_KNOB(kTwoPerCu, "DH_GEMM_TWO_PER_CU", 1);      // 128x64 grids of 257..512 workgroups: the 74-KB three-stage tile, two workgroups per CU (see the dispatch below)
 #ifdef DH_TUNING
   DH_KNOB(kWnt, "DH_W_NT", 0);                      // non-temporal weight DMA for GEMMs of at most this many row tiles (0 = never)
 #endif
@@ -1154,6 +1155,13 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (BM == 128 && BN == 128 && (glu || (kMw128 && tiles_per_split >= kMw128))) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k, glu);
   // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
   // x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge; 64x64 tiles: no K grouping wins in situ)
+  // between one and two workgroups per CU (the 96x96-latent level of a 768x768 image: 72 x 5 = 360 tiles; the B = 2 CFG pass at
+  // 64x64 latents: 64 x 5 = 320): the 147-KB two-group tile fits one workgroup per CU, so such a grid runs as two rounds with the
+  // second one mostly empty; a three-stage ring without the K groups is 74 KB, two workgroups share a CU and the grid is one round
+  // (same-box A/B, profiles/r04_ab_two_per_cu.txt: B = 2 forward 5.46 -> 5.30 ms, backward 6.82 -> 6.67 ms; 96x96 latents bf16 B = 1
+  // forward 6.49 -> 6.32 ms, backward 9.55 -> 9.40 ms; guided step 34.97 -> 35.30 steps/s)
+  else if (kTwoPerCu && BM == 128 && BN == 64 && tiles * splits > 256 && tiles * splits <= 512)
+    launch_tile<T, 128, 64, 3, 1, 1, 1>(gm, lnf, grid, st, k);
   else if (BM == 128 && BN == 64 && tiles_per_split >= kKg2MinKt) launch_tile<T, 128, 64, 3, 1, 2, 1>(gm, lnf, grid, st, k);
   // eight waves (4 x 2, 32 x 160 outputs each): the two-stage ring has one 57-KB tile in flight and its 56 one-KiB DMA pieces were
   // issued by four waves, 14 each at 60 - 185 cycles apiece -- the issue, not the latency, bounded the tile; with seven pieces per

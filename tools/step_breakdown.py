@@ -11,7 +11,7 @@ marks = [i for i, r in enumerate(rows) if "k_ddim_cfg" in r[2]]
 # one guided step of the TIMED region (full launch count, no device-side spin of the event-bracket pass)
 segs = [rows[a + 1: b + 1] for a, b in zip(marks[:-1], marks[1:])]
 first_spin = next((i for i, x in enumerate(segs) if any("spin_kernel" in r[2] for r in x)), len(segs))
-segs = [x for x in segs[:first_spin] if len(x) > 2500]
+segs = [x for x in segs[:first_spin] if len(x) > 1800]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 seg = segs[-k]
 span = (seg[-1][1] - seg[0][0]) / 1e3

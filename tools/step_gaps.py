@@ -9,7 +9,7 @@ rows.sort()
 marks = [i for i, r in enumerate(rows) if "k_ddim_cfg" in r[2]]
 segs = [rows[a + 1: b + 1] for a, b in zip(marks[:-1], marks[1:])]
 first_spin = next((i for i, x in enumerate(segs) if any("spin_kernel" in r[2] for r in x)), len(segs))
-segs = [x for x in segs[:first_spin] if len(x) > 2500][-6:]
+segs = [x for x in segs[:first_spin] if len(x) > 1800][-6:]
 def nm(n):
     m = re.search(r"k_[a-z0-9_]+", n)
     return m.group(0) if m else n[:36]

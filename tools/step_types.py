@@ -10,11 +10,11 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 # guided steps of the TIMED region: segments between two DDIM steps that hold the full 7-pass launch count and no
 # device-side spin (the spin marks the eager event-bracket pass); the last k of them
 segs = [rows[a + 1: b + 1] for a, b in zip(marks[:-1], marks[1:])]
-# guided steps of the TIMED region: full 7-pass segments (> 2500 launches) in front of the first device-side spin
+# guided steps of the TIMED region: full 7-pass segments (> 1800 launches; an unguided step has ~600) in front of the first device-side spin
 # (the spin marks the eager event-bracket pass that follows the timed region); the schedule has a period of three
 # steps with different launch counts, so whole periods are averaged
 first_spin = next((i for i, x in enumerate(segs) if any("spin_kernel" in r[2] for r in x)), len(segs))
-segs = [x for x in segs[:first_spin] if len(x) > 2500]
+segs = [x for x in segs[:first_spin] if len(x) > 1800]
 k = 3 * max(1, min(k, len(segs) // 3))
 seg = [r for x in segs[-k:] for r in x]
 busy = sum(e - s for s, e, _ in seg) / 1e3 / k
