@@ -1058,6 +1058,9 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   const long tiles256 = (long)cdiv(k.M, 256) * cdiv(k.N, 128);
   const bool mw2 = kMwBlocks > 0 && k.N % 128 == 0 && tiles256 >= kMwBlocks &&
                    !(k.M <= 256 && k.M > 128 && cdiv(k.N, 128) < 128) && (tiles256 >= kMwShortK || ktiles >= kSplitMinK);
+  // (tried and dropped, profiles/r04_ab_two128.txt: a 256x128 grid of 129..255 workgroups -- M = 8192, N = 640 at batch 8: 160 -- as twice
+  //  as many 128x128 two-stage tiles, two per CU: conv K = 5760 91.6 -> 95.9 us, batch-8 forward 12.74 -> 13.05 ms; the smaller tile
+  //  stages a third more bytes per flop and that outweighs the 96 CUs it wakes up)
   if (mw2) { BM = 256; BN = 128; }
   // GEGLU epilogues (dense, N a multiple of 128, never split): 64x64, 128x128 or 256x128 tiles only
   const int glu = k.glu_y ? 1 : (k.glub_x ? 2 : 0);
