@@ -502,16 +502,19 @@ class GuidedStableDiffuser(GuidedDiffuser):
         yield in turn, so the lanes' streams always hold work and the GPU interleaves them; nothing synchronises the lanes with
         each other.  Returns the generators' return values in job order (tensors produced on the lanes' streams; the caller's
         current stream is made to wait for every lane before this returns)."""
-        outer = torch.cuda.current_stream(lanes[0].device)
+        import contextlib
+        on_device = all(getattr(ln, "_stream", None) is not None for ln in lanes)      # (False: the scheduling alone, CPU tests)
+        outer = torch.cuda.current_stream(lanes[0].device) if on_device else None
         for ln in lanes:
-            ln._stream.wait_stream(outer)
+            if on_device:
+                ln._stream.wait_stream(outer)
         queues = [[(i, job) for i, job in enumerate(jobs) if i % len(lanes) == li] for li in range(len(lanes))]
         running = [None] * len(lanes)
         results = [None] * len(jobs)
         with torch.no_grad():
             while any(q for q in queues) or any(r is not None for r in running):
                 for li, ln in enumerate(lanes):
-                    with torch.cuda.stream(ln._stream):
+                    with (torch.cuda.stream(ln._stream) if on_device else contextlib.nullcontext()):
                         if running[li] is None and queues[li]:
                             i, job = queues[li].pop(0)
                             running[li] = (i, job(ln))
@@ -524,7 +527,8 @@ class GuidedStableDiffuser(GuidedDiffuser):
                             results[i] = done.value
                             running[li] = None
         for ln in lanes:
-            outer.wait_stream(ln._stream)
+            if on_device:
+                outer.wait_stream(ln._stream)
         return results
 
     def guided_inference_batch_lanes(self, latents, chunks, uncond_embeddings, prompt, activations_orig, streams=2,

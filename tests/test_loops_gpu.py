@@ -589,3 +589,29 @@ def test_sharded_edit_driver_on_one_gpu(tmp_path):
         assert img.shape == (512, 512, 3)
         assert S.read_png(os.path.join(out, f"edit_{i:03d}_disparity.png")).shape == (512, 512)
     assert json.load(open(os.path.join(out, "report.json")))["edits"] == 5
+
+
+def test_sharded_edit_driver_lanes_write_the_same_images(tmp_path):
+    """tools/run_edits_sharded.py --streams 2 (the rank's batches on two concurrent lanes of one process, weights resident once)
+    writes byte for byte the PNGs of --streams 1 at the same batch: 6 edits in batches of 2, so three chunks over two lanes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    outs = {}
+    for streams in (1, 2):
+        out = str(tmp_path / f"edits_s{streams}")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_edits_sharded.py"), "--edits", "6", "--batch", "2",
+                            "--streams", str(streams), "--out", out], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rep = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rep["edits"] == 6 and rep["concurrent_streams"] == streams and rep["edits_per_s"] > 0
+        outs[streams] = out
+    for i in range(6):
+        for suffix in ("", "_disparity"):
+            a = open(os.path.join(outs[1], f"edit_{i:03d}{suffix}.png"), "rb").read()
+            b = open(os.path.join(outs[2], f"edit_{i:03d}{suffix}.png"), "rb").read()
+            assert a == b, f"edit {i}{suffix}: two lanes wrote a different image"
+

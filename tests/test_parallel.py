@@ -228,3 +228,39 @@ def test_run_edits_with_streams_hands_the_whole_share_to_the_lanes():
         os.environ.update(old)
     assert calls == [(5, 2, 2)]
     assert [gi for gi, _, _ in res] == [1, 3, 5, 7, 9] and all(float(im[0, 0, 0]) == gi for gi, im, _ in res)
+
+
+def test_run_lanes_interleaves_jobs_one_yield_at_a_time():
+    """GuidedStableDiffuser.run_lanes (the host side of the concurrent edit lanes): job i runs on lane i % n, a lane's jobs one
+    after the other, every lane advances by ONE yield per round (so every lane's stream always holds work), results come back in
+    job order.  Scheduling only: lanes without a stream (no GPU)."""
+    from types import SimpleNamespace
+    from diffusionhandles_amd.guided_stable_diffuser import GuidedStableDiffuser
+    trace = []
+
+    def make(i, steps):
+        def job(lane):
+            def body():
+                for k in range(steps):
+                    trace.append((lane.name, i, k))
+                    yield None
+                return f"result{i}"
+            return body()
+        return job
+
+    lanes = [SimpleNamespace(name="A", _stream=None, device="cpu"), SimpleNamespace(name="B", _stream=None, device="cpu")]
+    res = GuidedStableDiffuser.run_lanes(lanes, [make(0, 3), make(1, 2), make(2, 2), make(3, 1), make(4, 1)])
+    assert res == [f"result{i}" for i in range(5)]
+    assert {i for ln, i, _ in trace if ln == "A"} == {0, 2, 4} and {i for ln, i, _ in trace if ln == "B"} == {1, 3}
+    # a lane never works on two jobs at once, and keeps their order
+    for name in "AB":
+        seq = [i for ln, i, _ in trace if ln == name]
+        assert seq == sorted(seq)
+    # the two lanes alternate while both have work: no lane runs two steps in a row before the other ran one
+    both = trace[:6]                                   # (lane B has run out of work after its third step)
+    assert all(both[k][0] != both[k + 1][0] for k in range(len(both) - 1))
+    # one lane only: plain sequential execution
+    trace.clear()
+    assert GuidedStableDiffuser.run_lanes(lanes[:1], [make(0, 2), make(1, 1)]) == ["result0", "result1"]
+    assert trace == [("A", 0, 0), ("A", 0, 1), ("A", 1, 0)]
+

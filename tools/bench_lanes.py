@@ -39,7 +39,9 @@ print("weights GB", gd.unet.weight_bytes() / 1e9, "workspace GB (max_batch 16)",
 # whole edits: (edits, batch, streams)
 ref = {}
 CASES = ((8, 8, 1), (8, 4, 1), (8, 4, 2), (16, 8, 1), (16, 8, 2), (8, 2, 2), (8, 1, 2), (8, 1, 1), (12, 4, 3))
-if os.environ.get("DH_LANES_CASES") == "wide":      # more lanes of full batches
+if os.environ.get("DH_LANES_CASES") == "queues":    # short list for A/Bs of runtime settings (GPU_MAX_HW_QUEUES)
+    CASES = ((16, 8, 1), (16, 8, 2), (24, 8, 3))
+elif os.environ.get("DH_LANES_CASES") == "wide":      # more lanes of full batches
     CASES = ((24, 8, 1), (24, 8, 3), (32, 8, 1), (32, 8, 4), (16, 8, 2))
 for n, batch, streams in CASES:
     with torch.no_grad():
