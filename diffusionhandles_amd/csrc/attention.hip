@@ -63,24 +63,51 @@ __device__ __forceinline__ void load_row_frags(const T* base, long ld, long row,
 }
 
 // a 64 x 64 tile travels global -> registers (fetch, issued one tile ahead of its use) -> LDS (commit); the GT threads
-// of a wave group share the 512 sixteen-byte chunks of the tile
-template <int GT> struct TileRegs { uint4 v[(512 + GT - 1) / GT]; };
+// of a wave group share the 512 sixteen-byte chunks of the tile.
+// The fetch is INLINE ASM and every load is unconditional (round 4, s_memtime stamps of the dK/dV loop, tools/attn_timeline_dkv.py:
+// a third of a 5 950-cycle tile sat between the tile's two barriers).  With compiler-issued loads the prefetch never overlapped the
+// MFMAs it was issued under: `ok ? load : 0` made hipcc merge the loaded registers with the zeros right behind the load, it moved
+// loaded values to their loop-carried registers at once, and __syncthreads() is a fence (s_waitcnt vmcnt(0)) -- and since vmcnt
+// retires in order, any one of these waits drains every load issued before it.  Now: asm loads the compiler does not count (a
+// chunk index past the tile reads chunk 511 again and is never committed; a row past the matrix reads its last row again -- finite
+// values whose probabilities are zero: keys past Nk are masked, queries past Nq carry lse = +inf), LDS-only barriers
+// (lds_barrier), and ONE s_waitcnt vmcnt(0) in front of the commit, pinned to the tile registers (tile_wait) so that no use of
+// them can be scheduled in front of it.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+template <int GT> struct TileRegs { u4v v[(512 + GT - 1) / GT]; };
 template <class T, int GT>
 __device__ __forceinline__ void fetch_tile(const T* base /* + head column */, long ld, long row0, long rows_total,
                                            TileRegs<GT>& t, int tid) {
 #pragma unroll
   for (int j = 0; j < (512 + GT - 1) / GT; ++j) {
-    const int idx = tid + j * GT;
-    const long r = row0 + (idx >> 3);
-    t.v[j] = (idx < 512 && r < rows_total) ? *reinterpret_cast<const uint4*>(base + r * ld + (idx & 7) * 8) : make_uint4(0, 0, 0, 0);
+    int idx = tid + j * GT;
+    idx = idx < 512 ? idx : 511;
+    long r = row0 + (idx >> 3);
+    r = r < rows_total ? r : rows_total - 1;
+    const T* ptr = base + r * ld + (idx & 7) * 8;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(t.v[j]) : "v"(ptr) : "memory");
   }
+}
+// The compiler-issued loads of a kernel's prologue (row fragments, lse) must be COMPLETE, and known to hipcc as complete, before a
+// loop that keeps asm loads in flight: otherwise its own s_waitcnt for them (re-evaluated on the loop's back edge) counts the asm
+// loads and drains them.  Using the registers as asm operands makes it wait here.
+__device__ __forceinline__ void frags_ready(uint4 (&f)[4]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(f[kk].x), "+v"(f[kk].y), "+v"(f[kk].z), "+v"(f[kk].w));
+}
+// every load this wave has issued has landed; the tile registers are (re)defined here: their uses stay behind the wait
+template <int GT>
+__device__ __forceinline__ void tile_wait(TileRegs<GT>& a, TileRegs<GT>& b) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < (512 + GT - 1) / GT; ++j) { asm volatile("" : "+v"(a.v[j])); asm volatile("" : "+v"(b.v[j])); }
 }
 template <int GT>
 __device__ __forceinline__ void commit_tile(const TileRegs<GT>& t, unsigned short* rm, int tid) {
 #pragma unroll
   for (int j = 0; j < (512 + GT - 1) / GT; ++j) {
     const int idx = tid + j * GT;
-    if (512 % GT == 0 || idx < 512) *reinterpret_cast<uint4*>(&rm[(idx >> 3) * TLD + (idx & 7) * 8]) = t.v[j];
+    if (512 % GT == 0 || idx < 512) *reinterpret_cast<u4v*>(&rm[(idx >> 3) * TLD + (idx & 7) * 8]) = t.v[j];
   }
 }
 
@@ -119,10 +146,13 @@ __device__ __forceinline__ uint4 tr_frag(const unsigned short* tptr, int cbase, 
 constexpr int DTILE = 64 * 64;                // halves
 __device__ uint4 g_attn_zero_page[8];         // source of the rows past the end of K / V
 #ifdef DH_ATTN_STAMP
+__device__ unsigned long long g_attn_ts_dkv[16];   // the same for k_attn_bwd_dkv (DKV_STAMP)
+#define DKV_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_attn_ts_dkv[i] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ unsigned long long g_attn_ts[8];   // s_memtime stamps of wave 0 of block (0,0,0) (timing builds only, tools/attn_timeline.py)
 #define ATTN_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_attn_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ATTN_STAMP(i) do { } while (0)
+#define DKV_STAMP(i) do { } while (0)
 #endif
 __device__ __forceinline__ int dswz(int r) {
   const int y = r >> 1;
@@ -199,6 +229,17 @@ __device__ __forceinline__ void store_rows_t(T* base, long ld, long row, int col
 
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// Workgroup barrier of the register-staged tile loops that orders LDS traffic ONLY.  __syncthreads() is a fence + s_barrier, and
+// the fence is `s_waitcnt vmcnt(0) lgkmcnt(0)`: it drains the global loads of the NEXT tile that were issued a moment earlier
+// precisely so that they would fly under this tile's MFMAs -- the prefetch never overlapped anything (round 4, s_memtime stamps
+// of the dK/dV loop, tools/attn_timeline_dkv.py: 1 900 of a tile's 5 950 cycles sat in front of the second barrier).  The tiles'
+// consumers are ordered by data dependence (commit_tile stores registers the compiler waits for by itself).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------- forward
 // One block = 128 queries x KS key ranges: wave group ks (4 waves, own K/V tiles) runs the online softmax over
 // keys [ks, ks+1) * ceil(tiles / KS) and the groups' (m, l, O) are merged through LDS at the end.  A single
@@ -228,6 +269,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
   const bool qok = qrow < Nq;
   uint4 qf[4];
   load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
+  if (!DB) frags_ready(qf);
   v16f oacc[2] = {zero16(), zero16()};
   float m_run = -INFINITY, l_run = 0.f;
   const T* kp = k + (long)b * Nk * ldk + h * HD;
@@ -272,15 +314,20 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
     if (it == 1) ATTN_STAMP(2);
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;        // uniform per wave group; barriers are block-wide
-    if (DB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile `it` have landed ...
-    __syncthreads();                                               // ... and so have everyone's; tile it-1's buffer is free
+    if (DB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of tile `it` have landed ...
+      __syncthreads();                                             // ... and so have everyone's; tile it-1's buffer is free
+    } else {
+      lds_barrier();                                               // (the next tile's global loads stay in flight)
+    }
     if (DB && act && t_begin + it + 1 < t_end) dma_tile(k0 + 64, (it + 1) & 1);
     if (!DB) {
       if (act) {
+        tile_wait<GT>(rk, rv);
         commit_tile<GT>(rk, sK0, tid);
         commit_tile<GT>(rv, sK0 + TILE, tid);
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (!act) continue;
     if (!DB && t_begin + it + 1 < t_end) {            // next tile's loads fly under this tile's MFMAs
@@ -456,7 +503,9 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
     del_q = xor32_sum(del_q);
     if (delta && qok && ks == 0 && hi == 0) delta[((long)b * H + h) * Nq + qrow] = del_q;      // NULL: already there
   }
-  const float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;
+  float lse_q = qok ? lse[((long)b * H + h) * Nq + qrow] * LOG2E : INFINITY;
+  frags_ready(qf); frags_ready(dof);
+  asm volatile("" : "+v"(lse_q), "+v"(del_q));
   v16f dqacc[2] = {zero16(), zero16()};
   const T* kp = k + (long)b * Nk * ldk + h * HD;
   const T* vp = v + (long)b * Nk * ldk + h * HD;
@@ -471,12 +520,13 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
   for (int it = 0; it < tps; ++it) {
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;
-    __syncthreads();
+    lds_barrier();
     if (act) {
+      tile_wait<GT>(rk, rv);
       commit_tile<GT>(rk, sK, tid);
       commit_tile<GT>(rv, sV, tid);
     }
-    __syncthreads();
+    lds_barrier();
     if (!act) continue;
     if (t_begin + it + 1 < t_end) {
       fetch_tile<T, GT>(kp, ldk, k0 + 64, Nk, rk, tid);
@@ -559,6 +609,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
   uint4 kf[4], vf[4];
   load_row_frags<T>(k + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, kf);
   load_row_frags<T>(v + (long)b * Nk * ldk, ldk, krow, kok, h * HD, hi, vf);
+  frags_ready(kf); frags_ready(vf);
   v16f dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
   const T* qp = q + (long)b * Nq * ldq + h * HD;
   const T* dop = d_o + (long)b * Nq * lddo + h * HD;
@@ -571,31 +622,57 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
   const int tps = (tpc + KS - 1) / KS;
   const int t_begin = chunk * tpc + ks * tps, t_end = min(t_begin + tps, c_end);
   TileRegs<GT> rq, rdo;
+  // the tile's 64 lse / delta values travel like the tile itself: fetched one tile ahead into a register of the group's first
+  // wave, committed to LDS with the tile.  (Round 4: they used to be loaded between the two barriers of the tile -- a dependent
+  // global load of ~1 900 cycles in front of the second barrier, a third of the 5 950-cycle tile by the s_memtime stamps of
+  // tools/attn_timeline_dkv.py, profiles/r04_dkv_timeline.txt.)
+  float lse_n = 0.f, del_n = 0.f;
+  auto fetch_stats = [&](long q0n) {       // raw, unconditional loads (clamped row): nothing here may need the value yet
+    if (tid < 64) {
+      long qr = q0n + tid;
+      qr = qr < Nq ? qr : Nq - 1;
+      const float* pl = lse + ((long)b * H + h) * Nq + qr;
+      const float* pd = delta + ((long)b * H + h) * Nq + qr;
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(lse_n) : "v"(pl) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(del_n) : "v"(pd) : "memory");
+    }
+  };
   if (t_begin < t_end) {
     fetch_tile<T, GT>(qp, ldq, t_begin * 64, Nq, rq, tid);
     fetch_tile<T, GT>(dop, lddo, t_begin * 64, Nq, rdo, tid);
+    fetch_stats((long)t_begin * 64);
   }
+  DKV_STAMP(0);
   for (int it = 0; it < tps; ++it) {
     const int q0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;
-    __syncthreads();
+    if (it == 2) DKV_STAMP(1);
+    if (it == 3) DKV_STAMP(6);
+    lds_barrier();
+    if (it == 2) DKV_STAMP(2);
     if (act) {
+      tile_wait<GT>(rq, rdo);
+      asm volatile("" : "+v"(lse_n), "+v"(del_n));
       commit_tile<GT>(rq, sQ, tid);
       commit_tile<GT>(rdo, sdO, tid);
+      if (tid < 64) {
+        const bool qin = q0 + tid < Nq;
+        sLse[tid] = qin ? lse_n * LOG2E : INFINITY;
+        sDel[tid] = qin ? del_n : 0.f;
+      }
       if (t_begin + it + 1 < t_end) {
         fetch_tile<T, GT>(qp, ldq, q0 + 64, Nq, rq, tid);
         fetch_tile<T, GT>(dop, lddo, q0 + 64, Nq, rdo, tid);
-      }
-      if (tid < 64) {
-        const long qr = q0 + tid;
-        sLse[tid] = qr < Nq ? lse[((long)b * H + h) * Nq + qr] * LOG2E : INFINITY;
-        sDel[tid] = qr < Nq ? delta[((long)b * H + h) * Nq + qr] : 0.f;
+        fetch_stats((long)q0 + 64);
       }
     }
-    __syncthreads();
+    if (it == 2) DKV_STAMP(3);
+    lds_barrier();
+    if (it == 2) DKV_STAMP(4);
     if (!act) continue;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
+      if (it == 2 && t2 == 1) DKV_STAMP(5);
       v16f s = tile_times_frags<T>(sQ, t2 * 32, ln, hi, kf);      // rows = queries, col = key
       const v16f dp = tile_times_frags<T>(sdO, t2 * 32, ln, hi, vf);
       v16f ds;
@@ -623,6 +700,7 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
       }
     }
   }
+  DKV_STAMP(7);
   if (KS > 1) {
     static_assert(KS <= 2, "the dK/dV merge buffer holds one pair of groups");
     float* cb = reinterpret_cast<float*>(smem);       // 4 waves x 32 x 64 f32 = 32 KiB <= KS * GRP * 2 bytes
@@ -861,6 +939,9 @@ void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k,
 }  // namespace dh
 
 #ifdef DH_ATTN_STAMP
+extern "C" int dh_dbg_attn_stamps_dkv(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dh::g_attn_ts_dkv), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 extern "C" int dh_dbg_attn_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(dh::g_attn_ts), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
