@@ -652,9 +652,11 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
     if (it == 2) DKV_STAMP(2);
     if (act) {
       tile_wait<GT>(rq, rdo);
+      if (it == 2) DKV_STAMP(8);
       asm volatile("" : "+v"(lse_n), "+v"(del_n));
       commit_tile<GT>(rq, sQ, tid);
       commit_tile<GT>(rdo, sdO, tid);
+      if (it == 2) DKV_STAMP(9);
       if (tid < 64) {
         const bool qin = q0 + tid < Nq;
         sLse[tid] = qin ? lse_n * LOG2E : INFINITY;

@@ -23,5 +23,5 @@ for rep in range(4):
     torch.cuda.synchronize()
     assert fn(ts) == 0
     t = [int(x) for x in ts]
-    print(f"N={N} H={H} B={B} rep {rep}: loop total {t[7] - t[0]} ticks; tile 2: wait at barrier 1 {t[2] - t[1]}, commit (ds_write of Q / dO) {t[3] - t[2]}, "
+    print(f"N={N} H={H} B={B} rep {rep}: loop total {t[7] - t[0]} ticks; tile 2: wait at barrier 1 {t[2] - t[1]}, commit phase {t[3] - t[2]} (= wait for the prefetched tile {t[8] - t[2]} + ds_write of Q / dO {t[9] - t[8]} + stats and next fetch issue {t[3] - t[9]}), "
           f"barrier 2 {t[4] - t[3]}, first 32-query half (S, dP, exp, dV, dK) {t[5] - t[4]}, second half + next fetch issue {t[6] - t[5]}, whole tile {t[6] - t[1]}")

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:?}"; export TMPDIR=/tmp
-for lib in tools/bin/libdh_before_dkv.so diffusionhandles_amd/libdiffhandles_hip.so; do
+for lib in tools/bin/libdh_before_dkv.so tools/bin/libdh_dkv1.so diffusionhandles_amd/libdiffhandles_hip.so; do
   rm -rf /tmp/pa_$$; 
   DIFFHANDLES_LIB=$GRAFT_REPO_ROOT/$lib rocprofv3 --kernel-trace --output-format csv -d /tmp/pa_$$ -- python3 tools/bench_attn.py > /dev/null 2>&1
   echo "== $lib"
