@@ -140,7 +140,9 @@ class GuidedStableDiffuser(GuidedDiffuser):
                 self.text_encoder = build_text_encoder(os.environ["DIFFHANDLES_TEXT_ENCODER_DIR"])
                 text_native = True
             elif isinstance(self.text_encoder, str):
-                self.text_encoder = build_text_encoder()           # the SD-2 text configuration, random weights
+                with torch.random.fork_rng(devices=[]):            # random weights, but the SAME in every process (seeded like the U-Net's)
+                    torch.manual_seed(1000 + self._synthetic_seed)
+                    self.text_encoder = build_text_encoder()       # the SD-2 text configuration
             if text_native:
                 from .vae import HipTextEncoder
                 tc = self.text_encoder.config.to_dict()
@@ -154,7 +156,9 @@ class GuidedStableDiffuser(GuidedDiffuser):
                                            self._unet_config["sample_size"], self.dtype)
             elif isinstance(self.vae, str):
                 native = self.vae == "sd-native"
-                self.vae = AutoencoderKL()
+                with torch.random.fork_rng(devices=[]):            # (two runs of a driver must decode with the same random VAE)
+                    torch.manual_seed(2000 + self._synthetic_seed)
+                    self.vae = AutoencoderKL()
                 if native:
                     self.vae = NativeDecodeVAE(self.vae, self._unet_config["sample_size"], self.dtype)
             if self.tokenizer is None:
