@@ -269,7 +269,9 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
   const bool qok = qrow < Nq;
   uint4 qf[4];
   load_row_frags<T>(q + (long)b * Nq * ldq, ldq, qrow, qok, h * HD, hi, qf);
-  if (!DB) frags_ready(qf);
+  frags_ready(qf);      // (DB as well: hipcc's own wait for these prologue loads, re-evaluated inside the loop, counted the LDS-DMA
+                        //  pieces of the NEXT tile issued just before it -- vmcnt(1), vmcnt(0) -- and drained them on the spot: the
+                        //  "double-buffered" forward had been loading synchronously since round 3)
   v16f oacc[2] = {zero16(), zero16()};
   float m_run = -INFINITY, l_run = 0.f;
   const T* kp = k + (long)b * Nk * ldk + h * HD;

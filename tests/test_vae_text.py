@@ -169,10 +169,16 @@ def test_diffuser_with_native_text_tower_and_vae():
     hip = HipUNet(dtype=torch.float16, max_batch=2)
     hip.init_synthetic(0)
     conf = C.load_default().guided_diffuser
-    torch.manual_seed(21)
-    gd = GuidedStableDiffuser(conf, unet=hip, text_encoder="sd2-native", vae="sd-native").to(dev)
+    gd = GuidedStableDiffuser(conf, unet=hip, text_encoder="sd2-native", vae="sd-native", synthetic_seed=3).to(dev)
     assert isinstance(gd.text_encoder, HipTextEncoder) and isinstance(gd.vae, NativeDecodeVAE)
-    torch.manual_seed(21)
+    # the diffuser seeds its random-weight text tower with 1000 + synthetic_seed (the same weights in every process: two runs of
+    # a driver must agree byte for byte) without touching the caller's RNG stream
+    torch.manual_seed(77)
+    probe = torch.rand(1).item()
+    torch.manual_seed(77)
+    GuidedStableDiffuser(conf, unet=hip, text_encoder="sd2", vae="sd", synthetic_seed=3).to(dev)
+    assert torch.rand(1).item() == probe, "building the random-weight modules consumed the caller's RNG"
+    torch.manual_seed(1000 + 3)
     ref = build_text_encoder().to(dev).eval()
     emb = gd._encode(["a sphere on a plane", ""])
     ids = gd.tokenizer(["a sphere on a plane", ""], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
