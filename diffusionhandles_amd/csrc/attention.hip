@@ -154,6 +154,13 @@ __device__ unsigned long long g_attn_ts[8];   // s_memtime stamps of wave 0 of b
 #define ATTN_STAMP(i) do { } while (0)
 #define DKV_STAMP(i) do { } while (0)
 #endif
+#ifdef DH_ATTN_STAMP_DQ      // the same stamps in k_attn_bwd_dq instead (one kernel at a time writes the array)
+#undef DKV_STAMP
+#define DKV_STAMP(i) do { } while (0)
+#define DQ_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_attn_ts_dkv[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DQ_STAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ int dswz(int r) {
   const int y = r >> 1;
   return ((y & 1) << 2) | (y & 2) | ((y >> 2) & 1);
@@ -475,17 +482,22 @@ __global__ void k_attn_delta(const T* o, long ldo, const T* d_o, long lddo, floa
 // ---------------------------------------------------------------------------- backward dQ
 // Same block shape as the forward (128 queries x KS key ranges, dQ partial sums merged through LDS).
 // delta = rowsum(dO * O) is computed here from the row fragments and written for the dK/dV kernel.
-template <class T, int KS, int QW>
+// DB (round 4, grids that fit the chip once or twice, like the forward): the K / V tiles go global -> LDS by LDS-DMA into dense
+// source-swizzled tiles, double-buffered per key group -- no staging registers, no commit, ONE barrier per key tile.  The s_memtime
+// stamps of the register-staged loop (tools/attn_timeline_dkv.py, DH_TIMELINE_KERNEL=dq) put 1 700 of a key tile's 6 000 cycles into
+// wait-for-prefetch + commit + second barrier + fetch issue, phases in which no MFMA runs on any of the block's twelve waves.
+template <class T, int KS, int QW, bool DB>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long ldq, const T* k, const T* v, long ldk, const T* o,
                                                           long ldo, const T* d_o, long lddo, const float* lse, float* delta,
                                                           T* dq, long lddq, int H, int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) unsigned short smem[KS * 2 * TILE];
+  constexpr int NBUF = DB ? 2 : 1;
+  constexpr int TSZ = DB ? DTILE : TILE;        // halves per staged tile
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[KS * NBUF * 2 * TSZ];
   constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
   const int ks = threadIdx.x / GT, tid = threadIdx.x - ks * GT;
   const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
-  unsigned short* sK = smem + ks * 2 * TILE;
-  unsigned short* sV = sK + TILE;
+  unsigned short* sK0 = smem + ks * NBUF * 2 * TSZ;     // buffer p: K at sK0 + 2 p TSZ, V one tile behind it
   const long qrow = (long)blockIdx.x * (32 * QW) + wave * 32 + ln;
   const bool qok = qrow < Nq;
   uint4 qf[4], dof[4];
@@ -511,34 +523,80 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
   v16f dqacc[2] = {zero16(), zero16()};
   const T* kp = k + (long)b * Nk * ldk + h * HD;
   const T* vp = v + (long)b * Nk * ldk + h * HD;
-  const unsigned short* kt = sK + (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
+  const int kt_off = (4 * hi + (t16 >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
   const int tiles = (Nk + 63) >> 6, tps = (tiles + KS - 1) / KS;
   const int t_begin = ks * tps, t_end = min(t_begin + tps, tiles);
-  TileRegs<GT> rk, rv;
+  TileRegs<GT> rk, rv;                          // (DB: unused)
+  // DB: the 16 one-KiB pieces of a K/V tile pair (8 rows each) are issued by the group's waves in turn (k_attn_fwd has the layout)
+  const unsigned lds_grp = DB ? (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + ks * NBUF * 2 * TSZ * 2 : 0u;
+  const int d_row = lane >> 3;
+  const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);      // chunk for even pieces; odd: ^ 1
+  const T* d_zero = reinterpret_cast<const T*>(g_attn_zero_page) + (lane & 7) * 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int key0, int buf) {
+#pragma unroll
+    for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
+      const int p = wave_u + j * QW;                 // wave-uniform
+      if (p < 16) {
+        const int pp = p & 7;
+        const long r = (long)key0 + 8 * pp + d_row;
+        const T* src = (p < 8 ? kp : vp) + r * ldk + ((d_c0 ^ (pp & 1)) << 3);
+        attn_dma16(r < Nk ? src : d_zero, __builtin_amdgcn_readfirstlane(lds_grp + (unsigned)(buf * 2 * TSZ * 2 + p * 1024)));
+      }
+    }
+  };
   if (t_begin < t_end) {
-    fetch_tile<T, GT>(kp, ldk, t_begin * 64, Nk, rk, tid);
-    fetch_tile<T, GT>(vp, ldk, t_begin * 64, Nk, rv, tid);
+    if (DB) {
+      dma_tile(t_begin * 64, 0);
+    } else {
+      fetch_tile<T, GT>(kp, ldk, t_begin * 64, Nk, rk, tid);
+      fetch_tile<T, GT>(vp, ldk, t_begin * 64, Nk, rv, tid);
+    }
   }
+  // dense-tile fragment addressing (per lane, hoisted)
+  const int xk = hi ^ dswz(ln);
+  const int d_rl = 4 * hi + (t16 >> 2), d_cl = 2 * ((lane >> 4) & 1) + ((t16 & 3) >> 1);
+  const int d_lo = d_cl ^ dswz(d_rl), d_up = d_cl ^ dswz(d_rl + 8), d_within = 4 * (t16 & 1);
+  DQ_STAMP(0);
   for (int it = 0; it < tps; ++it) {
     const int k0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;
-    lds_barrier();
-    if (act) {
-      tile_wait<GT>(rk, rv);
-      commit_tile<GT>(rk, sK, tid);
-      commit_tile<GT>(rv, sV, tid);
+    if (it == 2) DQ_STAMP(1);
+    if (it == 3) DQ_STAMP(6);
+    if (DB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of tile `it` have landed ...
+      __syncthreads();                                             // ... and so have everyone's; tile it-1's buffer is free
+      if (it == 2) { DQ_STAMP(2); DQ_STAMP(8); DQ_STAMP(3); DQ_STAMP(4); }
+      if (act && t_begin + it + 1 < t_end) dma_tile(k0 + 64, (it + 1) & 1);
+      if (!act) continue;
+    } else {
+      lds_barrier();
+      if (it == 2) DQ_STAMP(2);
+      if (act) {
+        tile_wait<GT>(rk, rv);
+        if (it == 2) DQ_STAMP(8);
+        commit_tile<GT>(rk, sK0, tid);
+        commit_tile<GT>(rv, sK0 + TILE, tid);
+      }
+      if (it == 2) DQ_STAMP(3);
+      lds_barrier();
+      if (it == 2) DQ_STAMP(4);
+      if (!act) continue;
+      if (t_begin + it + 1 < t_end) {
+        fetch_tile<T, GT>(kp, ldk, k0 + 64, Nk, rk, tid);
+        fetch_tile<T, GT>(vp, ldk, k0 + 64, Nk, rv, tid);
+      }
     }
-    lds_barrier();
-    if (!act) continue;
-    if (t_begin + it + 1 < t_end) {
-      fetch_tile<T, GT>(kp, ldk, k0 + 64, Nk, rk, tid);
-      fetch_tile<T, GT>(vp, ldk, k0 + 64, Nk, rv, tid);
-    }
+    if (it == 2) DQ_STAMP(9);
+    const unsigned short* sK = sK0 + (DB ? (it & 1) * 2 * TSZ : 0);
+    const unsigned short* sV = sK + TSZ;
+    const unsigned short* kt = sK + (DB ? d_rl * 64 : kt_off);
     const bool ragged = k0 + 64 > Nk;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-      v16f s = tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
-      const v16f dp = tile_times_frags<T>(sV, t2 * 32, ln, hi, dof);
+      if (it == 2 && t2 == 1) DQ_STAMP(5);
+      v16f s = DB ? dtile_times_frags<T>(sK, t2 * 32, ln, xk, qf) : tile_times_frags<T>(sK, t2 * 32, ln, hi, qf);
+      const v16f dp = DB ? dtile_times_frags<T>(sV, t2 * 32, ln, xk, dof) : tile_times_frags<T>(sV, t2 * 32, ln, hi, dof);
       if (ragged) {                // keys past Nk (a real branch, see k_attn_fwd): their probabilities are zero
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -555,10 +613,12 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
         const uint4 dsf = pack8<T>(s, st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          dqacc[dt] = Mma<T>::run(tr_frag(kt, dt * 32, t2 * 32 + 16 * st), dsf, dqacc[dt]);
+          dqacc[dt] = Mma<T>::run(DB ? dtr_frag(kt, d_lo, d_up, d_within, dt, t2 * 32 + 16 * st) : tr_frag(kt, dt * 32, t2 * 32 + 16 * st), dsf,
+                                  dqacc[dt]);
       }
     }
   }
+  DQ_STAMP(7);
   if (KS > 1) {
     float* cb = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -830,9 +890,18 @@ static void attn_dq_launch(int B, hipStream_t st, const void* q, long ldq, const
                            const void* o, long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq,
                            long lddq, int H, int Nq, int Nk) {
   // (the 16-wave shape is never chosen, launch_attention_bwd_dq: at 128 registers per lane it would spill; not instantiated)
-  if constexpr (KS * QW < 16)
-    hipLaunchKernelGGL((k_attn_bwd_dq<T, KS, QW>), dim3(cdiv(Nq, 32 * QW), H, B), dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
+  if constexpr (KS * QW < 16) {
+    const dim3 grid(cdiv(Nq, 32 * QW), H, B);
+    if constexpr (KS >= 2) {      // key-split blocks of grids that fit the chip once or twice: LDS-DMA double buffer (as the forward)
+      if ((long)grid.x * grid.y * grid.z <= 512) {
+        hipLaunchKernelGGL((k_attn_bwd_dq<T, KS, QW, true>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq, (const T*)k, (const T*)v,
+                           ldk, (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((k_attn_bwd_dq<T, KS, QW, false>), grid, dim3(64 * QW * KS), 0, st, (const T*)q, ldq,
                        (const T*)k, (const T*)v, ldk, (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
+  }
 }
 template <class T, int KS, int QW>
 static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,

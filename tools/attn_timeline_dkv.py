@@ -23,5 +23,9 @@ for rep in range(4):
     torch.cuda.synchronize()
     assert fn(ts) == 0
     t = [int(x) for x in ts]
+    if os.environ.get("DH_TIMELINE_KERNEL") == "dq":      # library built with -DDH_ATTN_STAMP -DDH_ATTN_STAMP_DQ: the stamps sit in k_attn_bwd_dq
+        print(f"dq N={N} H={H} B={B} rep {rep}: loop total {t[7] - t[0]} ticks; key tile 2: wait at barrier 1 {t[2] - t[1]}, wait for the prefetched K / V {t[8] - t[2]}, "
+              f"commit {t[3] - t[8]}, barrier 2 {t[4] - t[3]}, next fetch issue {t[9] - t[4]}, first 32-key half (S, dP, exp, dQ) {t[5] - t[9]}, second half {t[6] - t[5]}, whole tile {t[6] - t[1]}")
+        continue
     print(f"N={N} H={H} B={B} rep {rep}: loop total {t[7] - t[0]} ticks; tile 2: wait at barrier 1 {t[2] - t[1]}, commit phase {t[3] - t[2]} (= wait for the prefetched tile {t[8] - t[2]} + ds_write of Q / dO {t[9] - t[8]} + stats and next fetch issue {t[3] - t[9]}), "
           f"barrier 2 {t[4] - t[3]}, first 32-query half (S, dP, exp, dV, dK) {t[5] - t[4]}, second half + next fetch issue {t[6] - t[5]}, whole tile {t[6] - t[1]}")
