@@ -347,6 +347,17 @@ class GuidedStableDiffuser(GuidedDiffuser):
         return energy_and_grad(act, st.orig[k][t_idx], st.pc, fgw, bgw, self.conf.fg_patch_size, self.conf.bg_patch_size,
                                st.size, self.conf.bg_loss_type, grad_scale=self.grad_scale, out=out)[1]
 
+    @staticmethod
+    def _latent_buffer(st, x, iteration):
+        """The latent of optimisation iteration `iteration`: two buffers per guidance state, used alternately (the update reads
+        the previous iteration's buffer or the caller's tensor and writes the other one; the DDIM step that follows allocates its
+        own output, so nothing the caller holds is ever overwritten) -- no allocation inside the step loop."""
+        bufs = st.__dict__.setdefault("_xbuf", [None, None])
+        k = iteration & 1
+        if bufs[k] is None or bufs[k].shape != x.shape or bufs[k].device != x.device:
+            bufs[k] = torch.empty_like(x)
+        return bufs[k]
+
     def guided_step(self, st, x, t_idx, t, uncond, record=None, images=None):
         """One guided-denoise step (guided_stable_diffuser.py:377-479): up to num_optsteps x
         {U-Net forward, energy + gradient, backward-to-latent, latent update}, then the CFG
@@ -372,7 +383,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
                     d_acts[k] = self.unet.io_view("act_grad", k)[:1] if ip else torch.empty_like(acts[k])
                     self._energy_grad(st, k, acts[k][0], t_idx, fgw[k], bgw[k], out=d_acts[k][0])
                 d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False, inplace=ip)
-                x_new = torch.empty_like(x)
+                x_new = self._latent_buffer(st, x, iteration)
                 _lib.check(L.dh_latent_update_strided(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(d_sample), d_sample.shape[-1],
                                                       x.shape[-1], 0.1, self.grad_scale, x.numel() // x.shape[-1],
                                                       _lib.stream_ptr()), "dh_latent_update_strided")
@@ -412,7 +423,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
                         fw = fgw[k] if st.n_pairs > 0 else 0.0
                         self._energy_grad(st, k, acts[k][e], t_idx, fw, bgw[k], out=d_acts[k][e])
                 d_sample, _ = self.unet.backward(d_acts, None, want_sample_grad=True, want_text_grad=False, inplace=True)
-                x_new = torch.empty_like(x)
+                x_new = self._latent_buffer(sts[0], x, iteration)
                 _lib.check(L.dh_latent_update_strided(_lib.ptr(x_new), _lib.ptr(x), _lib.ptr(d_sample), d_sample.shape[-1],
                                                       x.shape[-1], 0.1, self.grad_scale, x.numel() // x.shape[-1],
                                                       _lib.stream_ptr()), "dh_latent_update_strided")
