@@ -96,35 +96,14 @@ extern "C" int dh_dbg_gemm_glu(int dtype, int bwd, const void* A, long lda, cons
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
-static GnSync* g_dbg_seam = nullptr;
 extern "C" int dh_dbg_groupnorm(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 const void* dy, void* dx, float* scratch, int B, int HW, int C, int G, float eps,
                                 int silu, int accumulate, void* stream) {
-  launch_groupnorm_fwd(dtype, x, gamma, beta, y, stats, scratch, B, HW, C, G, eps, silu, (hipStream_t)stream, 0, g_dbg_seam);
+  launch_groupnorm_fwd(dtype, x, gamma, beta, y, stats, scratch, B, HW, C, G, eps, silu, (hipStream_t)stream);
   if (dy && dx)
     launch_groupnorm_bwd(dtype, x, dy, gamma, beta, stats, dx, scratch, B, HW, C, G, silu, accumulate, (hipStream_t)stream);
   DH_LAUNCH_CHECK();
   return DH_OK;
-}
-// on != 0: the GroupNorm hooks run the one-launch form where it applies (unet_kernels.h "GroupNorm seam"), on counters owned
-// by this file; returns the seam's failure flag (synchronises the device) and re-arms the counters
-extern "C" int dh_dbg_gn_seam(int on) {
-  int failed = 0;
-  if (g_dbg_seam) {
-    GnSync h;
-    DH_CHECK_HIP(hipDeviceSynchronize());
-    DH_CHECK_HIP(hipMemcpy(&h, g_dbg_seam, sizeof(GnSync), hipMemcpyDeviceToHost));
-    failed = (int)h.fail;
-    DH_CHECK_HIP(hipMemset(g_dbg_seam, 0, sizeof(GnSync)));
-  }
-  if (on && !g_dbg_seam) {
-    DH_CHECK_HIP(hipMalloc((void**)&g_dbg_seam, sizeof(GnSync)));
-    DH_CHECK_HIP(hipMemset(g_dbg_seam, 0, sizeof(GnSync)));
-  } else if (!on && g_dbg_seam) {
-    (void)hipFree(g_dbg_seam);
-    g_dbg_seam = nullptr;
-  }
-  return failed;
 }
 extern "C" int dh_dbg_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 const void* dy, const void* add, void* dx, int rows, int C, float eps, void* stream) {

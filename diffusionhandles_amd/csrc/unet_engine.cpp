@@ -96,7 +96,6 @@ struct dh_unet {
   // device arenas
   unsigned short *w16 = nullptr, *act = nullptr, *grad = nullptr, *scratch = nullptr;
   float *pf = nullptr, *f32a = nullptr, *partial = nullptr, *small = nullptr;
-  GnSync* gn_sync = nullptr;           // seam counters of the one-launch GroupNorms (private to the engine: one stream of work)
   // well-known tensors
   int t_text = -1, t_kv = -1, t_conv_in_out = -1, t_final = -1, act_ids[3] = {-1, -1, -1};
   int act_op_end[3] = {0, 0, 0};   // ops [0, act_op_end[i]) produce captured activation i
@@ -650,8 +649,6 @@ static int create_engine(const dh_unet_config* cfg, dh_unet* parent, dh_unet** o
   if ((e = hipMalloc((void**)&u->partial, u->partial_elems * 4)) != hipSuccess) return fail(e, "hipMalloc split-K");
   if ((e = hipMalloc((void**)&u->scratch, u->scratch_elems * 2)) != hipSuccess) return fail(e, "hipMalloc scratch");
   if ((e = hipMalloc((void**)&u->small, u->small_elems * 4)) != hipSuccess) return fail(e, "hipMalloc small");
-  if ((e = hipMalloc((void**)&u->gn_sync, sizeof(GnSync))) != hipSuccess) return fail(e, "hipMalloc seam counters");
-  (void)hipMemset(u->gn_sync, 0, sizeof(GnSync));
   {
     const dh_unet_config& c = u->cfg;
     const size_t ns = (size_t)c.max_batch * c.sample_size * c.sample_size;
@@ -696,7 +693,6 @@ extern "C" void dh_unet_destroy(dh_unet* u) {
   if (u->owns_weights) { (void)hipFree(u->w16); (void)hipFree(u->pf); }      // (a shared engine never touches its parent here: destruction order at process exit is not ours)
   (void)hipFree(u->act); (void)hipFree(u->grad);
   (void)hipFree(u->f32a); (void)hipFree(u->partial); (void)hipFree(u->scratch); (void)hipFree(u->small);
-  (void)hipFree(u->gn_sync);
   (void)hipFree(u->in_sample); (void)hipFree(u->in_text); (void)hipFree(u->io_eps); (void)hipFree(u->out_dsample);
   (void)hipFree(u->out_dtext); (void)hipFree(u->t_dev);
   for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -842,7 +838,7 @@ static void forward_ops(dh_unet* u, int B, int n_ops, int first_op, bool kv_hit,
         const Ten& t = u->tens[o.in0];
         const int have = (oi > 0 && u->ops[oi - 1].gn_next == oi) ? gn_have : 0;
         launch_groupnorm_fwd(dt, u->aptr(o.in0), u->pf + o.gamma_off, u->pf + o.beta_off, u->aptr(o.out),
-                             u->f32a + o.stats_off, u->small, B, t.rows, t.C, o.groups, o.eps, o.silu, st, have, u->gn_sync);
+                             u->f32a + o.stats_off, u->small, B, t.rows, t.C, o.groups, o.eps, o.silu, st, have);
         gn_have = 0;
         break;
       }

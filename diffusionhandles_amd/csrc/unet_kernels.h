@@ -34,94 +34,6 @@ __host__ __device__ inline int glu_col(int o, int gate) { return 32 * (o >> 4) +
 // fused-weight row (= stored column) n' -> row of the torch parameter [2F][K] (value rows first, then gate rows)
 __host__ __device__ inline int glu_src_row(int n, int F) { return ((n >> 4) & 1) * F + 16 * (n >> 5) + (n & 15); }
 
-// ---------------------------------------------------------------------------------------------------- GroupNorm seam
-// GroupNorm in ONE launch: the S slice workgroups of an (image, 4-group block) leave their slice statistics, meet at a seam
-// (an arrival counter in memory), merge the S slices and normalise the rows they still hold in registers -- instead of a
-// statistics launch and an apply launch with a 3.5-us launch boundary between them.  The seam needs its S workgroups
-// co-resident: the launchers take this path only for grids of at most GN_SEAM_WGS workgroups of 256 threads (the chip holds
-// >= 1024 such workgroups), and every spin is BOUNDED -- a workgroup that waits longer than GN_SPIN_CAP polls (seconds) raises
-// `fail`, poisons its output with NaN and leaves; dh_unet_health() reports it and re-arms the counters.
-struct GnSync { unsigned arrive[64]; unsigned left[64]; unsigned fail; unsigned pad[63]; };
-constexpr int GN_SEAM_SLOTS = 64;        // (image, group block) pairs of one launch
-constexpr int GN_SEAM_WGS = 512;         // bigger grids: two launches
-constexpr int GN_HOLD = 8;               // 16-byte chunks a thread keeps across the seam
-constexpr unsigned GN_SPIN_CAP = 1u << 22;
-typedef __attribute__((address_space(1))) unsigned gn_gu32;
-// seam payload: written through and read past the caches (agent-scope relaxed atomics: the XCDs' L2s are not coherent with
-// each other inside a kernel)
-__device__ __forceinline__ void gn_put(float* p, float v) {
-  __hip_atomic_store((gn_gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float gn_get(const float* p) {
-  return __uint_as_float(__hip_atomic_load((gn_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// every thread of the workgroup calls it after its gn_put()s; returns false when the seam failed
-__device__ __forceinline__ bool gn_seam(GnSync* sy, int slot, unsigned S) {
-  __shared__ unsigned seam_ok;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores have landed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    gn_gu32* ctr = (gn_gu32*)&sy->arrive[slot];
-    gn_gu32* fail = (gn_gu32*)&sy->fail;
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0, ok = 1;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > GN_SPIN_CAP) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
-    }
-    seam_ok = ok;
-  }
-  __syncthreads();
-  return seam_ok != 0;
-}
-// The last workgroup to leave the seam re-arms the slot (the next launch that uses it starts after this kernel has ended).
-// Thread 0 takes its leaving ticket right behind a passed seam and looks at it at the end of the kernel, so that the round
-// trip of the atomic lies under the normalisation.
-__device__ __forceinline__ unsigned gn_leave_ticket(GnSync* sy, int slot) {
-  return threadIdx.x == 0 ? __hip_atomic_fetch_add((gn_gu32*)&sy->left[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-}
-__device__ __forceinline__ void gn_leave(GnSync* sy, int slot, unsigned S, unsigned ticket) {
-  if (threadIdx.x == 0 && ticket == S - 1) {
-    __hip_atomic_store((gn_gu32*)&sy->arrive[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((gn_gu32*)&sy->left[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// behind a passed seam: merge the S slice triples (n | mean | M2 planes, the k_gn_partial layout) of the workgroup's GN_GB
-// groups -- 8 lanes per group, Chan's formula, the arithmetic of the apply kernels' gn_combine -- into sm_st[gl] = (mean, rstd)
-__device__ __forceinline__ void gn_merge_block(const float* part, int b, int G, int g0, int S, float eps, float2* sm_st,
-                                               float* stats_out) {
-  if (threadIdx.x < 8 * 4) {
-    const int gl = threadIdx.x >> 3, sub = threadIdx.x & 7, g = g0 + gl;
-    const bool act = g < G;
-    const float* p = part + ((size_t)(b * G + (act ? g : 0)) * 3) * S;
-    float cn[8], cm[8], cq[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int s = sub + 8 * k;
-      const bool on = act && s < S;
-      cn[k] = on ? gn_get(p + s) : 0.f;
-      cm[k] = on ? gn_get(p + S + s) : 0.f;
-      cq[k] = on ? gn_get(p + 2 * S + s) : 0.f;
-    }
-    float n = 0.f, sm = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { n += cn[k]; sm += cn[k] * cm[k]; }
-    n = oct_sum(n); sm = oct_sum(sm);
-    const float mean = sm / n;
-    float m2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { const float d = cm[k] - mean; m2 += cq[k] + cn[k] * d * d; }
-    m2 = oct_sum(m2);
-    if (act && sub == 0) {
-      const float rstd = rsqrtf(m2 / n + eps);
-      sm_st[gl] = make_float2(mean, rstd);
-      if (stats_out) { stats_out[2 * (b * G + g)] = mean; stats_out[2 * (b * G + g) + 1] = rstd; }
-    }
-  }
-  __syncthreads();
-}
-
 enum { A_DENSE = 0, A_CONV3 = 1, A_CONVT2 = 2 };
 
 struct GemmArgs {
@@ -199,10 +111,9 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
 // GroupNorm (+SiLU): y = act(gn(x));  stats = [B*G][2] (mean, rstd) saved for backward.
 // have_partials != 0: the slice statistics in `scratch` were already left by the producer of x
 // (split-K reduce / concat), only the apply kernel runs.
-// sync != NULL (a zeroed GnSync owned by the caller, one per stream of work): small grids run as ONE launch ("GroupNorm seam").
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
-                          int have_partials = 0, GnSync* sync = nullptr);
+                          int have_partials = 0);
 int gn_slices(int HW, int B);   // number of row slices of the GroupNorm statistics for HW rows per image, B images
 constexpr int GN_GB = 4;        // groups per statistics workgroup
 // out[m][0..Ca) = a[m], out[m][Ca..Ca+Cb) = b[m], plus the GroupNorm slice statistics of out (G groups)

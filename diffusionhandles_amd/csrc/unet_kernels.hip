@@ -381,133 +381,6 @@ __global__ void __launch_bounds__(256) k_gn_apply(const T* x, const float* gamma
   }
 }
 
-// GroupNorm forward in one launch (unet_kernels.h, "GroupNorm seam"): k_gn_partial<fwd>'s workgroup shape and slice
-// arithmetic with the <= GN_HOLD chunks of every thread kept in registers, the seam, gn_combine's merge for the
-// workgroup's own 4 groups and k_gn_apply's normalisation of the kept chunks.  The launcher guarantees that a thread's
-// rows fit GN_HOLD.
-template <class T>
-__global__ void __launch_bounds__(256) k_gn_fused_fwd(const T* x, const float* gamma, const float* beta, float* part,
-                                                      float* stats, T* y, int HW, int C, int G, int S, float eps, int silu,
-                                                      GnSync* sync) {
-  __shared__ float sm_red[4][2 * GN_GB];
-  __shared__ float2 sm_st[GN_GB];
-  const int s = blockIdx.x, g0 = blockIdx.y * GN_GB, b = blockIdx.z, cpg = div_small(C, rcp_fast(G));
-  const int W = GN_GB * cpg, nch = W >> 3;
-  const float inv_nch = rcp_fast(nch), inv_S = rcp_fast(S);
-  const int RP = div_small((int)blockDim.x, inv_nch);
-  const int r0 = div_small(HW * s, inv_S), r1 = div_small(HW * (s + 1), inv_S);
-  const size_t base = (size_t)b * HW * C + (size_t)g0 * cpg;
-  const int rr = div_small((int)threadIdx.x, inv_nch), ch = threadIdx.x - rr * nch;
-  const int slot = b * gridDim.y + blockIdx.y;
-  const bool mine = rr < RP && g0 * cpg + ch * 8 < C;
-  float ga[GN_GB], gq[GN_GB], pg[GN_GB];
-#pragma unroll
-  for (int gl = 0; gl < GN_GB; ++gl) {
-    ga[gl] = 0.f; gq[gl] = 0.f;
-    pg[gl] = g0 + gl >= G ? 0.f : to_f32<T>(x[base + (size_t)r0 * C + gl * cpg]);
-  }
-  uint4 keep[GN_HOLD];
-  int gi[8];
-  float gm[8], bt[8];
-  if (mine) {
-    const float inv_cpg = rcp_fast(cpg);
-    float a[8], q[8], pv[8];
-#pragma unroll
-    for (int k = 0; k < GN_HOLD; ++k) {          // every load of the thread in flight before the first use
-      const int r = r0 + rr + k * RP;
-      keep[k] = r < r1 ? *reinterpret_cast<const uint4*>(x + base + (size_t)r * C + ch * 8) : make_uint4(0, 0, 0, 0);
-    }
-    *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(gamma + g0 * cpg + ch * 8);
-    *reinterpret_cast<float4*>(gm + 4) = *reinterpret_cast<const float4*>(gamma + g0 * cpg + ch * 8 + 4);
-    *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(beta + g0 * cpg + ch * 8);
-    *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(beta + g0 * cpg + ch * 8 + 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      gi[i] = div_small(ch * 8 + i, inv_cpg);
-      a[i] = 0.f; q[i] = 0.f; pv[i] = 0.f;
-#pragma unroll
-      for (int gl = 0; gl < GN_GB; ++gl) pv[i] = gi[i] == gl ? pg[gl] : pv[i];
-    }
-#pragma unroll
-    for (int k = 0; k < GN_HOLD; ++k) {
-      if (r0 + rr + k * RP < r1) {
-        const T* v = reinterpret_cast<const T*>(&keep[k]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = to_f32<T>(v[i]) - pv[i]; a[i] += d; q[i] += d * d; }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int gl = 0; gl < GN_GB; ++gl) {
-        ga[gl] += gi[i] == gl ? a[i] : 0.f;
-        gq[gl] += gi[i] == gl ? q[i] : 0.f;
-      }
-  }
-#pragma unroll
-  for (int gl = 0; gl < GN_GB; ++gl) { ga[gl] = wave_sum(ga[gl]); gq[gl] = wave_sum(gq[gl]); }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int gl = 0; gl < GN_GB; ++gl) { sm_red[threadIdx.x >> 6][2 * gl] = ga[gl]; sm_red[threadIdx.x >> 6][2 * gl + 1] = gq[gl]; }
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < GN_GB && g0 + (int)threadIdx.x < G) {
-    const int gl = threadIdx.x, g = g0 + gl;
-    float sa = 0.f, sq = 0.f;
-    for (int w = 0; w < 4; ++w) { sa += sm_red[w][2 * gl]; sq += sm_red[w][2 * gl + 1]; }
-    const float n = (float)(r1 - r0) * (float)cpg;
-    float piv = 0.f;
-#pragma unroll
-    for (int k = 0; k < GN_GB; ++k) piv = gl == k ? pg[k] : piv;
-    float* o = part + ((size_t)(b * G + g) * 3) * S + s;
-    gn_put(o, n); gn_put(o + S, piv + sa / n); gn_put(o + 2 * S, sq - sa * sa / n);
-  }
-  const bool ok = gn_seam(sync, slot, (unsigned)S);
-  const unsigned ticket = ok ? gn_leave_ticket(sync, slot) : 0u;
-  if (ok) gn_merge_block(part, b, G, g0, S, eps, sm_st, s == 0 ? stats : nullptr);
-  if (mine) {
-    float mu[8], rs[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      mu[i] = 0.f; rs[i] = 0.f;
-#pragma unroll
-      for (int gl = 0; gl < GN_GB; ++gl) { mu[i] = gi[i] == gl ? sm_st[gl].x : mu[i]; rs[i] = gi[i] == gl ? sm_st[gl].y : rs[i]; }
-      if (!ok) mu[i] = __builtin_nanf("");      // a failed seam must not look like a result
-    }
-    typedef T T8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-    for (int k = 0; k < GN_HOLD; ++k) {
-      const int r = r0 + rr + k * RP;
-      if (r < r1) {
-        const T8 xv = __builtin_bit_cast(T8, keep[k]);
-        T8 o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float z = (to_f32<T>(xv[i]) - mu[i]) * rs[i] * gm[i] + bt[i];
-          if (silu) z = silu_f(z);
-          o[i] = from_f32<T>(z);
-        }
-        *reinterpret_cast<uint4*>(y + base + (size_t)r * C + ch * 8) = __builtin_bit_cast(uint4, o);
-      }
-    }
-  }
-  if (ok) gn_leave(sync, slot, (unsigned)S, ticket);
-}
-
-// does the one-launch form apply?  (grid small enough for the seam, a thread's rows within GN_HOLD)
-static bool gn_fused_ok(const GnSync* sync, int B, int HW, int C, int G, int S) {
-#ifdef DH_TUNING
-  static const int off = getenv("DH_GN_FUSED") ? !atoi(getenv("DH_GN_FUSED")) : 0;
-  if (off) return false;
-#endif
-  if (!sync || G <= 0 || C % G) return false;
-  const int cpg = C / G, GY = cdiv(G, GN_GB);
-  if ((GN_GB * cpg) % 8 || GN_GB * cpg > 2048 || G % GN_GB) return false;
-  if (B * GY > GN_SEAM_SLOTS || B * GY * S > GN_SEAM_WGS) return false;
-  const int RP = 256 / (GN_GB * cpg / 8), rows = cdiv(HW, S);
-  return cdiv(rows, RP) <= GN_HOLD;
-}
-
 // chunks per thread of the two apply kernels: keep >= ~1024 workgroups in flight
 static inline int gn_apply_iters(size_t blocks_total) {
   size_t it = blocks_total / 1024;
@@ -516,17 +389,9 @@ static inline int gn_apply_iters(size_t blocks_total) {
 
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
-                          int have_partials, GnSync* sync) {
+                          int have_partials) {
   DH_ABLATE(2);
   const int S = gn_slices(HW, B);
-  if (!have_partials && gn_fused_ok(sync, B, HW, C, G, S)) {
-    dim3 g1(S, cdiv(G, GN_GB), B);
-    if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_gn_fused_fwd<f16>), g1, dim3(256), 0, st, (const f16*)x, gamma, beta, scratch, stats, (f16*)y, HW, C, G, S, eps, silu, sync);
-    else
-      hipLaunchKernelGGL((k_gn_fused_fwd<bf16>), g1, dim3(256), 0, st, (const bf16*)x, gamma, beta, scratch, stats, (bf16*)y, HW, C, G, S, eps, silu, sync);
-    return;
-  }
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);
