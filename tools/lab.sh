@@ -300,21 +300,20 @@ cat gpurun_out/scan_small_grids.txt | head -50
 ) }
 # sweep-knobs: A/B of dispatch knobs of the tuning build on the guided step of bench.py
 recipe_sweep_knobs() { (
+# lab.sh sweep-knobs ["KNOB=v [KNOB2=w]" ...]: every point once between two baselines; no arguments = the standing list
 cd ${GRAFT_REPO_ROOT:-$PWD}
-run() { echo "== $*: $(env "$@" timeout 200 python bench.py --no-time-edit --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"; }
+export DIFFHANDLES_LIB=${DIFFHANDLES_LIB:-$PWD/tools/bin/libdiffhandles_hip_tuning.so}
+run() { echo "== $*: $(env $@ timeout 200 python bench.py --no-time-edit --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"; }
+if [ $# -eq 0 ]; then
+  set -- DH_BIG_TILES=96 DH_BIG_TILES=200 DH_SPLITK_MINKT=28 DH_SPLITK_MINKT=40 DH_SPLITK_TARGET=240 DH_SPLITK_TILES=128 \
+         DH_GN_SLICES=24 DH_GN_SLICES=48 DH_ATTN_KS=2 DH_ATTN_KS=4 DH_ATTN_QW=2 DH_ATTN_QW=4
+fi
 run X=0
-run DH_BIG_TILES=96
-run DH_BIG_TILES=200
-run DH_SPLITK_MINKT=28
-run DH_SPLITK_MINKT=40
-run DH_SPLITK_TARGET=240
-run DH_SPLITK_TILES=128
-run DH_GN_SLICES=24
-run DH_GN_SLICES=48
-run DH_ATTN_KS=2
-run DH_ATTN_KS=4
-run DH_ATTN_QW=2
-run DH_ATTN_QW=4
+n=0
+for point in "$@"; do
+  run $point
+  n=$((n + 1)); if [ $((n % 8)) -eq 0 ]; then run X=0; fi
+done
 run X=0
 ) }
 # sweep-modes: per-shape tile / split-K search on the batch-8 and 96x96-latent GEMM shapes
