@@ -239,7 +239,13 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   static_assert(!LNF || (WG == 1 && MODE == GM_DENSE), "the folded LayerNorm needs every k-step of a row in one wave group");
   DH_STAMP(0);
   constexpr int NWV = 4 * MW;                               // waves that share one staged tile
-  constexpr int TM = BM / 64 / MW, TN = BN / 64;
+  // wave arrangement: two wave columns (each wave BN / 2 columns), or ONE when BN is not a multiple of 64 -- the 128x160
+  // tile: four wave rows of 32 x 160 outputs (1 x 5 blocks of 32 x 32 per wave, the wave shape of the eight-wave 128x320 tile)
+  constexpr int WNS = BN % 64 ? 1 : 2, WMS = NWV / WNS;
+  constexpr int RPW = BM / WMS, CPW = BN / WNS;             // rows / columns of the output tile per wave
+  constexpr int TM = RPW / 32, TN = CPW / 32;
+  static_assert(RPW % 32 == 0 && CPW % 32 == 0, "a wave owns whole 32 x 32 blocks");
+  static_assert(WNS == 2 || (!LNF && GLU == 0 && WG == 1 && KG == 1), "the one-column arrangement carries the plain epilogue only");
   constexpr int NPA = BM / 32 / WG / MW, NPB = BN / 32 / WG / MW;     // 1-KiB pieces per wave per stage
   constexpr int NP = NPA + NPB;
   constexpr int STAGE = (BM + BN) * 128;
@@ -249,7 +255,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   const int grp = WG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;     // wave-uniform (feeds m0 through dma16)
   const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
   unsigned char* smem = smem_all + kg * (ST * STAGE);
-  const int wm = wave >> 1, wn = wave & 1, ln = lane & 31, hi = lane >> 5;
+  const int wm = WNS == 2 ? wave >> 1 : wave, wn = WNS == 2 ? wave & 1 : 0, ln = lane & 31, hi = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   int kbeg = blockIdx.z * p.k_per_split;
   int kend = kbeg + p.k_per_split;
@@ -311,7 +317,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
   for (int j = 0; j < NPB; ++j) {
     const int row = 8 * (wave + NWV * (j * WG + grp));     // first row of the piece inside the BN tile
-    b_ptr[j] = Wg + ((size_t)((n0 + row) >> 6) * KT) * 4096 + (size_t)(row & 63) * 64 + lane * 8;
+    b_ptr[j] = Wg + ((size_t)((n0 + row) >> 6) * KT) * 4096 + (size_t)((n0 + row) & 63) * 64 + lane * 8;     // (n0 % 64 = 32 on odd 160-column tiles)
   }
   int tap = 0, c0 = 0;
   if (MODE != GM_DENSE) { const int kt0 = kbeg >> 6, ch = kt0 / 9; tap = kt0 - ch * 9; c0 = ch * BK; }    // conv_k_index order
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   const bool pre_r = PRE && p.R != nullptr && p.pre_r && p.splits == 1 && (WG == 1 || grp == 0) && (KG == 1 || kg == 0);
   // (the eight-wave 128x320 tile holds five column blocks per wave: 80 registers of prefetched bias would push it over the
   //  256-register budget of two waves per SIMD; its bias is read in the epilogue, a warm 1.3 KB vector)
-  constexpr bool PRE_B = PRE && !(MW == 2 && BN == 320);
+  constexpr bool PRE_B = PRE && !(MW == 2 && BN == 320) && WNS == 2;
   const bool pre_b = PRE_B && p.bias != nullptr && p.pre_r && p.splits == 1;
   float4 bpre[PRE_B ? TN : 1][4];
   if (pre_b) {
@@ -401,7 +407,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+        const int n = n0 + wn * CPW + j * 32 + 8 * g + 4 * hi;
         bpre[PRE_B ? j : 0][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
@@ -413,7 +419,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+        const int n = n0 + wn * CPW + j * 32 + 8 * g + 4 * hi;
         lsp[PRE_LN ? j : 0][g] = n < p.N ? *reinterpret_cast<const float4*>(p.ln_s + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         ltp[PRE_LN ? j : 0][g] = n < p.N ? *reinterpret_cast<const float4*>(p.ln_t + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -422,12 +428,12 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   if (pre_r) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int m = m0 + wm * RPW + i * 32 + ln;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+          const int n = n0 + wn * CPW + j * 32 + 8 * g + 4 * hi;
           rpre[i][j][g] = (m < p.M && n < p.N)
                               ? *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n)
                               : make_uint2(0, 0);
@@ -445,8 +451,8 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
   for (int kk = 0; kk < BK / 16; ++kk) {
     const unsigned pc = (unsigned)(((2 * kk + hi) ^ ((ln >> 1) & 7)) << 4);
-    fa_off[kk] = (unsigned)((wm * (BM / (2 * MW)) + ln) * 128) + pc;
-    fb_off[kk] = (unsigned)(BM * 128 + (wn * (BN / 2) + ln) * 128) + pc;
+    fa_off[kk] = (unsigned)((wm * RPW + ln) * 128) + pc;
+    fb_off[kk] = (unsigned)(BM * 128 + (wn * CPW + ln) * 128) + pc;
   }
   int stg = 0;                     // kt % ST
   DH_STAMP(2);
@@ -567,13 +573,13 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
       float var = q * inv_k - mean * mean;
       var = var > 0.f ? var : 0.f;
       const float rstd = rsqrtf(var + p.ln_eps);
-      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int m = m0 + wm * RPW + i * 32 + ln;
       if (blockIdx.y == 0 && wn == 0 && hi == 0 && m < p.M) { p.ln_stats[2 * (size_t)m] = mean; p.ln_stats[2 * (size_t)m + 1] = rstd; }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+          const int n = n0 + wn * CPW + j * 32 + 8 * g + 4 * hi;
           if (n >= p.N) continue;
           float4 sv, tv;
           if (PRE_LN) { sv = lsp[PRE_LN ? j : 0][g]; tv = ltp[PRE_LN ? j : 0][g]; }
@@ -596,11 +602,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     T* Y = reinterpret_cast<T*>(p.glu_y);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int m = m0 + wm * RPW + i * 32 + ln;
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * (BN / 2) + j * 32;
+        const int nb = n0 + wn * CPW + j * 32;
         if (nb >= p.N) continue;
         uint2 w[4];
         float pv[4][4];
@@ -648,11 +654,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     uint4 Hc[TM][TN][2], Gc[TM][TN][2];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int m = m0 + wm * RPW + i * 32 + ln;
       const int mc = m < p.M ? m : p.M - 1;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        int nb = n0 + wn * (BN / 2) + j * 32;
+        int nb = n0 + wn * CPW + j * 32;
         if (nb >= p.N) nb = 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -664,11 +670,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int m = m0 + wm * RPW + i * 32 + ln;
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * (BN / 2) + j * 32;
+        const int nb = n0 + wn * CPW + j * 32;
         if (nb >= p.N) continue;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -710,19 +716,19 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     const bool hb = p.bias != nullptr, hr = p.R != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int m = m0 + wm * RPW + i * 32 + ln;
       if (m >= p.M) continue;
-      T* orow = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n0 + wn * (BN / 2) + 8 * hi;
+      T* orow = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n0 + wn * CPW + 8 * hi;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (n0 + wn * (BN / 2) + j * 32 >= p.N) continue;
+        if (n0 + wn * CPW + j * 32 >= p.N) continue;
         uint2 w[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
           if (hb) {
             float4 b = bpre[PRE_B ? j : 0][g];
-            if (!PRE_B) b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi);
+            if (!PRE_B) b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * CPW + j * 32 + 8 * g + 4 * hi);
             v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
           }
           if (hr) {
@@ -750,11 +756,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   if (p.splits == 1 && p.wide_store) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+      const int m = m0 + wm * RPW + i * 32 + ln;
       if (m >= p.M) continue;                       // both lanes of a pair share m
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * (BN / 2) + j * 32;
+        const int nb = n0 + wn * CPW + j * 32;
         if (nb >= p.N) continue;                    // N is a multiple of 32 on this path
         uint2 w[4];
 #pragma unroll
@@ -776,13 +782,13 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / (2 * MW)) + i * 32 + ln;
+    const int m = m0 + wm * RPW + i * 32 + ln;
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+        const int n = n0 + wn * CPW + j * 32 + 8 * g + 4 * hi;
         if (n >= p.N) continue;
         if (p.splits > 1) {
           float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
@@ -999,7 +1005,7 @@ static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK
     if (glu == 2) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 2>)); return; }
   }
   if (gm == GM_DENSE) {
-    if constexpr (WG == 1 && BN != 320) {      // (the 128x320 tile is never asked for the folded LayerNorm: large batches run it as a kernel)
+    if constexpr (WG == 1 && BN != 320 && BN != 160) {      // (the 128x320 / 128x160 tiles are never asked for the folded LayerNorm)
       if (lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true>)); return; }
     }
     DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW>));
@@ -1065,6 +1071,12 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   // GEGLU epilogues (dense, N a multiple of 128, never split): 64x64, 128x128 or 256x128 tiles only
   const int glu = k.glu_y ? 1 : (k.glub_x ? 2 : 0);
   if (glu && !(BM == 64 && BN == 64)) { BM = mw2 ? 256 : 128; BN = 128; }
+  // 128x160 tiles (four wave rows of 32 x 160) where exactly they fill the chip in ONE round and nothing needs K split: the
+  // batched 32x32-latent level (M = 8192, N = 640: 64 x 4 = 256 workgroups instead of 160 256x128 ones) and its kin
+  DH_KNOB(kT160, "DH_GEMM_T160", 224);              // fewest 128x160 tiles for that (0 = never)
+  const long tiles160 = (long)cdiv(k.M, 128) * (k.N / 160);
+  const bool t160 = kT160 > 0 && k.N % 160 == 0 && !lnf && !glu && !n320 && BM != 64 && tiles160 >= kT160 && tiles160 <= 256;
+  if (t160) { BM = 128; BN = 160; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
   if (k.partial && !lnf && !glu && tiles < kSplitTiles && ktiles >= kSplitMinK) {
@@ -1077,14 +1089,14 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   }
 #ifdef DH_TUNING
   // per-shape policy search (tools/sweep_gemm_shapes.py): DH_GEMM_LOG=1 prints every dispatch, DH_FORCE_TILE / DH_FORCE_SPLITS override
-  // the choice (1 = 64x64, 2 = 128x64 two K groups, 3 = 128x64, 4 = 128x128 eight waves, 5 = 128x128, 6 = 256x128 eight waves)
+  // the choice (1 = 64x64, 2 = 128x64 two K groups, 3 = 128x64, 4 = 128x128 eight waves, 5 = 128x128, 6 = 256x128 eight waves, 7 = 128x160)
   static const int kLog = getenv("DH_GEMM_LOG") ? atoi(getenv("DH_GEMM_LOG")) : 0;
   const int kForceTile = getenv("DH_FORCE_TILE") ? atoi(getenv("DH_FORCE_TILE")) : 0;          // (re-read per dispatch: one process sweeps)
   const int kForceSplits = getenv("DH_FORCE_SPLITS") ? atoi(getenv("DH_FORCE_SPLITS")) : 0;
   int force_tile = 0;
   if (kForceTile && !(k.glu_y || k.glub_x)) {
-    const int fbm = kForceTile == 1 ? 64 : (kForceTile == 6 ? 256 : 128), fbn = (kForceTile <= 3) ? 64 : 128;
-    if (k.N % fbn == 0 || fbn == 64) { BM = fbm; BN = fbn; force_tile = kForceTile; }
+    const int fbm = kForceTile == 1 ? 64 : (kForceTile == 6 ? 256 : 128), fbn = kForceTile == 7 ? 160 : ((kForceTile <= 3) ? 64 : 128);
+    if ((k.N % fbn == 0 || fbn == 64) && !(fbn == 160 && lnf)) { BM = fbm; BN = fbn; force_tile = kForceTile; }
   }
   if (kForceSplits && k.partial && !lnf) {
     splits = kForceSplits;
@@ -1152,9 +1164,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (force_tile == 4) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k);
   else if (force_tile == 5) launch_tile<T, 128, 128, 4, 1, 1, 1>(gm, lnf, grid, st, k);
   else if (force_tile == 6) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k);
+  else if (force_tile == 7) launch_tile<T, 128, 160, 4, 1, 1, 1>(gm, false, grid, st, k);
   else
 #endif
-  if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k, glu);
+  if (t160) launch_tile<T, 128, 160, 4, 1, 1, 1>(gm, false, grid, st, k);
+  else if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k, glu);
   else if (BM == 128 && BN == 128 && (glu || (kMw128 && tiles_per_split >= kMw128))) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k, glu);
   // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
   // x5760: 50.8 -> 42.7 us; 128x128 tiles and short loops lose to the merge; 64x64 tiles: no K grouping wins in situ)

@@ -49,7 +49,8 @@ def run_gemm(dtype, A, lda, W, M, N, K, mode=0, geo=(0, 0, 0, 0, 0, 1, 0), bias=
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (1024, 640, 2560), (256, 1280, 1280), (64, 1280, 1280),
                                      (77, 2560, 1024), (3, 1280, 320), (4096, 2560, 320), (200, 128, 6400),
-                                     (28800, 960, 320), (28700, 320, 640)])      # >= 224 row tiles: the eight-wave 128x320 tile (N = 3 x 320; ragged M)
+                                     (28800, 960, 320), (28700, 320, 640),       # >= 224 row tiles: the eight-wave 128x320 tile (N = 3 x 320; ragged M)
+                                     (8192, 640, 1280), (7300, 640, 320), (2048, 2560, 640)])    # 224..256 tiles of 128x160 (column tiles start inside a 64-row weight tile; ragged M)
 def test_gemm_dense(dtype, M, N, K):
     g = torch.Generator(device=dev()).manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g, device=dev()).to(dtype)
@@ -113,7 +114,8 @@ def nhwc(x):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,Cin,Cout,H,stride,up", [(1, 320, 320, 64, 1, 0), (2, 640, 320, 32, 1, 0), (1, 320, 320, 64, 2, 0),
                                                      (1, 1280, 1280, 8, 1, 1), (2, 64, 128, 16, 1, 0), (1, 1920, 640, 32, 1, 0),
-                                                     (2, 128, 128, 16, 2, 0), (1, 640, 640, 32, 1, 1)])
+                                                     (2, 128, 128, 16, 2, 0), (1, 640, 640, 32, 1, 1),
+                                                     (8, 320, 640, 32, 1, 0)])      # M = 8192, N = 640: the 128x160 tile
 def test_conv3_forward_and_input_gradient(dtype, B, Cin, Cout, H, stride, up):
     g = torch.Generator(device=dev()).manual_seed(Cin + Cout + H + stride + up)
     x = torch.randn(B, Cin, H, H, generator=g, device=dev()).to(dtype)

@@ -10,7 +10,7 @@
 import collections, csv, ctypes, json, os, re, sys
 
 REPS = 4
-TILES = {0: "policy", 1: "64x64", 2: "128x64 kg2", 3: "128x64", 4: "128x128 mw2", 5: "128x128", 6: "256x128 mw2"}
+TILES = {0: "policy", 1: "64x64", 2: "128x64 kg2", 3: "128x64", 4: "128x128 mw2", 5: "128x128", 6: "256x128 mw2", 7: "128x160"}
 
 
 def shapes_from_log(path):
@@ -25,10 +25,12 @@ def shapes_from_log(path):
 def candidates(M, N, K, mode, lnf):
     kt = K // 64
     out = [(0, 0)]
-    for tile in (1, 2, 3, 4, 5, 6):
+    for tile in (1, 2, 3, 4, 5, 6, 7):
         bm = 64 if tile == 1 else (256 if tile == 6 else 128)
-        bn = 64 if tile <= 3 else 128
-        if N % bn and bn == 128:
+        bn = 160 if tile == 7 else (64 if tile <= 3 else 128)
+        if N % bn and bn != 64:
+            continue
+        if tile == 7 and lnf:
             continue
         if bm == 256 and M <= 128:
             continue
@@ -121,8 +123,10 @@ def parse(manifest, trace):
         best = min([c for c in cands if c[1] != 0] or [pol])
         tot_pol += pol[0] * key[4]; tot_best += min(best[0], pol[0]) * key[4]
         flag = "  <<<" if best[0] < 0.9 * pol[0] else ""
+        t160 = min([c for c in cands if c[1] == 7] or [None], key=lambda c: c[0] if c else 0)
+        s160 = f"   128x160: {t160[0]:7.1f} us (splits {t160[2]})" if t160 else ""
         print(f"M={key[0]:5d} N={key[1]:5d} K={key[2]:6d} mode={key[3]} x{key[4]:3d}: policy {pol[0]:7.1f} us   best {best[0]:7.1f} us "
-              f"({TILES[best[1]]}, splits {best[2]}){flag}")
+              f"({TILES[best[1]]}, splits {best[2]}){flag}{s160}")
     print(f"weighted total: policy {tot_pol:.0f} us, per-shape best {tot_best:.0f} us ({100 * (1 - tot_best / tot_pol):.1f} % less)")
 
 
