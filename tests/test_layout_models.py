@@ -98,3 +98,45 @@ def test_conv_k_index_is_a_bijection_with_taps_adjacent():
         for c0 in range(0, C, 64):
             tiles = {idx[(t, c)] >> 6 for c in range(c0, c0 + 64)}
             assert tiles == {(c0 >> 6) * 9 + t}
+
+
+def _wt_index(n, k, K):
+    r, c = n & 63, (k & 63) >> 3
+    return ((n >> 6) * (K >> 6) + (k >> 6)) * 4096 + r * 64 + ((c ^ ((r >> 1) & 7)) << 3) + (k & 7)
+
+
+def test_gemm_128x160_tile_pieces_and_wave_blocks():
+    """csrc/gemm.hip, the 128x160 tile (one wave column: BN is not a multiple of 64).  (i) W pieces: wave w fetches the 1-KiB
+    pieces of rows 8 (w + 4 j) .. + 7 of the 160-row column tile, j = 0..4, from the tiled weight layout at
+    ((n0 + row) >> 6) * KT * 4096 + ((n0 + row) & 63) * 64 + lane * 8 -- n0 = 160 * tile is 32 mod 64 on odd tiles -- and the DMA
+    puts lane l of a piece at LDS row (row + (l >> 3)), 16-byte position l & 7: the staged tile must hold element (n, k) of the
+    column tile at row n - n0, chunk ((k & 63) >> 3) ^ ((row >> 1) & 7), which is where the fragment reads look for it.
+    (ii) the four waves' 1 x 5 blocks of 32 x 32 tile the 128 x 160 outputs exactly once."""
+    K, kt = 256, 2                                  # K tile 2 of a 4-tile K
+    KT = K >> 6
+    for tile in range(4):                           # N = 640
+        n0 = 160 * tile
+        staged = {}
+        for w in range(4):
+            for j in range(5):
+                row = 8 * (w + 4 * j)
+                for lane in range(64):
+                    src = ((n0 + row) >> 6) * KT * 4096 + ((n0 + row) & 63) * 64 + lane * 8 + kt * 4096
+                    lds_row, pos = row + (lane >> 3), lane & 7
+                    assert (lds_row, pos) not in staged
+                    staged[(lds_row, pos)] = src
+        assert len(staged) == 160 * 8
+        for r in range(160):
+            for c in range(8):
+                k = 64 * kt + 8 * c
+                pos = c ^ ((r >> 1) & 7)            # fragment reads: chunk c of row r sits at c ^ ((r >> 1) & 7)
+                assert staged[(r, pos)] == _wt_index(n0 + r, k, K), (tile, r, c)
+    owned = set()
+    for w in range(4):                              # wm = w, wn = 0: rows 32 w .. + 31, five column blocks
+        for j in range(5):
+            for ln in range(32):
+                for col in range(32):
+                    key = (32 * w + ln, 32 * j + col)
+                    assert key not in owned
+                    owned.add(key)
+    assert len(owned) == 128 * 160
