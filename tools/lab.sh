@@ -250,7 +250,7 @@ DH_LATENT=96 DH_DTYPE=bf16 rocprofv3 --kernel-trace --output-format csv -d gpuru
 f=$(ls gpurun_out/l96/*/*kernel_trace.csv | head -1)
 python3 tools/trace_by_grid.py $f 300 > gpurun_out/l96/by_grid.txt
 rm -f $f
-tail -3 gpurun_out/b8/log.txt gpurun_out/l96/log.txt
+tail -n 3 gpurun_out/b8/log.txt; tail -n 3 gpurun_out/l96/log.txt
 ) }
 # prof-invert: kernel accounting of the per-image phase (null-text inversion + initial inference)
 recipe_prof_invert() { (
