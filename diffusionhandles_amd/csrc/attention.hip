@@ -649,21 +649,28 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
 // 128 keys x KS query ranges per block; the groups' dK / dV partial sums are merged through LDS.
 // (capping this kernel at 168 VGPRs -- three waves per SIMD -- spills 216 bytes per lane into the loop: guided step -5 %,
 // profiles/r03_ab_dkv_occ.txt; a four-group variant needs the register diet first)
-template <class T, int KS, int QW>
+// DB (round 4, like k_attn_bwd_dq): the Q / dO tiles are dense source-swizzled tiles filled by LDS-DMA, double-buffered per query
+// group -- no staging registers (24 - 32 VGPRs), no commit phase (1 150 of a tile's 4 800 cycles by the s_memtime stamps,
+// profiles/r04_dkv_timeline_after_prefetch_fix.txt), ONE barrier per query tile, and none of the bank conflicts of the padded
+// register-staged tiles (SQ_LDS_BANK_CONFLICT 0.21 of this kernel's LDS-active cycles, profiles/r04_pmc_gemm_sq.txt).  The tile's
+// 64 lse / delta values still travel through a register of the group's first wave, into a statistics buffer per tile buffer.
+template <class T, int KS, int QW, bool DB>
 __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long ldq, const T* k, const T* v, long ldk, const T* d_o,
                                                            long lddo, const float* lse, const float* delta, T* dk, T* dv,
                                                            long lddk, int H, int Nq, int Nk, float* qpart, int qchunks) {
   // qchunks > 1 (cross-attention: one key block per head, thousands of queries): blockIdx.x is a QUERY chunk and the
   // block leaves f32 partial dK / dV in qpart [chunk][b][h][dK|dV][32*QW keys][64]; k_attn_dkv_reduce sums the chunks
-  constexpr int GRP = 2 * TILE + 256;     // shorts per group: Q tile, dO tile, 64 lse + 64 delta (f32)
-  __shared__ __attribute__((aligned(16))) unsigned short smem[KS * GRP];
+  constexpr int NBUF = DB ? 2 : 1;
+  constexpr int TSZ = DB ? DTILE : TILE;        // halves per staged tile
+  constexpr int GRP = NBUF * (2 * TSZ + 256);   // shorts per group: per buffer a Q tile, a dO tile, 64 lse + 64 delta (f32)
+  __shared__ __attribute__((aligned(1024))) unsigned short smem[KS * GRP];
   constexpr int GT = 64 * QW;                 // threads of one wave group (QW waves of 32 rows each)
   const int ks = threadIdx.x / GT, tid = threadIdx.x - ks * GT;
   const int lane = tid & 63, wave = tid >> 6, ln = lane & 31, hi = lane >> 5, t16 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
-  unsigned short* sQ = smem + ks * GRP;
-  unsigned short* sdO = sQ + TILE;
-  float* sLse = reinterpret_cast<float*>(sdO + TILE);
+  unsigned short* sQ = smem + ks * GRP;        // buffer p: Q at sQ + 2 p TSZ, dO one tile behind it; statistics behind all tiles
+  unsigned short* sdO = sQ + TSZ;
+  float* sLse = reinterpret_cast<float*>(sQ + NBUF * 2 * TSZ);      // buffer p: + 128 p
   float* sDel = sLse + 64;
   const int chunk = qchunks > 1 ? blockIdx.x : 0;
   const long krow = (long)(qchunks > 1 ? 0 : blockIdx.x) * (32 * QW) + wave * 32 + ln;
@@ -699,51 +706,101 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
       asm volatile("global_load_dword %0, %1, off" : "=&v"(del_n) : "v"(pd) : "memory");
     }
   };
+  // DB: the 16 one-KiB pieces of a Q / dO tile pair (8 rows each) are issued by the group's waves in turn (k_attn_fwd has the layout)
+  const unsigned lds_grp = DB ? (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + ks * GRP * 2 : 0u;
+  const int d_row = lane >> 3;
+  const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);      // chunk for even pieces; odd: ^ 1
+  const T* d_zero = reinterpret_cast<const T*>(g_attn_zero_page) + (lane & 7) * 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int q0n, int buf) {
+#pragma unroll
+    for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
+      const int p = wave_u + j * QW;                 // wave-uniform
+      if (p < 16) {
+        const int pp = p & 7;
+        const long r = (long)q0n + 8 * pp + d_row;
+        const T* src = p < 8 ? qp + r * ldq + ((d_c0 ^ (pp & 1)) << 3) : dop + r * lddo + ((d_c0 ^ (pp & 1)) << 3);
+        attn_dma16(r < Nq ? src : d_zero, __builtin_amdgcn_readfirstlane(lds_grp + (unsigned)(buf * 2 * TSZ * 2 + p * 1024)));
+      }
+    }
+  };
   if (t_begin < t_end) {
-    fetch_tile<T, GT>(qp, ldq, t_begin * 64, Nq, rq, tid);
-    fetch_tile<T, GT>(dop, lddo, t_begin * 64, Nq, rdo, tid);
+    if (DB) {
+      dma_tile(t_begin * 64, 0);
+    } else {
+      fetch_tile<T, GT>(qp, ldq, t_begin * 64, Nq, rq, tid);
+      fetch_tile<T, GT>(dop, lddo, t_begin * 64, Nq, rdo, tid);
+    }
     fetch_stats((long)t_begin * 64);
   }
+  // dense-tile fragment addressing (per lane, hoisted)
+  const int xk = hi ^ dswz(ln);
+  const int d_rl = 4 * hi + (t16 >> 2), d_cl = 2 * ((lane >> 4) & 1) + ((t16 & 3) >> 1);
+  const int d_lo = d_cl ^ dswz(d_rl), d_up = d_cl ^ dswz(d_rl + 8), d_within = 4 * (t16 & 1);
   DKV_STAMP(0);
   for (int it = 0; it < tps; ++it) {
     const int q0 = (t_begin + it) * 64;
     const bool act = t_begin + it < t_end;
+    const int buf = DB ? (it & 1) : 0;
     if (it == 2) DKV_STAMP(1);
     if (it == 3) DKV_STAMP(6);
-    lds_barrier();
-    if (it == 2) DKV_STAMP(2);
-    if (act) {
-      tile_wait<GT>(rq, rdo);
-      if (it == 2) DKV_STAMP(8);
+    if (DB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of tile `it` (and its statistics) have landed ...
       asm volatile("" : "+v"(lse_n), "+v"(del_n));
-      commit_tile<GT>(rq, sQ, tid);
-      commit_tile<GT>(rdo, sdO, tid);
-      if (it == 2) DKV_STAMP(9);
-      if (tid < 64) {
+      if (act && tid < 64) {
         const bool qin = q0 + tid < Nq;
-        sLse[tid] = qin ? lse_n * LOG2E : INFINITY;
-        sDel[tid] = qin ? del_n : 0.f;
+        sLse[buf * 128 + tid] = qin ? lse_n * LOG2E : INFINITY;
+        sDel[buf * 128 + tid] = qin ? del_n : 0.f;
       }
-      if (t_begin + it + 1 < t_end) {
-        fetch_tile<T, GT>(qp, ldq, q0 + 64, Nq, rq, tid);
-        fetch_tile<T, GT>(dop, lddo, q0 + 64, Nq, rdo, tid);
+      __syncthreads();                                             // ... and so have everyone's; tile it-1's buffer is free
+      if (it == 2) { DKV_STAMP(2); DKV_STAMP(8); DKV_STAMP(9); DKV_STAMP(3); DKV_STAMP(4); }
+      if (act && t_begin + it + 1 < t_end) {
+        dma_tile(q0 + 64, (it + 1) & 1);
         fetch_stats((long)q0 + 64);
       }
+      if (!act) continue;
+    } else {
+      lds_barrier();
+      if (it == 2) DKV_STAMP(2);
+      if (act) {
+        tile_wait<GT>(rq, rdo);
+        if (it == 2) DKV_STAMP(8);
+        asm volatile("" : "+v"(lse_n), "+v"(del_n));
+        commit_tile<GT>(rq, sQ, tid);
+        commit_tile<GT>(rdo, sdO, tid);
+        if (it == 2) DKV_STAMP(9);
+        if (tid < 64) {
+          const bool qin = q0 + tid < Nq;
+          sLse[tid] = qin ? lse_n * LOG2E : INFINITY;
+          sDel[tid] = qin ? del_n : 0.f;
+        }
+        if (t_begin + it + 1 < t_end) {
+          fetch_tile<T, GT>(qp, ldq, q0 + 64, Nq, rq, tid);
+          fetch_tile<T, GT>(dop, lddo, q0 + 64, Nq, rdo, tid);
+          fetch_stats((long)q0 + 64);
+        }
+      }
+      if (it == 2) DKV_STAMP(3);
+      lds_barrier();
+      if (it == 2) DKV_STAMP(4);
+      if (!act) continue;
     }
-    if (it == 2) DKV_STAMP(3);
-    lds_barrier();
-    if (it == 2) DKV_STAMP(4);
-    if (!act) continue;
+    const unsigned short* tQ = sQ + buf * 2 * TSZ;
+    const unsigned short* tdO = tQ + TSZ;
+    const unsigned short* qtr = DB ? tQ + d_rl * 64 : qt;          // transposed-read bases of this lane
+    const unsigned short* dotr = DB ? tdO + d_rl * 64 : dot;
+    const float* tLse = sLse + buf * 128;
+    const float* tDel = sDel + buf * 128;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       if (it == 2 && t2 == 1) DKV_STAMP(5);
-      v16f s = tile_times_frags<T>(sQ, t2 * 32, ln, hi, kf);      // rows = queries, col = key
-      const v16f dp = tile_times_frags<T>(sdO, t2 * 32, ln, hi, vf);
+      v16f s = DB ? dtile_times_frags<T>(tQ, t2 * 32, ln, xk, kf) : tile_times_frags<T>(tQ, t2 * 32, ln, hi, kf);      // rows = queries, col = key
+      const v16f dp = DB ? dtile_times_frags<T>(tdO, t2 * 32, ln, xk, vf) : tile_times_frags<T>(tdO, t2 * 32, ln, hi, vf);
       v16f ds;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 l4 = *reinterpret_cast<const float4*>(&sLse[t2 * 32 + 8 * g + 4 * hi]);
-        const float4 d4 = *reinterpret_cast<const float4*>(&sDel[t2 * 32 + 8 * g + 4 * hi]);
+        const float4 l4 = *reinterpret_cast<const float4*>(&tLse[t2 * 32 + 8 * g + 4 * hi]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&tDel[t2 * 32 + 8 * g + 4 * hi]);
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -758,8 +815,10 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
         const uint4 pf = pack8<T>(s, st), dsf = pack8<T>(ds, st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dvacc[dt] = Mma<T>::run(tr_frag(dot, dt * 32, t2 * 32 + 16 * st), pf, dvacc[dt]);
-          dkacc[dt] = Mma<T>::run(tr_frag(qt, dt * 32, t2 * 32 + 16 * st), dsf, dkacc[dt]);
+          dvacc[dt] = Mma<T>::run(DB ? dtr_frag(dotr, d_lo, d_up, d_within, dt, t2 * 32 + 16 * st) : tr_frag(dotr, dt * 32, t2 * 32 + 16 * st), pf,
+                                  dvacc[dt]);
+          dkacc[dt] = Mma<T>::run(DB ? dtr_frag(qtr, d_lo, d_up, d_within, dt, t2 * 32 + 16 * st) : tr_frag(qtr, dt * 32, t2 * 32 + 16 * st), dsf,
+                                  dkacc[dt]);
         }
       }
     }
@@ -903,11 +962,15 @@ static void attn_dq_launch(int B, hipStream_t st, const void* q, long ldq, const
                        (const T*)k, (const T*)v, ldk, (const T*)o, ldo, (const T*)d_o, lddo, lse, delta, (T*)dq, lddq, H, Nq, Nk);
   }
 }
+#ifndef DH_DKV_DB
+#define DH_DKV_DB 1       // 0: the register-staged tiles (same-box A/B builds, tools/lab.sh build-tuning with DH_DEFS=-DDH_DKV_DB=0)
+#endif
 template <class T, int KS, int QW>
 static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, const void* k, const void* v, long ldk,
                             const void* d_o, long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk,
                             int H, int Nq, int Nk, float* qpart, int qchunks) {
-  hipLaunchKernelGGL((k_attn_bwd_dkv<T, KS, QW>), dim3(qchunks > 1 ? qchunks : cdiv(Nk, 32 * QW), H, B), dim3(64 * QW * KS), 0,
+  // (the kernel's registers hold it to one workgroup per CU whatever the LDS: the double-buffered form serves every grid)
+  hipLaunchKernelGGL((k_attn_bwd_dkv<T, KS, QW, DH_DKV_DB != 0>), dim3(qchunks > 1 ? qchunks : cdiv(Nk, 32 * QW), H, B), dim3(64 * QW * KS), 0,
                      st, (const T*)q, ldq, (const T*)k, (const T*)v, ldk, (const T*)d_o, lddo, lse, delta, (T*)dk, (T*)dv, lddk,
                      H, Nq, Nk, qpart, qchunks);
   if (qchunks > 1) {
