@@ -170,6 +170,44 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// The issue of a tile's DMA pieces is VALU / SALU work of the waves that also run the MFMAs, and on a SIMD the two add up: with the
+// address of every piece computed per lane in 64 bits (row * pitch, tail select, readfirstlane of the LDS address) a piece cost
+// ~38 instructions, ~150 cycles -- ~900 of a lone wave's 4 300 cycles per dK/dV tile by the s_memtime stamps
+// (profiles/r04_ab_attn_dkv_dma.txt).  A tile that lies wholly inside its matrix needs none of it: the per-lane part of a piece's
+// address (row-in-tile * pitch + swizzled chunk) is a 32-bit offset computed ONCE per kernel, the tile's base is a scalar, and
+// global_load_lds takes exactly that pair (SGPR base + VGPR offset).  Ragged last tiles keep the per-lane form.
+template <int QW> struct DmaPieces { unsigned voff[(16 + QW - 1) / QW]; };
+template <int QW>
+__device__ __forceinline__ void dma_pieces_init(DmaPieces<QW>& d, int wave_u, int lane, long ld_a, long ld_b) {
+  const int d_row = lane >> 3;
+  const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);
+#pragma unroll
+  for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
+    const int p = wave_u + j * QW, pp = p & 7;
+    d.voff[j] = (unsigned)(((long)(8 * pp + d_row) * (p < 8 ? ld_a : ld_b) + ((d_c0 ^ (pp & 1)) << 3)) * 2);
+  }
+}
+__device__ __forceinline__ void attn_dma16_s(const void* base, unsigned voff, unsigned lds) {
+  // (the operands ARE wave-uniform; the readfirstlanes tell the compiler so -- an "s" constraint alone does not)
+  const unsigned long long b64 = (unsigned long long)base;
+  const unsigned long long sbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64) |
+                                   ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32)) << 32);
+  const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
+}
+// the 16 pieces of a tile pair (A rows 0-63 then B rows 0-63) whose 64 rows all exist; base_a / base_b: row 0 of the tile (+ head
+// column), lds_tile: byte address of the pair's buffer -- all wave-uniform
+template <int QW>
+__device__ __forceinline__ void dma_tile_full(const DmaPieces<QW>& d, int wave_u, const void* base_a, const void* base_b,
+                                              unsigned lds_tile) {
+#pragma unroll
+  for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
+    const int p = wave_u + j * QW;
+    if (p < 16) attn_dma16_s(p < 8 ? base_a : base_b, d.voff[j], lds_tile + (unsigned)(p * 1024));
+  }
+}
 // acc = sum_kk mfma(A = rows (rowbase + lane&31) of a dense tile, B = register fragments); xk = hi ^ dswz(lane & 31)
 template <class T>
 __device__ __forceinline__ v16f dtile_times_frags(const unsigned short* tile, int rowbase, int ln, int xk, const uint4 (&f)[4]) {
@@ -294,7 +332,13 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_fwd(const T* q, long ldq,
   const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);      // chunk for even pieces; odd: ^ 1
   const T* d_zero = reinterpret_cast<const T*>(g_attn_zero_page) + (lane & 7) * 8;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  DmaPieces<QW> dpc;
+  if (DB) dma_pieces_init<QW>(dpc, wave_u, lane, ldk, ldk);
   auto dma_tile = [&](int key0, int buf) {
+    if (key0 + 64 <= Nk) {                           // (wave-uniform) every row of the tile exists: scalar base + hoisted lane offsets
+      dma_tile_full<QW>(dpc, wave_u, kp + (long)key0 * ldk, vp + (long)key0 * ldk, lds_grp + (unsigned)(buf * 2 * TSZ * 2));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
       const int p = wave_u + j * QW;                 // wave-uniform
@@ -533,7 +577,13 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dq(const T* q, long l
   const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);      // chunk for even pieces; odd: ^ 1
   const T* d_zero = reinterpret_cast<const T*>(g_attn_zero_page) + (lane & 7) * 8;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  DmaPieces<QW> dpc;
+  if (DB) dma_pieces_init<QW>(dpc, wave_u, lane, ldk, ldk);
   auto dma_tile = [&](int key0, int buf) {
+    if (key0 + 64 <= Nk) {                           // (wave-uniform) every row of the tile exists: scalar base + hoisted lane offsets
+      dma_tile_full<QW>(dpc, wave_u, kp + (long)key0 * ldk, vp + (long)key0 * ldk, lds_grp + (unsigned)(buf * 2 * TSZ * 2));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
       const int p = wave_u + j * QW;                 // wave-uniform
@@ -712,7 +762,13 @@ __global__ void __launch_bounds__(64 * QW * KS) k_attn_bwd_dkv(const T* q, long 
   const int d_c0 = (lane & 7) ^ ((((lane >> 4) >> 1) & 1) << 1 | ((lane >> 4) & 1) << 2);      // chunk for even pieces; odd: ^ 1
   const T* d_zero = reinterpret_cast<const T*>(g_attn_zero_page) + (lane & 7) * 8;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  DmaPieces<QW> dpc;
+  if (DB) dma_pieces_init<QW>(dpc, wave_u, lane, ldq, lddo);
   auto dma_tile = [&](int q0n, int buf) {
+    if (q0n + 64 <= Nq) {                            // (wave-uniform) every row of the tile exists: scalar base + hoisted lane offsets
+      dma_tile_full<QW>(dpc, wave_u, qp + (long)q0n * ldq, dop + (long)q0n * lddo, lds_grp + (unsigned)(buf * 2 * TSZ * 2));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < (16 + QW - 1) / QW; ++j) {
       const int p = wave_u + j * QW;                 // wave-uniform
