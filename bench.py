@@ -86,6 +86,8 @@ def launch_ranks(args, argv, script=None, plan=None):
     launch_timeout = getattr(args, "launch_timeout", 0) or 0
     # the rendezvous port is found by bind / close, so another process can take it before rank 0 listens: a job whose rank 0
     # (the rendezvous host) fails inside the first seconds is started again on a fresh port (twice at most)
+    import threading
+    worst = 0
     for attempt in range(3):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -97,34 +99,84 @@ def launch_ranks(args, argv, script=None, plan=None):
                                    "launch_timeout_s": launch_timeout}, **(plan or {}))))
             return 0
         started = time.time()
-        procs = [subprocess.Popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL) for r, e in enumerate(envs)]
+        # rank 0's stderr is passed through AND its tail kept: a retry needs evidence that the port was taken
+        procs = [subprocess.Popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL,
+                                  stderr=subprocess.PIPE if r == 0 else None) for r, e in enumerate(envs)]
         rank0 = procs[0]
-        rank0_failed_at = None
+        tail = bytearray()
+
+        def tee(pipe=rank0.stderr):
+            for chunk in iter(lambda: pipe.read1(65536), b""):
+                sys.stderr.buffer.write(chunk)
+                sys.stderr.buffer.flush()
+                tail.extend(chunk)
+                del tail[:-65536]
+        th = threading.Thread(target=tee, daemon=True)
+        th.start()
         rcs = []
         deadline = started + launch_timeout if launch_timeout > 0 else None      # overall limit: a rank that hangs ends the job
         first_failure = None
+        timed_out = False
         while procs:
             for p in list(procs):
                 rc = p.poll()
                 if rc is not None:
                     procs.remove(p)
                     rcs.append(rc)
-                    if rc != 0 and p is rank0 and rank0_failed_at is None:
-                        rank0_failed_at = time.time()
                     if rc != 0 and first_failure is None:   # a rank died: the others wait at a barrier; give them a minute, then end them
                         first_failure = time.time()
-                        deadline = min(deadline, first_failure + 60) if deadline else first_failure + 60
-            if deadline is not None and time.time() > deadline:
+                        if p is rank0 and port_clash(bytes(tail)):
+                            deadline = first_failure         # the rendezvous never existed: nothing to wait for
+                        else:
+                            deadline = min(deadline, first_failure + 60) if deadline else first_failure + 60
+            if deadline is not None and time.time() > deadline and procs:
                 for p in procs:
                     p.kill()
-                if first_failure is None:
-                    rcs.append(124)                          # timed out (the value `timeout` returns)
+                if first_failure is None and not timed_out:
+                    timed_out = True
+                    rcs.append(124)                          # timed out (the value `timeout` returns), once
             time.sleep(0.2)
+        th.join(timeout=5)
         worst = max((abs(rc) for rc in rcs), default=0)
-        if worst != 0 and rank0_failed_at is not None and rank0_failed_at - started < 20 and attempt < 2:
-            continue                                         # rank 0 (the rendezvous host) died at once: most likely the port; once more on another
+        if worst != 0 and rank0.returncode not in (0, None) and port_clash(bytes(tail)) and attempt < 2:
+            continue                                         # rank 0 could not listen on the port found by bind / close: once more on another
         return worst
     return worst
+
+
+def port_clash(stderr_tail):
+    """Evidence in rank 0's stderr that the rendezvous port was taken between the parent's bind / close and rank 0's listen --
+    the only failure the launcher starts the job again for (a bad argument, an import error or an OOM is final)."""
+    t = stderr_tail.lower()
+    return b"eaddrinuse" in t or b"address already in use" in t
+
+
+class Sections:
+    """Secondary measurements never cost the headline line, but they do not fail silently either: every exception is kept
+    (section name + message), the JSON line carries them as a top-level "errors" list and the process exits non-zero AFTER
+    printing the line when the list is not empty (finish)."""
+
+    def __init__(self):
+        self.errors = []
+
+    def note(self, name, exc):
+        self.errors.append({"section": name, "error": f"{type(exc).__name__}: {exc}"})
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+    def run(self, name, fn):
+        """fn() or, when it raises, {"error": ...} with the failure recorded."""
+        if os.environ.get("DH_BENCH_INJECT_FAIL") == name:      # test hook (tests/test_bench_errors.py, the GPU suite)
+            return self.note(name, RuntimeError("injected failure (DH_BENCH_INJECT_FAIL)"))
+        try:
+            return fn()
+        except Exception as exc:          # noqa: BLE001 - never lose the headline line to a secondary measurement
+            return self.note(name, exc)
+
+    def finish(self, out, fd):
+        """Write the one JSON line (with "errors") to fd; returns the process exit code: 0, or 3 when a section failed."""
+        out["errors"] = list(self.errors)
+        os.write(fd, (json.dumps(out) + "\n").encode())
+        return 3 if self.errors else 0
 
 
 def cpu_baseline():
@@ -423,14 +475,14 @@ def main():
                             "images bit-identical to the one-stream batches; MAX over ranks"}
                 del imgs2
 
+    sections = Sections()
     if K > 1:
         if world > 1:
             batched_section()          # every rank meets the same barriers: an exception must end the job, not leave ranks waiting
         else:
-            try:
-                batched_section()
-            except Exception as exc:          # noqa: BLE001 - never lose the headline line to a secondary measurement
-                edits_info = {"error": f"{type(exc).__name__}: {exc}"}
+            failed = sections.run("batched_section", batched_section)
+            if failed is not None:
+                edits_info = failed
 
     # ---- secondary measurements (rank 0).  They never gate the headline line: a failure is reported in place of the numbers.
     def hbm_records(gd_, st_, depth_, bg_, mask_, res):
@@ -438,6 +490,7 @@ def main():
             for _ in range(3):
                 fn()
             if graph:       # replay through a captured graph: device time of the launches, no host gaps between them
+                eager = fn
                 try:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
@@ -445,8 +498,11 @@ def main():
                         fn()
                     fn = g.replay
                     fn()
-                except Exception:
-                    pass
+                    graphed.append(True)
+                except Exception as exc:          # noqa: BLE001 - the record says so ("graph": false) and the failure is listed
+                    sections.note("hbm_records.graph_capture", exc)
+                    fn = eager
+                    graphed.append(False)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(n):
@@ -456,6 +512,7 @@ def main():
             return e0.elapsed_time(e1) / n * 1e-3
 
         out = []
+        graphed = []
         with torch.no_grad(), gd_.on_stream():
             cur = [o[1] for o in st_.orig]                    # another timestep's activations stand in for "current"
             for layers, tag in (((2,), "t%3==0: act2"), ((1,), "t%3==1: act1"), ((1, 2), "t%3==2: act1+act2")):
@@ -468,7 +525,7 @@ def main():
                 nbytes = sum(3 * cur[k].numel() * cur[k].element_size() for k in layers)
                 out.append({"kernel": f"guidance energy fwd+bwd ({tag}) at {res}x{res}", "bound": "hbm", "bytes": nbytes,
                             "us": round(sec * 1e6, 2), "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK,
-                            "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK, 4)})
+                            "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK, 4), "graph": bool(graphed and graphed[-1])})
             tfs8 = [(TRANSFORMS[i % 8][0], Y, torch.tensor(TRANSFORMS[i % 8][1])) for i in range(8)]
             sec = timed(lambda: reproject_edits(depth_, bg_, mask_, gd_.get_depth_intrinsics(), tfs8, device_correspondences=True), n=5)
             per_edit = 9e6 * (res / 512.0) ** 2
@@ -480,54 +537,49 @@ def main():
 
     hbm = None
     if rank == 0:
-        try:
-            hbm = hbm_records(gd, st, depth, bg_depth, mask, args.res)
-        except Exception as exc:          # noqa: BLE001
-            hbm = {"error": f"{type(exc).__name__}: {exc}"}
+        hbm = sections.run("hbm_records", lambda: hbm_records(gd, st, depth, bg_depth, mask, args.res))
 
     # one whole edit: transform_foreground = re-projection + 38 guided + 12 unguided steps + AutoencoderKL decode
+    def whole_edit():
+        rot = dict(rot_angle=ang, rot_axis=Y, translation=torch.tensor(tr))
+        with torch.no_grad():
+            dh.transform_foreground(depth, prompt, mask, bg_depth, uncond, init_noise, acts, **rot)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            dh.transform_foreground(depth, prompt, mask, bg_depth, uncond, init_noise, acts, **rot)
+            torch.cuda.synchronize()
+            te = time.perf_counter() - te
+            lat_img = torch.randn(1, 4, lat, lat, device=dev)
+            gd.decode_latent_image(lat_img)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            gd.decode_latent_image(lat_img)
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td
+        per_image = phases["inversion_s"] + phases["initial_inference_s"]
+        phases.update({"edit_s": round(te, 3), "vae_decode_s": round(td, 4),
+                       "edits_per_s_identity_cached": round(1.0 / te, 4),
+                       "edits_per_s_with_inversion_and_initial_inference": round(1.0 / (te + per_image), 4),
+                       "edit_what": "transform_foreground: z-buffer + index maps + 38 guided + 12 unguided steps + AutoencoderKL "
+                                    "decode (the SD VAE decoder on the engine's kernels, csrc/vae_engine.cpp, random weights)"})
+
     if rank == 0 and phases is not None:
-        try:
-            rot = dict(rot_angle=ang, rot_axis=Y, translation=torch.tensor(tr))
-            with torch.no_grad():
-                dh.transform_foreground(depth, prompt, mask, bg_depth, uncond, init_noise, acts, **rot)
-                torch.cuda.synchronize()
-                te = time.perf_counter()
-                dh.transform_foreground(depth, prompt, mask, bg_depth, uncond, init_noise, acts, **rot)
-                torch.cuda.synchronize()
-                te = time.perf_counter() - te
-                lat_img = torch.randn(1, 4, lat, lat, device=dev)
-                gd.decode_latent_image(lat_img)
-                torch.cuda.synchronize()
-                td = time.perf_counter()
-                gd.decode_latent_image(lat_img)
-                torch.cuda.synchronize()
-                td = time.perf_counter() - td
-            per_image = phases["inversion_s"] + phases["initial_inference_s"]
-            phases.update({"edit_s": round(te, 3), "vae_decode_s": round(td, 4),
-                           "edits_per_s_identity_cached": round(1.0 / te, 4),
-                           "edits_per_s_with_inversion_and_initial_inference": round(1.0 / (te + per_image), 4),
-                           "edit_what": "transform_foreground: z-buffer + index maps + 38 guided + 12 unguided steps + AutoencoderKL "
-                                        "decode (the SD VAE decoder on the engine's kernels, csrc/vae_engine.cpp, random weights)"})
-        except Exception as exc:          # noqa: BLE001
-            phases["error"] = f"{type(exc).__name__}: {exc}"
+        failed = sections.run("phases.whole_edit", whole_edit)
+        if failed is not None:
+            phases["error"] = failed["error"]
 
     # ---- BASELINE config 5: 768x768, bf16 U-Net + f32 guidance (energy, cotangent seed, latent gradient and update in f32) ----
     res768 = None
     if rank == 0 and args.res768 and args.res == 512:
-        try:
-            del dh, gd, st, acts
-            torch.cuda.empty_cache()
-            res768 = bench_768(conf, dev, prompt, TRANSFORMS, Y, max(5, args.steps // 2))
-        except Exception as exc:          # noqa: BLE001
-            res768 = {"error": f"{type(exc).__name__}: {exc}"}
+        del dh, gd, st, acts
+        torch.cuda.empty_cache()
+        res768 = sections.run("res768_bf16", lambda: bench_768(conf, dev, prompt, TRANSFORMS, Y, max(5, args.steps // 2)))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.res == 512:
-        try:
-            cpu = cpu_baseline()
-        except Exception as exc:          # noqa: BLE001
-            cpu = {"error": f"{type(exc).__name__}: {exc}"}
+        cpu = sections.run("cpu_baseline", cpu_baseline)
+        if cpu is not None and "error" in cpu.get("pieces", {}):
+            sections.errors.append({"section": "cpu_baseline.pieces", "error": cpu["pieces"]["error"]})
 
     if rank == 0:
         value = world * args.steps / elapsed
@@ -544,9 +596,13 @@ def main():
             "edits": edits_info, "res768_bf16": res768,
         }
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        rc = sections.finish(out, json_fd)
+    else:
+        rc = 0
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)       # after the line: a broken secondary record (config 3 / 5, HBM kernels, CPU baseline) is not a pass
 
 
 def bench_768(conf, dev, prompt, TRANSFORMS, Y, steps):

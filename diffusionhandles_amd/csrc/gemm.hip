@@ -21,7 +21,7 @@
 
 #include <hip/hip_ext.h>
 
-#include "unet_kernels.h"
+#include "gemm_k.h"
 
 namespace dh {
 
@@ -35,55 +35,11 @@ struct GemmProf {
   hipEvent_t e0 = nullptr, e1 = nullptr;      // start / stop events of the launch being issued (hipExtLaunchKernelGGL)
 };
 static GemmProf g_prof;
+static int g_pp_force = 0;      // test hook (dh_dbg_gemm_family): 0 = policy, 1 = never k_gemm_pp, 2 = k_gemm_pp whenever it can carry the launch
 #ifdef DH_TUNING
 static unsigned long long* g_gemm_ts = nullptr;      // device buffer of 8 stamps (dh_dbg_gemm_timeline)
 #endif
 bool gemm_profiling_on() { return g_prof.on; }
-
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef __bf16 v8b __attribute__((ext_vector_type(8)));
-typedef float v16f __attribute__((ext_vector_type(16)));
-
-template <class T> struct Mfma;
-template <> struct Mfma<f16> {
-  static __device__ __forceinline__ v16f run(uint4 a, uint4 b, v16f c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
-  }
-};
-template <> struct Mfma<bf16> {
-  static __device__ __forceinline__ v16f run(uint4 a, uint4 b, v16f c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8b, a), __builtin_bit_cast(v8b, b), c, 0, 0, 0);
-  }
-};
-
-struct GemmK {   // kernel-side copy of GemmArgs (plain data)
-  const void* A; long lda;
-  const void* W;
-  int M, N, K;
-  int mode, Hin, Win, Cin, Hout, Wout, stride, up, pad;
-  const float* bias;
-  const float* rowvec; int rowvec_ld; int rows_per_batch; float inv_rows_per_batch;
-  const void* R; long ldr;
-  void* C; long ldc;
-  int act_silu;
-  int pre_r;        // fetch the residual tile before the K loop
-  int wide_store;   // 16-byte epilogue stores (N % 32 == 0, C and ldc 16-byte aligned)
-#ifdef DH_TUNING
-  int w_nt;         // non-temporal weight DMA (measured: no gain at <= 2 row tiles, a loss beyond; tuning builds only)
-  unsigned long long* ts;   // in-kernel timeline of workgroup (0,0,0), lane 0 of wave 0: s_memtime at the phase boundaries
-  int lnf_abl;      // timing-only ablation of the folded LayerNorm: 1 = no sums in the K loop, 2 = no exchange, 4 = no epilogue transform
-#endif
-  // LayerNorm folded into this GEMM (LNF instantiations): A is the LayerNorm INPUT x, W holds W * gamma, and
-  // out = rstd * (x W'^T - mean * ln_s) + ln_t with ln_s[n] = sum_k W'[n][k], ln_t[n] = sum_k beta[k] W[n][k] (+ bias);
-  // the row statistics come out of the K loop and are saved to ln_stats ([M][2]: mean, rstd) for the LayerNorm backward
-  const float* ln_s; const float* ln_t; float* ln_stats; float ln_eps;
-  float* partial;
-  int splits, k_per_split;
-  float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce only)
-  const void* gnb_x; long gnb_ldx; const float *gnb_gamma, *gnb_beta, *gnb_stats; int gnb_silu;   // backward statistics
-  const void* lnb_x; const float *lnb_gamma, *lnb_stats; const void* lnb_add; void* lnb_dx;        // LayerNorm backward on the reduce (host side only)
-  void* glu_y; long glu_ldy; const void* glub_x; void* glub_dx;                                    // GEGLU epilogues (GLU instantiations)
-};
 
 constexpr int BK = 64;
 // experiment switches (tools/lab.sh build-tuning DH_DEFS=...): never defined in the product build
@@ -1044,6 +1000,9 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   const bool lnf = k.ln_s != nullptr;
   int BM = 128, BN = (k.N % 128 == 0) ? 128 : 64;
   const int ktiles = k.K / BK;
+  // grids that fill the chip with 256- / 128-row tiles and carry the plain epilogue: the eight-wave ping-pong kernel (gemm_pp.hip)
+  PpPlan pp;
+  const bool use_pp = gemm_pp_plan(k, partial_elems, g_pp_force, &pp);
   if (BN == 128 && ktiles >= 16 && cdiv(k.M, 128) * cdiv(k.N, 128) <= kNarrowTiles) BN = 64;
   // few output tiles and a K loop too short to be worth slabs + a reduce launch: 64x64 tiles
   // (M=256 N=1280 K=1280: 16.7 -> 8.8 us; M=1024 N=640 K=640: 12.1 -> 8.9 us)
@@ -1077,9 +1036,11 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   const long tiles160 = (long)cdiv(k.M, 128) * (k.N / 160);
   const bool t160 = kT160 > 0 && k.N % 160 == 0 && !lnf && !glu && !n320 && BM != 64 && tiles160 >= kT160 && tiles160 <= 256;
   if (t160) { BM = 128; BN = 160; }
+  if (use_pp) { BM = pp.bm; BN = pp.bn; }
   const int tm = cdiv(k.M, BM), tn = cdiv(k.N, BN), tiles = tm * tn;
   int splits = 1;
-  if (k.partial && !lnf && !glu && tiles < kSplitTiles && ktiles >= kSplitMinK) {
+  if (use_pp) splits = pp.splits;
+  else if (k.partial && !lnf && !glu && tiles < kSplitTiles && ktiles >= kSplitMinK) {
     splits = kSplitTarget / tiles;
     if (splits > ktiles / 4) splits = ktiles / 4;
     if (splits > 32) splits = 32;
@@ -1094,20 +1055,20 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   const int kForceTile = getenv("DH_FORCE_TILE") ? atoi(getenv("DH_FORCE_TILE")) : 0;          // (re-read per dispatch: one process sweeps)
   const int kForceSplits = getenv("DH_FORCE_SPLITS") ? atoi(getenv("DH_FORCE_SPLITS")) : 0;
   int force_tile = 0;
-  if (kForceTile && !(k.glu_y || k.glub_x)) {
+  if (kForceTile && !use_pp && !(k.glu_y || k.glub_x)) {
     const int fbm = kForceTile == 1 ? 64 : (kForceTile == 6 ? 256 : 128), fbn = kForceTile == 7 ? 160 : ((kForceTile <= 3) ? 64 : 128);
     if ((k.N % fbn == 0 || fbn == 64) && !(fbn == 160 && lnf)) { BM = fbm; BN = fbn; force_tile = kForceTile; }
   }
-  if (kForceSplits && k.partial && !lnf) {
+  if (kForceSplits && !use_pp && k.partial && !lnf) {
     splits = kForceSplits;
     if (splits > ktiles / 2) splits = ktiles / 2 > 0 ? ktiles / 2 : 1;
     const size_t fit = partial_elems / ((size_t)k.M * k.N);
     if ((size_t)splits > fit) splits = (int)fit;
     if (splits < 1) splits = 1;
   }
-  if (kLog) fprintf(stderr, "GEMMLOG M=%d N=%d K=%d mode=%d lnf=%d gn=%d gnb=%d bias=%d R=%d rowvec=%d | BM=%d BN=%d splits=%d\n", k.M, k.N, k.K,
+  if (kLog) fprintf(stderr, "GEMMLOG M=%d N=%d K=%d mode=%d lnf=%d gn=%d gnb=%d bias=%d R=%d rowvec=%d | pp=%d BM=%d BN=%d splits=%d\n", k.M, k.N, k.K,
                     k.mode == A_DENSE ? 0 : (k.mode == A_CONV3 && k.stride == 1 && k.up == 0 ? 1 : 2), (int)lnf, k.gn_part != nullptr,
-                    k.gnb_x != nullptr, k.bias != nullptr, k.R != nullptr, k.rowvec != nullptr, BM, BN, splits);
+                    k.gnb_x != nullptr, k.bias != nullptr, k.R != nullptr, k.rowvec != nullptr, (int)use_pp, BM, BN, splits);
 #endif
   const int tiles_per_split = cdiv(ktiles, splits);
   splits = cdiv(ktiles, tiles_per_split);
@@ -1167,7 +1128,8 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (force_tile == 7) launch_tile<T, 128, 160, 4, 1, 1, 1>(gm, false, grid, st, k);
   else
 #endif
-  if (t160) launch_tile<T, 128, 160, 4, 1, 1, 1>(gm, false, grid, st, k);
+  if (use_pp) { pp.splits = splits; launch_gemm_pp(dtype, k, pp, st, g_prof.e0, g_prof.e1); }
+  else if (t160) launch_tile<T, 128, 160, 4, 1, 1, 1>(gm, false, grid, st, k);
   else if (mw2) launch_tile<T, 256, 128, 3, 1, 1, 2>(gm, lnf, grid, st, k, glu);
   else if (BM == 128 && BN == 128 && (glu || (kMw128 && tiles_per_split >= kMw128))) launch_tile<T, 128, 128, 4, 1, 1, 2>(gm, lnf, grid, st, k, glu);
   // two wave groups on disjoint K ranges: measured ahead only on the 128x64 tile (conv 4096x320x2880: 28.5 -> 24.9 us,
@@ -1240,6 +1202,14 @@ double launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
 // tuning builds: the next GEMM launches stamp the timeline of their first workgroup into `ts` (8 x u64, device memory)
 extern "C" int dh_dbg_gemm_timeline(unsigned long long* ts) { dh::g_gemm_ts = ts; return DH_OK; }
 #endif
+
+// test hook: which main-loop family the next launches use (0 = the shipped policy, 1 = k_gemm_dma only, 2 = k_gemm_pp for every
+// launch it can carry) -- parity tests run small shapes through both, tools/bench_gemm_pp.py times them side by side
+extern "C" int dh_dbg_gemm_family(int force) {
+  DH_REQUIRE(force >= 0 && force <= 2, "family: 0 policy, 1 k_gemm_dma, 2 k_gemm_pp");
+  dh::g_pp_force = force;
+  return DH_OK;
+}
 
 extern "C" int dh_gemm_profile_begin(void) {
   dh::g_prof.on = true;

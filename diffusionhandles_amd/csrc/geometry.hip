@@ -513,9 +513,14 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
   int2* nlr = nb_lr + (size_t)e * nb_lr_stride;
   const int per = (n + CGM_WGS - 1) / CGM_WGS, i0 = wg * per, i1 = i0 + per < n ? i0 + per : n;
   unsigned epoch = 0;
+  // The iteration count is published with atomicMin over a slot that workgroup 0 arms here, BEFORE its first seam: a workgroup
+  // whose bounded spin runs out on the LAST seam (the others have read fail == 0, pass it and write their slices) still leaves
+  // -1 in the slot whatever the order of the two updates, so the host never sees a count >= 0 beside a partly written
+  // disparity.  (A failure before workgroup 0 even started is seen by workgroup 0 at its first seam: the flag is sticky.)
+  if (wg == 0 && threadIdx.x == 0) atomicExch(&counts_out[e * count_stride + slot_it], 0x7fffffff);
   for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) map[U[i]] = i;
   bool alive = cg_seam<true>(sy, ++epoch);                           // every workgroup's part of the pixel -> unknown map (plain stores / loads)
-  if (!alive) { if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = -1; return; }
+  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
   double part = 0.0;
   for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) {
     const int pix = U[i], y = pix / res, xx = pix - y * res;
@@ -543,7 +548,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
     return t;
   };
   double rs = all_sum(part, 0);
-  if (!alive) { if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = -1; return; }
+  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
   const double bnorm = rs;
   double beta = 0.0;
   int cur = 0, it = 0;
@@ -590,9 +595,9 @@ __global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, co
     rs = rsn;
     cur ^= 1;
   }
-  if (!alive) { if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = -1; return; }     // (every workgroup of the system agrees: the flag is sticky)
+  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
   for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) d[U[i]] = (float)x[i];
-  if (threadIdx.x == 0 && wg == 0) counts_out[e * count_stride + slot_it] = it;
+  if (threadIdx.x == 0 && wg == 0) atomicMin(&counts_out[e * count_stride + slot_it], it);      // (a -1 of another workgroup stays)
 }
 
 // The same iteration with the vectors on chip: thread t owns unknowns t, t + 1024, ... (the order the kernel above

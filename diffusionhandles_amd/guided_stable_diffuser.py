@@ -140,7 +140,9 @@ class GuidedStableDiffuser(GuidedDiffuser):
                 self.text_encoder = build_text_encoder(os.environ["DIFFHANDLES_TEXT_ENCODER_DIR"])
                 text_native = True
             elif isinstance(self.text_encoder, str):
-                with torch.random.fork_rng(devices=[]):            # random weights, but the SAME in every process (seeded like the U-Net's)
+                # (manual_seed also re-seeds every device generator, lazily: the fork must cover the current device as well, or a
+                #  caller that draws noise on the device after building the diffuser gets a different stream)
+                with torch.random.fork_rng(devices=[device]):      # random weights, but the SAME in every process (seeded like the U-Net's)
                     torch.manual_seed(1000 + self._synthetic_seed)
                     self.text_encoder = build_text_encoder()       # the SD-2 text configuration
             if text_native:
@@ -156,7 +158,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
                                            self._unet_config["sample_size"], self.dtype)
             elif isinstance(self.vae, str):
                 native = self.vae == "sd-native"
-                with torch.random.fork_rng(devices=[]):            # (two runs of a driver must decode with the same random VAE)
+                with torch.random.fork_rng(devices=[device]):      # (two runs of a driver must decode with the same random VAE)
                     torch.manual_seed(2000 + self._synthetic_seed)
                     self.vae = AutoencoderKL()
                 if native:
@@ -489,12 +491,26 @@ class GuidedStableDiffuser(GuidedDiffuser):
         return lane
 
     def lanes(self, n, max_batch=None):
-        """[self, fork, ...]: n lanes on this diffuser's weights (cached per (n, max_batch))."""
-        key = (int(n), max_batch)
-        cache = self.__dict__.setdefault("_lane_cache", {})
-        if key not in cache:
-            cache[key] = [self] + [self.fork(max_batch) for _ in range(int(n) - 1)]
-        return cache[key]
+        """[self, fork, ...]: n lanes on this diffuser's weights.  ONE growing list of forks per max_batch: lanes(2) is a prefix
+        of lanes(3), so a process that serves 8, 16 and 24 edits at streams = 3 holds two forks, not three sets (a fork owns a
+        full engine arena: 28.4 GB at max_batch 16).  release_lanes() destroys them."""
+        n = int(n)
+        if n < 1:
+            raise ValueError(f"lanes(n): n must be >= 1, got {n}")
+        forks = self.__dict__.setdefault("_lane_forks", {}).setdefault(max_batch, [])
+        while len(forks) < n - 1:
+            forks.append(self.fork(max_batch))
+        return [self] + forks[:n - 1]
+
+    def lane_arena_bytes(self):
+        """HBM held by the forks of this diffuser (all max_batch keys), for services that budget it."""
+        return sum(f.unet.workspace_bytes() for forks in self.__dict__.get("_lane_forks", {}).values() for f in forks)
+
+    def release_lanes(self):
+        """Destroy every fork's engine (arenas, graphs) and forget them; the root diffuser and the shared weights stay."""
+        for forks in self.__dict__.pop("_lane_forks", {}).values():
+            for f in forks:
+                f.unet.close()
 
     def _decode_serialized(self, latents):
         """VAE decode of a lane's result on the ROOT diffuser's decode stream: the decoder engine has one activation arena, so
@@ -553,7 +569,10 @@ class GuidedStableDiffuser(GuidedDiffuser):
         passes the one-stream call executes for its chunk (same batch, same kernels, private arenas), so the images are
         bit-identical to guided_inference_batch chunk by chunk.  Returns one image tensor [K_i,3,H,W] per chunk."""
         kmax = max(len(d) for d, _ in chunks)
-        lanes = self.lanes(min(int(streams), len(chunks)), None if self.unet.max_batch >= 2 * kmax else 2 * kmax)
+        if self.unet.max_batch < 2 * kmax:
+            # lane 0 is THIS diffuser: it could not run its chunk, and forks sized 2 * kmax would be made for nothing
+            raise RuntimeError(f"engine max_batch {self.unet.max_batch} < 2*K = {2 * kmax}: build the diffuser with max_batch >= {2 * kmax}")
+        lanes = self.lanes(min(int(streams), len(chunks)))
         with torch.no_grad(), self.on_stream():
             cond = self._encode([prompt]).contiguous()
             orig = [a.to(self.device).permute(0, 2, 3, 1).to(self.dtype).contiguous() for a in activations_orig]

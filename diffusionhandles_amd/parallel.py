@@ -52,16 +52,18 @@ def broadcast_identity(identity, src=0, device=None, group=None):
         tensors = [null_text, noise] + list(acts)
         meta[0] = [(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in tensors]
     dist.broadcast_object_list(meta, src=src, group=group)
+    # gloo (CPU tests; the one-GPU rehearsal of the multi-rank drivers) moves host tensors; RCCL moves them GPU to GPU
+    wire = device if dist.get_backend(group) != "gloo" else torch.device("cpu")
     out = []
     for i, (shape, dt) in enumerate(meta[0]):
         if rank == src:
             t = tensors[i].contiguous()          # activations are channels-last views: the layout ranks agree on is [T,C,h,w] contiguous
-            if device is not None:
-                t = t.to(device)
+            if wire is not None:
+                t = t.to(wire)
         else:
-            t = torch.empty(shape, dtype=getattr(torch, dt), device=device)
+            t = torch.empty(shape, dtype=getattr(torch, dt), device=wire)
         dist.broadcast(t, src=src, group=group)
-        out.append(t)
+        out.append(t if device is None else t.to(device))
     return out[0], out[1], out[2:]
 
 

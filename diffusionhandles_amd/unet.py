@@ -54,11 +54,15 @@ class HipUNet:
         self._saved_batch = 0
         self._text_key = 0
 
+    def close(self):
+        """Destroy the engine now (its arenas go back to the device); the object is unusable afterwards."""
+        if getattr(self, "_h", None):
+            self._L.dh_unet_destroy(self._h)
+            self._h = None
+
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                self._L.dh_unet_destroy(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 

@@ -98,8 +98,9 @@ def initial_inference(unet, sched, init_latents, disparity, uncond_list, cond, n
 
 
 def guided_inference(unet, sched, latents, disparity, uncond_list, cond, acts_orig, corr, conf,
-                     fg_weight=None, bg_weight=None, record=None):
-    """conf: namespace with the 13 guided_diffuser keys.  Returns the final latents."""
+                     fg_weight=None, bg_weight=None, record=None, steps=None):
+    """conf: namespace with the 13 guided_diffuser keys.  Returns the final latents.
+    steps (tests only): run just these step indices of the loop (the same body, teacher-forced from `latents`); None = all."""
     fg_weight = conf.fg_weight if fg_weight is None else fg_weight
     bg_weight = conf.bg_weight if bg_weight is None else bg_weight
     torch.manual_seed(conf.seed)
@@ -112,6 +113,8 @@ def guided_inference(unet, sched, latents, disparity, uncond_list, cond, acts_or
     depth64 = init_depth(disparity, (s, s)) if getattr(conf, "use_depth", True) else None
     x = latents
     for i, t in enumerate(sched.timesteps):
+        if steps is not None and i not in steps:
+            continue
         size = tuple(acts_orig[2][i].shape[-2:])
         it = 0
         while it < conf.num_optsteps and i < conf.guidance_max_step:

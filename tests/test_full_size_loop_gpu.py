@@ -1,0 +1,200 @@
+"""Loop-level parity at the FULL SD-2-depth size (round 5; the object bench.py times).
+
+Every other loop test runs the TINY U-Net; the pieces are held at full size elsewhere (engine forward / backward with
+random cotangents, energy at C = 320 / 640, one null-text timestep).  Here the COMPOSITION is held at the real size: the
+planned energy writing into the engine's in-place cotangent buffer, the truncated tape (want_eps=False), the strided latent
+update reading the 5-channel d(sample), the text K|V cache across the three iterations, the tile policy of B = 1, B = 2
+(CFG), B = 8 / 16 (batched edits) and of 96 x 96 latents.  The oracle is oracle.loop_ref.guided_inference (the statements
+of /root/reference/diffhandles/guided_stable_diffuser.py:377-479, pinned to the reference's own loop by g7 / g7b / g14) on
+oracle.unet_torch.UNetTorch(SD2_DEPTH) in fp32 on the device, with the same (16-bit representable) seeded weights."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from diffusionhandles_amd.synthetic import TRANSFORMS, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+def _rig(dtype, sample_size, max_batch):
+    from diffusionhandles_amd import conf as C
+    from diffusionhandles_amd.guided_stable_diffuser import GuidedStableDiffuser
+    from diffusionhandles_amd.unet import HipUNet
+    from oracle import depth_ref as D
+    from oracle import unet_torch as U
+    cfg = dict(U.SD2_DEPTH, sample_size=sample_size)
+    ref = U.init_synthetic_(U.UNetTorch(cfg), seed=0).to(dev()).eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.to(dtype).float())
+            p.requires_grad_(False)
+    hip = HipUNet(dict(cfg, text_len=77), dtype=dtype, max_batch=max_batch)
+    hip.load_state_dict(ref.state_dict())
+    conf = C.load_default().guided_diffuser
+    gd = GuidedStableDiffuser(conf, unet=hip, unet_config=dict(cfg, text_len=77), dtype=dtype).to(dev())
+    res = 8 * sample_size
+    depth, bg, mask = make_scene(res)
+    disp = D.normalize_depth(1.0 / depth)[0].to(dev())
+    prompt = "a sphere on a plane"
+    cond = gd._encode([prompt])
+    unc = gd._encode([""])[None].expand(50, -1, -1, -1).contiguous()
+    noise = torch.randn(1, 4, sample_size, sample_size, generator=torch.Generator().manual_seed(2773)).to(dev())
+    return SimpleNamespace(ref=ref, hip=hip, gd=gd, conf=conf, depth=depth, bg=bg, mask=mask, disp=disp, prompt=prompt, cond=cond,
+                           unc=unc, noise=noise, res=res)
+
+
+class _FirstSteps:
+    """oracle.loop_ref.DDIM restricted to its first n timesteps (the oracle's initial inference records n timesteps)."""
+
+    def __new__(cls, n):
+        from oracle import loop_ref as L
+
+        class S(L.DDIM):
+            def set_timesteps(self, m):
+                super().set_timesteps(m)
+                self.timesteps = self.timesteps[:n]
+        return S()
+
+
+def _orig_activations(r, n):
+    """The original activations of the first n timesteps from the ORACLE's initial inference, as [50, C, h, w] lists (the
+    timesteps past n are never read: the steps tested there are unguided)."""
+    from oracle import loop_ref as L
+    acts_o, _, _, _ = L.initial_inference(r.ref, _FirstSteps(n), r.noise, r.disp, r.unc, r.cond)
+    full = []
+    for a in acts_o:
+        buf = torch.zeros((50,) + tuple(a.shape[1:]), dtype=torch.float32, device=dev())
+        buf[:n] = a
+        full.append(buf)
+    return full
+
+
+@pytest.fixture(scope="module")
+def full():
+    return _rig(torch.float16, 64, 16)
+
+
+def test_guided_step_full_size_matches_oracle(full):
+    """Three teacher-forced guided steps (t_idx 0, 1, 2: the three layer phases act2 / act1 / act1 + act2 of the weight
+    schedule, all three iteration multipliers each) and one unguided step (t_idx 38 = guidance_max_step) of
+    GuidedStableDiffuser.guided_step on HipUNet(SD2_DEPTH) fp16 against oracle.loop_ref.guided_inference(steps=[i]) on
+    UNetTorch(SD2_DEPTH) fp32, the real 512 x 512 re-projection, at the gates of the TINY teacher-forced loop test:
+    latent after the step rel-L2 < 5e-3, first-iteration update (the guidance gradient through the engine's backward)
+    < 6e-2, three-iteration update < 0.2."""
+    from diffusionhandles_amd.depth_transform import transform_depth
+    from oracle import loop_ref as L
+    r = full
+    gd = r.gd
+    ang, tr = TRANSFORMS[2]
+    disp_e, corr = transform_depth(r.depth.to(dev()), r.bg.to(dev()), r.mask.to(dev()), gd.get_depth_intrinsics(), rot_angle=ang,
+                                   rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor(tr))
+    acts = _orig_activations(r, 3)
+    assert acts[0].shape == (50, 1280, 32, 32) and acts[1].shape == (50, 640, 64, 64) and acts[2].shape == (50, 320, 64, 64)
+    gmax = r.conf.guidance_max_step
+    worst = dict(step=0.0, upd=0.0, upd3=0.0)
+    with torch.no_grad(), gd.on_stream():
+        gd.scheduler.set_timesteps(50)
+        ts = gd.scheduler.timesteps
+        st = gd.prepare_guidance(disp_e, r.prompt, acts, corr)
+        assert st.plan is not None and st.n_pairs > 1000
+        x_in = r.noise
+        for i in (0, 1, 2, gmax):
+            rec_o, rec_p = {}, {}
+            L.guided_inference(r.ref, L.DDIM(), x_in, disp_e, r.unc, r.cond, acts, corr.numpy(), r.conf, record=rec_o, steps=[i])
+            x_out = gd.guided_step(st, x_in.permute(0, 2, 3, 1).contiguous(), i, ts[i], r.unc[i], record=rec_p)
+            e = rel(x_out.permute(0, 3, 1, 2), rec_o["step"][0])
+            worst["step"] = max(worst["step"], e)
+            assert e < 5e-3, f"t_idx {i}: latent after the step rel-L2 {e:.3e} >= gate 5e-3"
+            if i < gmax:
+                assert len(rec_p["opt"]) == 3 and len(rec_o["opt"]) == 3
+                eu = rel(rec_p["opt"][0] - x_in, rec_o["opt"][0] - x_in)
+                eu3 = rel(rec_p["opt"][2] - x_in, rec_o["opt"][2] - x_in)
+                worst["upd"], worst["upd3"] = max(worst["upd"], eu), max(worst["upd3"], eu3)
+                assert eu < 6e-2 and eu3 < 0.2, (f"t_idx {i}: first-iteration update rel-L2 {eu:.3e} (gate 6e-2), three-iteration "
+                                                 f"update {eu3:.3e} (gate 0.2), update norm {(rec_o['opt'][0] - x_in).norm().item():.3e}")
+            else:
+                assert len(rec_o.get("opt", [])) == 0 and len(rec_p.get("opt", [])) == 0
+            x_in = rec_o["step"][0]                    # teacher forcing: the next step starts from the oracle's latent
+    print(f"full-size guided step vs oracle: worst latent-after-step rel-L2 {worst['step']:.3e} (gate 5e-3), first-iteration "
+          f"update {worst['upd']:.3e} (gate 6e-2), three-iteration update {worst['upd3']:.3e} (gate 0.2)")
+    full.acts, full.disp_e, full.corr = acts, disp_e, corr
+
+
+def test_guided_step_batch8_full_size_matches_single_steps(full):
+    """BASELINE config 3 at its real size: guided_step_batch with K = 8 edits (eight SE(3) transforms of one image, B = 8
+    optimisation passes and the B = 16 CFG pass on the full engine) against eight single guided_step calls (B = 1 / B = 2
+    passes) from the same per-edit inputs, for t_idx 0, 1, 2 (all three layer phases) and the unguided t_idx 38, teacher-forced
+    from the single-step latents: post-step latents rel-L2 <= 5e-3 per edit.  The two differ only by the engine's
+    batch-dependent tile selection (fp16 summation order)."""
+    from diffusionhandles_amd.depth_transform import reproject_edits
+    r = full
+    gd = r.gd
+    if not hasattr(r, "acts"):
+        r.acts = _orig_activations(r, 3)
+    K = 8
+    Y = torch.tensor([0.0, 1.0, 0.0])
+    tfs = [(TRANSFORMS[i][0], Y, torch.tensor(TRANSFORMS[i][1])) for i in range(K)]
+    gmax = r.conf.guidance_max_step
+    worst = 0.0
+    with torch.no_grad(), gd.on_stream():
+        gd.scheduler.set_timesteps(50)
+        ts = gd.scheduler.timesteps
+        edits = reproject_edits(r.depth.to(dev()), r.bg.to(dev()), r.mask.to(dev()), gd.get_depth_intrinsics(), tfs,
+                                device_correspondences=True)
+        sts = [gd.prepare_guidance(d, r.prompt, r.acts, c) for d, c in edits]
+        g = torch.Generator(device=dev()).manual_seed(77)
+        # distinct inputs per edit (a shared latent would hide a mixed-up batch index)
+        xb = (r.noise.permute(0, 2, 3, 1) + 0.05 * torch.randn(K, 64, 64, 4, generator=g, device=dev())).contiguous()
+        for i in (0, 1, 2, gmax):
+            singles = torch.cat([gd.guided_step(sts[e], xb[e:e + 1].contiguous(), i, ts[i], r.unc[i]).clone() for e in range(K)])
+            batched = gd.guided_step_batch(sts, xb, i, ts[i], r.unc[i]).clone()
+            assert batched.shape == singles.shape == (K, 64, 64, 4)
+            errs = [rel(batched[e], singles[e]) for e in range(K)]
+            worst = max(worst, max(errs))
+            assert max(errs) <= 5e-3, f"t_idx {i}: batched vs single post-step latent rel-L2 per edit {['%.2e' % v for v in errs]} (gate 5e-3)"
+            # and the edits really differ from each other (the comparison is not vacuous)
+            assert rel(singles[1], singles[2]) > 10 * max(errs)
+            xb = singles
+    print(f"K = 8 full-size batched step vs eight single steps: worst post-step latent rel-L2 {worst:.3e} (gate 5e-3)")
+
+
+def test_guided_step_768_full_size_bf16_matches_oracle():
+    """BASELINE config 5 at its real size: one guided-denoise step at 768 x 768 on HipUNet(SD2_DEPTH at 96 x 96 latents) in bf16
+    (fp32 guidance energy / backward seed) against the oracle on UNetTorch of the same configuration in fp32: the first latent
+    update and the latent after the step at the bf16 gates of tests/test_config5_gpu.py (8e-2 / 3e-2), cells on the 96 grid."""
+    from diffusionhandles_amd import depth_transform as DT
+    from oracle import depth_ref as D
+    from oracle import loop_ref as L
+    r = _rig(torch.bfloat16, 96, 2)
+    gd = r.gd
+    ang, tr = TRANSFORMS[2]
+    disp_e, corr = DT.transform_depth(r.depth.to(dev()), r.bg.to(dev()), r.mask.to(dev()), gd.get_depth_intrinsics(), rot_angle=ang,
+                                      rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor(tr))
+    _, corr_o = D.transform_depth_pc(r.depth, r.bg, r.mask, rot_angle=ang, rot_axis=[0, 1, 0], translation=tr)
+    assert np.array_equal(corr.numpy(), corr_o.numpy())
+    acts = _orig_activations(r, 1)
+    assert acts[1].shape == (50, 640, 96, 96) and acts[0].shape == (50, 1280, 48, 48)
+    rec_p, rec_o = {}, {}
+    with torch.no_grad(), gd.on_stream():
+        gd.scheduler.set_timesteps(50)
+        st = gd.prepare_guidance(disp_e, r.prompt, acts, corr)
+        assert st.plan is not None and st.plan.grid == 96
+        x = gd.guided_step(st, r.noise.permute(0, 2, 3, 1).contiguous(), 0, gd.scheduler.timesteps[0], r.unc[0], rec_p)
+    L.guided_inference(r.ref, L.DDIM(), r.noise, disp_e, r.unc, r.cond, acts, corr.numpy(), r.conf, record=rec_o, steps=[0])
+    up = rel(rec_p["opt"][0] - r.noise, rec_o["opt"][0] - r.noise)
+    up3 = rel(rec_p["opt"][2] - r.noise, rec_o["opt"][2] - r.noise)
+    step = rel(x.permute(0, 3, 1, 2), rec_o["step"][0])
+    print(f"768^2 full-size bf16 guided step vs oracle: first update rel-L2 {up:.3e} (gate 8e-2), three-iteration update {up3:.3e} "
+          f"(gate 0.3), latent after the step {step:.3e} (gate 3e-2)")
+    assert up < 8e-2 and up3 < 0.3 and step < 3e-2, (up, up3, step)

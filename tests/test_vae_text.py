@@ -174,10 +174,11 @@ def test_diffuser_with_native_text_tower_and_vae():
     # the diffuser seeds its random-weight text tower with 1000 + synthetic_seed (the same weights in every process: two runs of
     # a driver must agree byte for byte) without touching the caller's RNG stream
     torch.manual_seed(77)
-    probe = torch.rand(1).item()
+    probe, probe_dev = torch.rand(1).item(), torch.rand(4, device=dev).cpu()
     torch.manual_seed(77)
     GuidedStableDiffuser(conf, unet=hip, text_encoder="sd2", vae="sd", synthetic_seed=3).to(dev)
     assert torch.rand(1).item() == probe, "building the random-weight modules consumed the caller's RNG"
+    assert torch.equal(torch.rand(4, device=dev).cpu(), probe_dev), "building the random-weight modules re-seeded the DEVICE generator"
     torch.manual_seed(1000 + 3)
     ref = build_text_encoder().to(dev).eval()
     emb = gd._encode(["a sphere on a plane", ""])

@@ -86,11 +86,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU over RCCL; DH_BENCH_BACKEND=gloo (+ ranks folded onto the visible devices) exists only so that the
+    # multi-rank control flow can be exercised on a single-GPU box (tests/test_multirank_gpu.py), as in bench.py
+    backend = os.environ.get("DH_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     from diffusionhandles_amd import DiffusionHandles, parallel
     from diffusionhandles_amd import conf as C
     from diffusionhandles_amd.scene_io import load_scene, transform_args, write_png
@@ -136,7 +143,7 @@ def main():
     barrier()
     t_edits = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([t_edits], dtype=torch.float64, device=dev)
+        tt = torch.tensor([t_edits], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_edits = float(tt.item())
     results = parallel.gather_results([(gi, None if args.no_images else im, None if args.no_images else dp) for gi, im, dp in local])
