@@ -115,6 +115,8 @@ DEBUG_SIGNATURES = {
                           c_p, c_l, c_p, c_l, c_i, c_p, c_sz, c_p]),
     "dh_dbg_gemm_lnfold": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
     "dh_dbg_gemm_glu": (c_i, [c_i, c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "dh_dbg_gemm_family": (c_i, [c_i]),
+    "dh_dbg_gemm_pp_variant": (c_i, [c_i, c_p]),
     "dh_dbg_touch_tiled": (c_i, [c_sz, c_p]),
     "dh_dbg_groupnorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "dh_dbg_layernorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),

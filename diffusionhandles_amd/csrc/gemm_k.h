@@ -51,6 +51,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   // k_gemm_pp only (launch_gemm_pp fills them): row / column tile counts, work-item order (0 = column tile fastest, 1 = row
   // tile fastest), bytes the A / W buffer descriptors cover
   int pp_tm, pp_tn, pp_order; unsigned pp_a_bytes, pp_w_bytes;
+  unsigned long long* pp_ts;        // timeline stamps (measurement variants only)
 };
 
 

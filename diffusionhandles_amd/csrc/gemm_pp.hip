@@ -33,6 +33,9 @@
 // the loop).  Stage image, source-side swizzle and weight layout are exactly k_gemm_dma's (unet_kernels.h wt_index).
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "gemm_k.h"
 
 namespace dh {
@@ -42,38 +45,55 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned lane_u2p __attribute__((ext_vector_type(2)));
 
 template <class T> struct Mfma16;
+// (fragments are loaded AS the MFMA operand type: a uint4 that is bit-cast at the MFMA gets split into dwords and re-packed with
+//  v_pk_mov / v_mov pairs between the MFMAs)
 template <> struct Mfma16<f16> {
-  static __device__ __forceinline__ v4f run(uint4 a, uint4 b, v4f c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
-  }
+  typedef v8h frag;
+  static __device__ __forceinline__ v4f run(frag a, frag b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Mfma16<bf16> {
-  static __device__ __forceinline__ v4f run(uint4 a, uint4 b, v4f c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8b, a), __builtin_bit_cast(v8b, b), c, 0, 0, 0);
-  }
+  typedef v8b frag;
+  static __device__ __forceinline__ v4f run(frag a, frag b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
 constexpr unsigned PP_OOB = 0x80000000u;     // an offset no descriptor of < 2 GiB contains: the DMA writes zeros
 
-// one 1-KiB piece: lane i moves 16 bytes from (descriptor base + voff + soff) to LDS byte lds_dst + 16 i
-__device__ __forceinline__ void pp_dma(unsigned voff, v4i rsrc, unsigned soff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+// LDS-DMA pieces.  M0 holds the LDS byte address of a wave's first piece of a group (its A pieces / its W pieces of a stage);
+// piece j of the group lies j KiB further and is addressed by the instruction's immediate offset, which the hardware adds
+// to BOTH the LDS and the memory address -- so the per-piece source offset carries -1024 j.  M0 is not saved: nothing else in
+// this kernel uses it (LDS instructions need no M0 on gfx9+; checked in the ISA by tools/check_isa.py).
+__device__ __forceinline__ void pp_set_m0(unsigned lds_dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory"); }
+template <int IMM> __device__ __forceinline__ void pp_dma(unsigned voff, v4i rsrc, unsigned soff) {
+  // The scalar offset is copied by an s_mov INSIDE the statement: (1) MUBUF's soffset must be an SGPR and the "s" constraint
+  // alone lets a literal or a vector register through; (2) when the compiler produces the value with v_readfirstlane (a VALU
+  // write of an SGPR) a VMEM instruction must not read it for five wait states, and hipcc pads nothing for the operands of an
+  // asm statement -- measured: the first piece behind such a readfirstlane fetched from the PREVIOUS tile's offset.  An SALU
+  // copy has no such hazard towards VMEM.
+  unsigned tmp;
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_mov_b32 %0, %3\n\tbuffer_load_dwordx4 %1, %2, %0 offen offset:%4 lds"
+               : "=&s"(tmp) : "v"(voff), "s"(rsrc), "s"(soff), "n"(IMM) : "memory");
 }
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// at most `tiles` tiles of P pieces each may stay outstanding (tiles < CAP)
-template <int P, int CAP> __device__ __forceinline__ void pp_wait_tiles(int tiles) {
-  if constexpr (CAP <= 1) { pp_wait_vm<0>(); }
+// at most n (0 .. 15; more is clamped, which only waits longer) DMA pieces of this wave may stay outstanding
+template <int LO, int HI> __device__ __forceinline__ void pp_wait_vm_dyn(int n) {
+  if constexpr (LO == HI) { pp_wait_vm<LO>(); }
   else {
-    if (tiles >= CAP - 1) pp_wait_vm<P * (CAP - 1)>(); else pp_wait_tiles<P, CAP - 1>(tiles);
+    constexpr int MID = (LO + HI + 1) / 2;
+    if (n >= MID) pp_wait_vm_dyn<MID, HI>(n); else pp_wait_vm_dyn<LO, MID - 1>(n);
   }
 }
 __device__ __forceinline__ void pp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
 enum { PP_DENSE = 0, PP_CONV_S1 = 1, PP_GENERIC = 2 };
+// variants (measurement / A-B: tools/bench_gemm_pp.py; the shipped choice is PP_SHIP)
+enum { PPV_STAMP = 1,        // s_memtime stamps of waves 0 and 4 of workgroup 0 into p.pp_ts (timeline of the segments)
+       PPV_DMA_IN_MFMA = 2,  // the LDS-DMA pieces are issued between the MFMAs of the multiply segment instead of in the load segment
+       PPV_DMA_FIRST = 8,    // load segment: the LDS-DMA pieces are issued BEFORE the fragment reads
+       PPV_K64 = 4,          // a segment covers a whole 64-deep K tile (two k-steps): half the barriers, twice the fragment registers
+       PPV_NDIM_SHIFT = 4 }; // bits 4-6: only the LAST n piece slots of a tile (the W pieces first) go out inside the multiply segment
 
-template <class T, int BM, int BN, int MODE, int NST>
+template <class T, int BM, int BN, int MODE, int NST, int VAR>
 __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   constexpr int RPW = BM / 4, CPW = BN / 2;                 // rows / columns of the output tile per wave
   constexpr int TM = RPW / 16, TN = CPW / 16;
@@ -83,14 +103,23 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   constexpr int WPIECES = BN / 8;
   static_assert(WPIECES % 8 == 0 || WPIECES % 8 == 4, "the W pieces split evenly inside each wave group");
   constexpr int NPB0 = (WPIECES + 7) / 8, NPB1 = WPIECES / 8;   // W pieces per wave: waves 0-3 / waves 4-7
-  constexpr int NP0 = NPA + NPB0, NP1 = NPA + NPB1;
+  constexpr int NP0 = NPA + NPB0;                           // piece slots per wave and tile (the last W slot is empty for waves 4-7 when NPB1 < NPB0)
+  static_assert(NPA <= 4 && NPB0 <= 4, "immediate offsets reach 3 KiB");
   static_assert(NST >= 3 && NST * STAGE <= 160 * 1024, "ring does not fit the LDS");
+  constexpr int KS = (VAR & PPV_K64) ? 2 : 1;               // 32-deep k-steps per segment
+  constexpr int SEG = 2 / KS;                               // segments per K tile
+  constexpr bool STAMP = (VAR & PPV_STAMP) != 0, DFIRST = (VAR & PPV_DMA_FIRST) != 0;
+  // piece slots [0, XL) of a tile are issued in the load segments, [XL, NP0) between the MFMAs of the multiply segments: the
+  // two segments of an interval run side by side on a SIMD, the interval lasts as long as the longer one
+  constexpr int NDIM = (VAR & PPV_DMA_IN_MFMA) ? NP0 : ((VAR >> PPV_NDIM_SHIFT) & 7);
+  constexpr int XL = NP0 - (NDIM < NP0 ? NDIM : NP0);
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, wm = wave & 3;                   // group = column half; waves w and w + 4 share a SIMD
   const int l15 = lane & 15, quad = lane >> 4;
+  const int npw = g == 0 ? NP0 : NPA + NPB1;                // DMA pieces this wave issues per tile
 
   // ---- which output tile: XCD-aware order (block b runs on XCD b % 8; consecutive work items share an operand panel) ----
   int m0, n0, zsplit;
@@ -109,34 +138,41 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   const int nt = (kend - kbeg) >> 6;
 
   // ---- descriptors (scalar) ------------------------------------------------------------------------------------------------
-  // conv: the base is moved back by one image row + one pixel so that the tap offset (ky Win + kx) lda is never negative
-  const unsigned a_bias = MODE == PP_CONV_S1 ? (unsigned)((p.Win + 1) * p.lda * 2) : 0u;
+  // The A base is moved back by a_bias bytes and every source offset carries +a_bias: the stride-1 convolution's tap offset
+  // (ky Win + kx) lda is then never negative (a_bias = one image row + one pixel), and no offset goes below zero when the
+  // immediate's -1024 j is folded in (generic gather: 4 KiB).
+  const unsigned a_bias = MODE == PP_CONV_S1 ? (unsigned)((p.Win + 1) * p.lda * 2) : (MODE == PP_GENERIC ? 4096u : 0u);
   const size_t a_base = (size_t)p.A - a_bias;
   v4i ra, rw;
   ra[0] = (int)(unsigned)a_base; ra[1] = (int)((a_base >> 32) & 0xffff); ra[2] = (int)(p.pp_a_bytes + a_bias); ra[3] = 0x00020000;
   rw[0] = (int)(unsigned)(size_t)p.W; rw[1] = (int)(((size_t)p.W >> 32) & 0xffff); rw[2] = (int)p.pp_w_bytes; rw[3] = 0x00020000;
 
-  // ---- per-lane source offsets of this wave's pieces -------------------------------------------------------------------------
+  // ---- per-lane source offsets of this wave's pieces: wave w stages A rows [w BM / 8, (w + 1) BM / 8) and a contiguous run of
+  // W rows, so that its pieces of a group are consecutive KiB of the stage ------------------------------------------------------
   const int prow = lane >> 3;                               // row of this lane inside a piece
-  const int lchunk = (lane & 7) ^ (4 * (wave & 1) + (prow >> 1));      // source-side swizzle: chunk c of row r at c ^ ((r >> 1) & 7)
-  unsigned a_voff[NPA];                                     // dense / conv_s1: byte offset of (row, chunk); generic: batch base pixel
+  const int qa0 = wave * NPA;                               // first A piece of this wave
+  const int qb0 = g == 0 ? wave * NPB0 : 4 * NPB0 + (wave - 4) * NPB1;     // first W piece
+  unsigned a_voff[NPA];                                     // dense / conv_s1: byte offset of (row, chunk) - 1024 j; generic: batch base pixel
+  unsigned a_lch[NPA];                                      // generic: the swizzled chunk offset - 1024 j + a_bias
   unsigned a_taps[NPA];
   int a_oy[NPA], a_ox[NPA];
   bool a_ok[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
-    const int m = m0 + 8 * (wave + 8 * j) + prow;
+    const int m = m0 + 8 * (qa0 + j) + prow;
+    // source-side swizzle: chunk c of row r is stored at c ^ ((r >> 1) & 7); r = 8 (qa0 + j) + prow inside the tile
+    const int lchunk = (lane & 7) ^ ((4 * ((qa0 + j) & 1) + (prow >> 1)) & 7);
     a_ok[j] = m < p.M;
-    a_taps[j] = 0; a_oy[j] = 0; a_ox[j] = 0;
+    a_taps[j] = 0; a_oy[j] = 0; a_ox[j] = 0; a_lch[j] = 0;
     if (MODE == PP_DENSE) {
-      a_voff[j] = a_ok[j] ? (unsigned)m * (unsigned)(p.lda * 2) + lchunk * 16 : PP_OOB;
+      a_voff[j] = (a_ok[j] ? (unsigned)m * (unsigned)(p.lda * 2) + lchunk * 16 : PP_OOB) - 1024u * j;
     } else {
       const int hw = p.Hout * p.Wout;
       const int b = m / hw, r = m - b * hw;
       a_oy[j] = r / p.Wout;
       a_ox[j] = r - a_oy[j] * p.Wout;
       if (MODE == PP_CONV_S1) {
-        a_voff[j] = (unsigned)((b * p.Hin + a_oy[j]) * p.Win + a_ox[j]) * (unsigned)(p.lda * 2) + lchunk * 16;
+        a_voff[j] = (unsigned)((b * p.Hin + a_oy[j]) * p.Win + a_ox[j]) * (unsigned)(p.lda * 2) + lchunk * 16 - 1024u * j;
         if (a_ok[j]) {
 #pragma unroll
           for (int t = 0; t < 9; ++t)
@@ -144,34 +180,42 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         }
       } else {
         a_voff[j] = (unsigned)(b * p.Hin * p.Win);
+        a_lch[j] = lchunk * 16 + a_bias - 1024u * j;
       }
     }
   }
   const unsigned w_voff = lane * 16;
   const int KT = p.K >> 6;
-  unsigned w_soff[NPB0];                                     // scalar: byte offset of the piece's rows in the tiled weights (K tile 0)
+  unsigned w_soff[NPB0];                                     // scalar: byte offset of the piece's rows in the tiled weights (K tile 0) - 1024 j
 #pragma unroll
   for (int j = 0; j < NPB0; ++j) {
-    const int n = n0 + 8 * (wave + 8 * j);
-    w_soff[j] = (unsigned)(((n >> 6) * KT) * 8192 + (n & 63) * 128) + (unsigned)(kbeg >> 6) * 8192u;
+    const int n = n0 + 8 * (qb0 + j);
+    w_soff[j] = (unsigned)(((n >> 6) * KT) * 8192 + (n & 63) * 128) + (unsigned)(kbeg >> 6) * 8192u - 1024u * j;
   }
   int tap = 0, c0 = 0;
   if (MODE != PP_DENSE) { const int kt0 = kbeg >> 6, ch = kt0 / 9; tap = kt0 - ch * 9; c0 = ch * 64; }    // conv_k_index order
-  int kt_issue = 0;                                          // next tile to issue
+  int kt_issue = 0;                                          // tile at the issue cursor
+  int kti = 0;                                               // ... as the issue code reads it: a readfirstlane'd copy (the compiler
+                                                             // otherwise keeps the cursor in a vector register in the dense kernel)
+  int issued = 0;                                            // DMA pieces this wave has issued so far
 
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  // one piece q (0 .. NPA - 1: A, then W) of the tile at the issue cursor into ring slot `stage`
-  auto issue_piece = [&](int stage, int q) {
-    const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
-    if (q < NPA) {
-      const int j = q;
+  // LDS byte address of this wave's first A / first W piece in ring slot 0 (scalar registers: they feed M0)
+  const unsigned m0_a = __builtin_amdgcn_readfirstlane(lds0 + qa0 * 1024), m0_w = __builtin_amdgcn_readfirstlane(lds0 + BM * 128 + qb0 * 1024);
+  // piece slot Q (0 .. NPA - 1: A, then W) of the tile at the issue cursor into ring slot `stage`; FIRST: first piece of an
+  // issue run (M0 must be set even inside a group)
+  auto issue_piece = [&](int stage, auto Qc, bool first) {
+    constexpr int Q = decltype(Qc)::value;
+    if constexpr (Q < NPA) {
+      constexpr int j = Q;
+      if (j == 0 || first) pp_set_m0(m0_a + stage * STAGE);
       if (MODE == PP_DENSE) {
-        pp_dma(a_voff[j], ra, (unsigned)(kbeg + kt_issue * 64) * 2u, sbase + j * 8192);
+        pp_dma<j * 1024>(a_voff[j], ra, (unsigned)(kbeg + kti * 64) * 2u);
       } else if (MODE == PP_CONV_S1) {
         const int ky = tap / 3, kx = tap - ky * 3;
-        const unsigned soff = (unsigned)((ky * p.Win + kx) * (int)p.lda + c0) * 2u;
+        const unsigned soff = (unsigned)((ky * p.Win + kx) * (int)p.lda + c0) * 2u;      // relative to the moved base
         const bool ok = (a_taps[j] >> tap) & 1u;
-        pp_dma(ok ? a_voff[j] + a_bias : PP_OOB, ra, soff, sbase + j * 8192);
+        pp_dma<j * 1024>(ok ? a_voff[j] : PP_OOB - 1024u * j, ra, soff);
       } else {
         const int ky = tap / 3, kx = tap - ky * 3;
         bool ok = a_ok[j];
@@ -185,18 +229,43 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
           ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) && (ty >> 1) < p.Hin && (tx >> 1) < p.Win;
           sy = ty >> 1; sx = tx >> 1;
         }
-        const unsigned off = (a_voff[j] + (unsigned)(sy * p.Win + sx)) * (unsigned)(p.lda * 2) + lchunk * 16;
-        pp_dma(ok ? off : PP_OOB, ra, (unsigned)c0 * 2u, sbase + j * 8192);
+        const unsigned off = (a_voff[j] + (unsigned)(sy * p.Win + sx)) * (unsigned)(p.lda * 2) + a_lch[j];
+        pp_dma<j * 1024>(ok ? off : PP_OOB - 1024u * j, ra, (unsigned)c0 * 2u);
       }
+      ++issued;
     } else {
-      const int j = q - NPA;
-      if (j < NPB1 || g == 0) pp_dma(w_voff, rw, w_soff[j] + (unsigned)kt_issue * 8192u, sbase + BM * 128 + j * 8192);
+      constexpr int j = Q - NPA;
+      if (j < NPB1 || g == 0) {
+        if (j == 0 || first) pp_set_m0(m0_w + stage * STAGE);
+        pp_dma<j * 1024>(w_voff, rw, w_soff[j] + (unsigned)kti * 8192u);
+        ++issued;
+      }
+    }
+  };
+  // pieces [LO, HI) of the tile at the cursor
+  auto issue_range = [&](int stage, auto LOc, auto HIc) {
+    constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;
+    if constexpr (LO < HI) {
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        (issue_piece(stage, std::integral_constant<int, LO + I>{}, I == 0), ...);
+      }(std::make_integer_sequence<int, HI - LO>{});
     }
   };
   auto next_tile = [&]() {
     ++kt_issue;
+    kti = __builtin_amdgcn_readfirstlane(kt_issue);
     if (MODE != PP_DENSE) { if (++tap == 9) { tap = 0; c0 += 64; } }
   };
+  // this wave's pieces of tile u have landed once at most (issued - (u + 1) pieces-per-tile) later pieces are outstanding
+  auto wait_tile = [&](int u) {
+    int n = issued - (u + 1) * npw;
+    if (n < 0) n = 0;
+    pp_wait_vm_dyn<0, 15>(n);
+  };
+  unsigned long long* ts = nullptr;
+  int tsn = 0;
+  if constexpr (STAMP) { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ts = p.pp_ts + (wave >> 2) * 512; }
+  auto stamp = [&]() { if constexpr (STAMP) { if (ts && tsn < 512) ts[tsn++] = __builtin_amdgcn_s_memtime(); } };
 
   v4f acc[TM][TN];
 #pragma unroll
@@ -204,12 +273,12 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+  stamp();
   // ---- prologue: tiles 0 .. NST - 2 in flight ---------------------------------------------------------------------------------
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
     if (s < nt) {
-#pragma unroll
-      for (int q = 0; q < NP0; ++q) issue_piece(s, q);
+      issue_range(s, std::integral_constant<int, 0>{}, std::integral_constant<int, NP0>{});
       next_tile();
     }
   }
@@ -220,56 +289,86 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   const unsigned fa_base = (unsigned)((wm * RPW + l15) * 128);
   const unsigned fb_base = (unsigned)(BM * 128 + (g * CPW + l15) * 128);
 
-  // tile 0 has landed once at most the later tiles of the prologue are outstanding
-  {
-    const int later = (nt < NST - 1 ? nt : NST - 1) - 1;
-    if (g == 0) pp_wait_tiles<NP0, NST - 1>(later); else pp_wait_tiles<NP1, NST - 1>(later);
-  }
+  wait_tile(0);
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();               // the stagger: group 1 runs one interval behind group 0
+  stamp();
 
   int cur = 0;                                              // ring slot of tile t
-  uint4 fw[TN], fx[TM];
+  typedef typename Mfma16<T>::frag frag_t;
+  frag_t fw[KS][TN], fx[KS][TM];
+  constexpr int NMF = TM * TN * KS;                         // MFMAs of a segment
   for (int t = 0; t < nt; ++t) {
     const bool more = kt_issue < nt;
     const int nstage = cur == 0 ? NST - 1 : cur - 1;        // slot of tile t + NST - 1 = the slot tile t - 1 has left
     const unsigned char* st = smem + cur * STAGE;
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      ([&] {
+        constexpr int s = S;
+        constexpr int PLO = s * NP0 / SEG, PHI = (s + 1) * NP0 / SEG;     // piece slots of this segment
+        // ---- LOAD(t, s) ----
+        stamp();
+        auto read_frags = [&]() {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      // ---- LOAD(t, s) ----
-      {
-        const unsigned char* pb = st + fb_base + (s ? fo1 : fo0);
-        const unsigned char* pa = st + fa_base + (s ? fo1 : fo0);
+          for (int ks = 0; ks < KS; ++ks) {
+            const unsigned fo = (s * KS + ks) ? fo1 : fo0;
+            const unsigned char* pb = st + fb_base + fo;
+            const unsigned char* pa = st + fa_base + fo;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const uint4*>(pb + j * 2048);
+            for (int j = 0; j < TN; ++j) fw[ks][j] = *reinterpret_cast<const frag_t*>(pb + j * 2048);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fx[i] = *reinterpret_cast<const uint4*>(pa + i * 2048);
-      }
-      if (more) {
-#pragma unroll
-        for (int q = s * NP0 / 2; q < (s + 1) * NP0 / 2; ++q) issue_piece(nstage, q);
-      }
-      if (s == 1) {
-        if (more) next_tile();
-        // this wave's pieces of tile t + 1 have landed when only the tiles after it are outstanding
-        const int later = kt_issue - (t + 2);             // tiles t + 2 .. kt_issue - 1
-        if (g == 0) pp_wait_tiles<NP0, NST - 1>(later); else pp_wait_tiles<NP1, NST - 1>(later);
-      }
-      pp_wait_lds();
-      __builtin_amdgcn_s_barrier();
-      // ---- MFMA(t, s) ----
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma16<T>::run(fw[j], fx[i], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-    }
+            for (int i = 0; i < TM; ++i) fx[ks][i] = *reinterpret_cast<const frag_t*>(pa + i * 2048);
+          }
+        };
+        auto issue_load_part = [&]() {
+          constexpr int LLO = PLO < XL ? PLO : XL, LHI = PHI < XL ? PHI : XL;      // this segment's slots that stay in the load segment
+          if (more) issue_range(nstage, std::integral_constant<int, LLO>{}, std::integral_constant<int, LHI>{});
+          if constexpr (s == SEG - 1 && XL == NP0) { if (more) next_tile(); }
+        };
+        if constexpr (DFIRST) { issue_load_part(); __builtin_amdgcn_sched_barrier(0); stamp(); read_frags(); }
+        else { read_frags(); stamp(); issue_load_part(); }
+        stamp();
+        // group 1 is in this segment when group 0 finishes MFMA(t, last) and moves on to read tile t + 1
+        if constexpr (s == SEG - 1) { if (g == 1) wait_tile(t + 1); }
+        pp_wait_lds();
+        stamp();
+        __builtin_amdgcn_s_barrier();
+        stamp();
+        // ---- MFMA(t, s) ----
+        __builtin_amdgcn_s_setprio(1);
+        {
+          // this segment's slots that go out between its MFMAs, evenly spaced (piece k after MFMA (k + 1) NMF / (n + 1))
+          constexpr int MLO = PLO > XL ? PLO : XL, MHI = PHI > XL ? PHI : XL;
+          constexpr int NPC = MHI - MLO;
+          [&]<int... X>(std::integer_sequence<int, X...>) {
+            ([&] {
+              constexpr int x = X, ks = x / (TM * TN), i = (x / TN) % TM, j = x % TN;
+              acc[i][j] = Mfma16<T>::run(fw[ks][j], fx[ks][i], acc[i][j]);
+              if constexpr (NPC > 0) {
+                [&]<int... Kp>(std::integer_sequence<int, Kp...>) {
+                  ([&] {
+                    if constexpr ((Kp + 1) * NMF / (NPC + 1) - 1 == x) {
+                      if (more) issue_piece(nstage, std::integral_constant<int, MLO + Kp>{}, true);
+                    }
+                  }(), ...);
+                }(std::make_integer_sequence<int, NPC>{});
+              }
+            }(), ...);
+          }(std::make_integer_sequence<int, NMF>{});
+          if constexpr (s == SEG - 1 && XL < NP0) { if (more) next_tile(); }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        stamp();
+        // group 0 is in this segment right before it reads tile t + 1
+        if constexpr (s == SEG - 1) { if (g == 0) wait_tile(t + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }(), ...);
+    }(std::make_integer_sequence<int, SEG>{});
     cur = cur + 1 == NST ? 0 : cur + 1;
   }
   if (g == 0) __builtin_amdgcn_s_barrier();
+  stamp();
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------------
   // acc[i][j][r] = D[m = m0 + wm RPW + 16 i + l15][n = n0 + g CPW + 16 j + 4 quad + r]
@@ -303,10 +402,13 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const lane_u2p x = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[i][j][r]),
-                                                           __builtin_bit_cast(unsigned, acc[i][j + 1][r]), false, false);
-        v[r] = __builtin_bit_cast(float, x[0]);
-        v[4 + r] = __builtin_bit_cast(float, x[1]);
+        // (__builtin_bit_cast applied to the vector-ELEMENT lvalue acc[i][j][r] reads element 0 for every r with hipcc of
+        //  ROCm 7.2 -- seen in the ISA and on the device: copy the element to a float first)
+        const float fa = acc[i][j][r], fb = acc[i][j + 1][r];
+        const lane_u2p x = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, fa), __builtin_bit_cast(unsigned, fb), false, false);
+        const unsigned x0 = x[0], x1 = x[1];
+        v[r] = __builtin_bit_cast(float, x0);
+        v[4 + r] = __builtin_bit_cast(float, x1);
       }
       const int n = nb + 16 * (j + (quad & 1)) + 8 * (quad >> 1);
       if (!mok) continue;
@@ -393,25 +495,54 @@ bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan)
   return true;
 }
 
-template <class T, int BM, int BN, int NST>
+// the shipped main-loop variant (see the PPV_* flags; A/B in profiles/r05_ab_pp_variants.txt)
+constexpr int PP_SHIP = 0;
+static int g_pp_variant = PP_SHIP;                  // measurement builds (-DDH_PP_VARIANTS): dh_dbg_gemm_pp_variant
+static unsigned long long* g_pp_ts = nullptr;
+
+template <class T, int BM, int BN, int NST, int VAR>
 static void pp_launch_tile(int mode, dim3 grid, hipStream_t st, const GemmK& k, hipEvent_t e0, hipEvent_t e1) {
 #define DH_PP_LAUNCH(KERNEL)                                                                      \
   do {                                                                                            \
     if (e0) hipExtLaunchKernelGGL(KERNEL, grid, dim3(512), 0, st, e0, e1, 0, k);                  \
     else hipLaunchKernelGGL(KERNEL, grid, dim3(512), 0, st, k);                                   \
   } while (0)
-  if (mode == PP_DENSE) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_DENSE, NST>));
-  else if (mode == PP_CONV_S1) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_CONV_S1, NST>));
-  else DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_GENERIC, NST>));
+  if (mode == PP_DENSE) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_DENSE, NST, VAR>));
+  else if (mode == PP_CONV_S1) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_CONV_S1, NST, VAR>));
+  else {
+    if constexpr (VAR == PP_SHIP) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_GENERIC, NST, VAR>));
+  }
 #undef DH_PP_LAUNCH
+}
+
+template <class T, int VAR>
+static void pp_launch_var(const GemmK& k, const PpPlan& plan, int mode, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  if (plan.bm == 256 && plan.bn == 160) pp_launch_tile<T, 256, 160, 3, VAR>(mode, grid, st, k, e0, e1);
+  else if (plan.bm == 256) pp_launch_tile<T, 256, 128, 3, VAR>(mode, grid, st, k, e0, e1);
+  else if (plan.bn == 160) pp_launch_tile<T, 128, 160, 4, VAR>(mode, grid, st, k, e0, e1);
+  else pp_launch_tile<T, 128, 128, 4, VAR>(mode, grid, st, k, e0, e1);
 }
 
 template <class T>
 static void pp_launch(const GemmK& k, const PpPlan& plan, int mode, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  if (plan.bm == 256 && plan.bn == 160) pp_launch_tile<T, 256, 160, 3>(mode, grid, st, k, e0, e1);
-  else if (plan.bm == 256) pp_launch_tile<T, 256, 128, 3>(mode, grid, st, k, e0, e1);
-  else if (plan.bn == 160) pp_launch_tile<T, 128, 160, 4>(mode, grid, st, k, e0, e1);
-  else pp_launch_tile<T, 128, 128, 4>(mode, grid, st, k, e0, e1);
+#ifdef DH_PP_VARIANTS
+  // measurement build: every variant of the main loop side by side (f16, dense / stride-1 convolution)
+  if constexpr (std::is_same<T, f16>::value) {
+    if (mode != PP_GENERIC) {
+      switch (g_pp_variant) {
+#define DH_PP_CASE(V) case V: pp_launch_var<T, V>(k, plan, mode, grid, st, e0, e1); return;
+        DH_PP_CASE(1) DH_PP_CASE(2) DH_PP_CASE(4) DH_PP_CASE(5) DH_PP_CASE(6) DH_PP_CASE(7)
+        DH_PP_CASE(4 + 16) DH_PP_CASE(4 + 32) DH_PP_CASE(4 + 48) DH_PP_CASE(4 + 64) DH_PP_CASE(4 + 80)
+        DH_PP_CASE(5 + 16) DH_PP_CASE(5 + 32) DH_PP_CASE(5 + 48) DH_PP_CASE(5 + 64)
+        DH_PP_CASE(32) DH_PP_CASE(48)
+        DH_PP_CASE(8) DH_PP_CASE(9) DH_PP_CASE(12) DH_PP_CASE(13) DH_PP_CASE(12 + 16) DH_PP_CASE(12 + 32) DH_PP_CASE(13 + 32) DH_PP_CASE(12 + 48) DH_PP_CASE(12 + 64)
+#undef DH_PP_CASE
+        default: break;
+      }
+    }
+  }
+#endif
+  pp_launch_var<T, PP_SHIP>(k, plan, mode, grid, st, e0, e1);
 }
 
 void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
@@ -424,6 +555,7 @@ void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t
   k.pp_tn = k.N / plan.bn;
   k.pp_a_bytes = (unsigned)pp_a_bytes(k);
   k.pp_w_bytes = (unsigned)((size_t)k.N * k.K * 2);
+  k.pp_ts = g_pp_ts;
   // which operand panel consecutive work items (= one XCD's L2) share: the column tiles of a row tile share its A rows, the
   // row tiles of a column tile share its W rows; take the order with the smaller traffic estimate (the other operand is
   // then read once per XCD)
@@ -438,3 +570,15 @@ void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t
 }
 
 }  // namespace dh
+
+// measurement hook: main-loop variant of the next k_gemm_pp launches (builds with -DDH_PP_VARIANTS carry them; the product
+// library accepts only the shipped one) and the device buffer (2 x 512 u64) the stamping variants write their timeline to
+extern "C" int dh_dbg_gemm_pp_variant(int variant, unsigned long long* ts) {
+#ifndef DH_PP_VARIANTS
+  DH_REQUIRE(variant == dh::PP_SHIP, "this build carries the shipped k_gemm_pp variant only (tools/lab.sh build-pp-variants)");
+#endif
+  DH_REQUIRE(variant >= 0 && variant < 128, "variant: bit 0 stamps, bit 1 all DMA inside the MFMA segment, bit 2 64-deep segments, bits 4-6 pieces inside the MFMA segment");
+  dh::g_pp_variant = variant;
+  dh::g_pp_ts = ts;
+  return DH_OK;
+}

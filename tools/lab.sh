@@ -83,6 +83,18 @@ done
 wait
 ls -la "$ROOT"/tools/bin/libdh_attn_*.so
 ) }
+# build-pp-variants: the library with every k_gemm_pp main-loop variant (gemm_pp.hip under -DDH_PP_VARIANTS; CPU container) -> tools/bin/libdh_pp_variants.so
+recipe_build_pp_variants() { (
+set -e
+ROOT=$R
+SRC=$ROOT/diffusionhandles_amd/csrc
+make -C "$SRC" -j8 >/dev/null
+mkdir -p "$ROOT/tools/bin"
+OBJS=$(ls "$SRC"/*.o | grep -v gemm_pp.o)
+( cd "$SRC" && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-c++20-extensions -DDH_PP_VARIANTS -c gemm_pp.hip -o /tmp/dh_gemm_pp_variants.o )
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/bin/libdh_pp_variants.so" $OBJS /tmp/dh_gemm_pp_variants.o
+ls -la "$ROOT/tools/bin/libdh_pp_variants.so"
+) }
 # build-tuning: tuning build of the library (-DDH_TUNING) into tools/bin/ (CPU container)
 recipe_build_tuning() { (
 set -e
@@ -394,6 +406,7 @@ case "${1:-list}" in
   ablate-gemm) shift; recipe_ablate_gemm "$@" ;;
   ablate-attn) shift; recipe_ablate_attn "$@" ;;
   build-tuning) shift; recipe_build_tuning "$@" ;;
+  build-pp-variants) shift; recipe_build_pp_variants "$@" ;;
   gemm-warmth) shift; recipe_gemm_warmth "$@" ;;
   hbm) shift; recipe_hbm "$@" ;;
   pmc-traffic) shift; recipe_pmc_traffic "$@" ;;
@@ -416,6 +429,7 @@ recipes:
   ablate-gemm        k_gemm_dma ablations (0 full, 1 staging only, 2 compute only) on the batch-8 shapes; needs the tuning build
   ablate-attn        builds tools/bin/libdh_attn_<n>.so with attention.hip under -DDH_ATTN_ABL=n (timing-only ablations; CPU container)
   build-tuning       tuning build of the library (-DDH_TUNING) into tools/bin/ (CPU container)
+  build-pp-variants  the library with every k_gemm_pp main-loop variant (-DDH_PP_VARIANTS) into tools/bin/libdh_pp_variants.so (CPU container)
   gemm-warmth        GEMM duration with weights already in the caches vs cold (tools/bench_gemm_warmth.py under rocprofv3)
   hbm                rocprofv3 kernel traces of the HBM-bound pieces (guidance energy, K=8 re-projection) -> GB/s per kernel
   pmc-traffic        FETCH_SIZE / WRITE_SIZE passes over tools/time_unet.py 1 -> gpurun_out/pmc/*.tsv (then tools/pmc_summarise.py)
