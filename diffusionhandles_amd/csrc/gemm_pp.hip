@@ -75,7 +75,7 @@ template <int IMM> __device__ __forceinline__ void pp_dma(unsigned voff, v4i rsr
                : "=&s"(tmp) : "v"(voff), "s"(rsrc), "s"(soff), "n"(IMM) : "memory");
 }
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// at most n (0 .. 15; more is clamped, which only waits longer) DMA pieces of this wave may stay outstanding
+// at most n (0 .. HI; more is clamped, which only waits longer) vector-memory operations of this wave may stay outstanding
 template <int LO, int HI> __device__ __forceinline__ void pp_wait_vm_dyn(int n) {
   if constexpr (LO == HI) { pp_wait_vm<LO>(); }
   else {
@@ -89,7 +89,7 @@ enum { PP_DENSE = 0, PP_CONV_S1 = 1, PP_GENERIC = 2 };
 // variants (measurement / A-B: tools/bench_gemm_pp.py; the shipped choice is PP_SHIP)
 enum { PPV_STAMP = 1,        // s_memtime stamps of waves 0 and 4 of workgroup 0 into p.pp_ts (timeline of the segments)
        PPV_DMA_IN_MFMA = 2,  // the LDS-DMA pieces are issued between the MFMAs of the multiply segment instead of in the load segment
-       PPV_DMA_FIRST = 8,    // load segment: the LDS-DMA pieces are issued BEFORE the fragment reads
+       PPV_NO_RPRE = 8,      // the residual tile is loaded in the epilogue, chunk by chunk, instead of being prefetched behind the prologue
        PPV_K64 = 4,          // a segment covers a whole 64-deep K tile (two k-steps): half the barriers, twice the fragment registers
        PPV_NDIM_SHIFT = 4 }; // bits 4-6: only the LAST n piece slots of a tile (the W pieces first) go out inside the multiply segment
 
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   static_assert(NST >= 3 && NST * STAGE <= 160 * 1024, "ring does not fit the LDS");
   constexpr int KS = (VAR & PPV_K64) ? 2 : 1;               // 32-deep k-steps per segment
   constexpr int SEG = 2 / KS;                               // segments per K tile
-  constexpr bool STAMP = (VAR & PPV_STAMP) != 0, DFIRST = (VAR & PPV_DMA_FIRST) != 0;
+  constexpr bool STAMP = (VAR & PPV_STAMP) != 0;
   // piece slots [0, XL) of a tile are issued in the load segments, [XL, NP0) between the MFMAs of the multiply segments: the
   // two segments of an interval run side by side on a SIMD, the interval lasts as long as the longer one
   constexpr int NDIM = (VAR & PPV_DMA_IN_MFMA) ? NP0 : ((VAR >> PPV_NDIM_SHIFT) & 7);
@@ -257,10 +257,13 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
     if (MODE != PP_DENSE) { if (++tap == 9) { tap = 0; c0 += 64; } }
   };
   // this wave's pieces of tile u have landed once at most (issued - (u + 1) pieces-per-tile) later pieces are outstanding
+  // (the residual loads rpre_n sit in the queue behind the prologue's pieces and ahead of everything the loop issues)
+  int rpre_n = 0;
   auto wait_tile = [&](int u) {
     int n = issued - (u + 1) * npw;
     if (n < 0) n = 0;
-    pp_wait_vm_dyn<0, 15>(n);
+    if (u < NST - 1) n += rpre_n;
+    pp_wait_vm_dyn<0, 31>(n);
   };
   unsigned long long* ts = nullptr;
   int tsn = 0;
@@ -281,6 +284,28 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
       issue_range(s, std::integral_constant<int, 0>{}, std::integral_constant<int, NP0>{});
       next_tile();
     }
+  }
+  // ---- the residual tile is fetched NOW, in the layout the epilogue stores in (8 consecutive columns per lane and block pair,
+  // 4 for an odd last block): its first-touch latency (HBM: the tensor was written many kernels ago) flies under the K loop
+  // instead of standing, one dependent round trip per chunk, at the end of a kernel whose grid is a single round.  Plain loads:
+  // the compiler waits for them where the epilogue first reads them (vmcnt(0): everything has long landed); the counted waits of
+  // the loop see them as rpre_n extra operations behind the prologue's pieces.
+  constexpr int NRP = TN / 2, NR1 = TN & 1;                  // 16-byte chunks / trailing 8-byte chunk per output row block
+  const int nb = n0 + g * CPW;
+  const bool has_r = p.R != nullptr && p.splits == 1;
+  const bool pre_r = has_r && !(VAR & PPV_NO_RPRE);
+  uint4 rp16[TM][NRP > 0 ? NRP : 1];
+  uint2 rp8[TM];
+  if (pre_r) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * RPW + 16 * i + l15;
+      const T* rrow = reinterpret_cast<const T*>(p.R) + (size_t)(m < p.M ? m : p.M - 1) * p.ldr;
+#pragma unroll
+      for (int jp = 0; jp < NRP; ++jp) rp16[i][jp] = *reinterpret_cast<const uint4*>(rrow + nb + 16 * (2 * jp + (quad & 1)) + 8 * (quad >> 1));
+      if constexpr (NR1) rp8[i] = *reinterpret_cast<const uint2*>(rrow + nb + 16 * (TN - 1) + 4 * quad);
+    }
+    rpre_n = TM * (NRP + NR1);
   }
   // fragment addresses: per lane (row l15 of a 16-row block, chunk 4 s + quad of the 32-deep k-step s, swizzled); the swizzle
   // term ((row >> 1) & 7) only depends on l15 because every block starts on a multiple of 16 rows
@@ -325,8 +350,7 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
           if (more) issue_range(nstage, std::integral_constant<int, LLO>{}, std::integral_constant<int, LHI>{});
           if constexpr (s == SEG - 1 && XL == NP0) { if (more) next_tile(); }
         };
-        if constexpr (DFIRST) { issue_load_part(); __builtin_amdgcn_sched_barrier(0); stamp(); read_frags(); }
-        else { read_frags(); stamp(); issue_load_part(); }
+        { read_frags(); stamp(); issue_load_part(); }
         stamp();
         // group 1 is in this segment when group 0 finishes MFMA(t, last) and moves on to read tile t + 1
         if constexpr (s == SEG - 1) { if (g == 1) wait_tile(t + 1); }
@@ -372,7 +396,6 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------------
   // acc[i][j][r] = D[m = m0 + wm RPW + 16 i + l15][n = n0 + g CPW + 16 j + 4 quad + r]
-  const int nb = n0 + g * CPW;
   if (p.splits > 1) {
     float* part = p.partial + (size_t)zsplit * p.M * p.N;
 #pragma unroll
@@ -388,13 +411,14 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   }
   typedef T T4 __attribute__((ext_vector_type(4)));
   typedef T T8 __attribute__((ext_vector_type(8)));
-  const bool hb = p.bias != nullptr, hr = p.R != nullptr;
+  const bool hb = p.bias != nullptr, hv = p.rowvec != nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * RPW + 16 * i + l15;
     const bool mok = m < p.M;
     T* crow = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc;
-    const T* rrow = reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr;
+    // per-image vector (the time-embedding projection added to a resnet's first convolution): row m belongs to image m / rows_per_batch
+    const float* vrow = hv ? p.rowvec + (size_t)div_small(mok ? m : 0, p.inv_rows_per_batch) * p.rowvec_ld : nullptr;
 #pragma unroll
     for (int j = 0; j + 1 < TN; j += 2) {
       // blocks j, j + 1: the lane pairs (l, l ^ 16) trade four columns so that every lane holds EIGHT consecutive columns
@@ -416,8 +440,14 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
       }
-      if (hr) {
-        const T8 rv = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(rrow + n));
+      if (hv) {
+        const float4 b0 = *reinterpret_cast<const float4*>(vrow + n), b1 = *reinterpret_cast<const float4*>(vrow + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (has_r) {
+        uint4 raw = rp16[i][j / 2];
+        if (!pre_r) raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n);
+        const T8 rv = __builtin_bit_cast(T8, raw);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] += to_f32<T>(rv[c]);
       }
@@ -432,8 +462,11 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
       if (mok) {
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         if (hb) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        if (hr) {
-          const T4 rv = __builtin_bit_cast(T4, *reinterpret_cast<const uint2*>(rrow + n));
+        if (hv) { const float4 b = *reinterpret_cast<const float4*>(vrow + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        if (has_r) {
+          uint2 raw = rp8[i];
+          if (!pre_r) raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n);
+          const T4 rv = __builtin_bit_cast(T4, raw);
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += to_f32<T>(rv[c]);
         }
@@ -462,8 +495,9 @@ static size_t pp_a_bytes(const GemmK& k) {
 
 bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan) {
   if (force == 1) return false;
-  // what the kernel carries: the plain epilogue (bias, residual), 16-byte aligned rows, descriptors below 2 GiB
-  if (k.ln_s || k.glu_y || k.glub_x || k.rowvec || k.act_silu) return false;
+  // what the kernel carries: the plain epilogue (bias, per-image vector, residual), 16-byte aligned rows, descriptors below 2 GiB
+  if (k.ln_s || k.glu_y || k.glub_x || k.act_silu) return false;
+  if (k.rowvec && (k.rowvec_ld % 4 || ((size_t)k.rowvec & 15))) return false;
   if (k.K % 64 || k.M <= 0 || !k.C) return false;
   if (k.N % 160 && k.N % 128) return false;
   if (k.ldc % 8 || ((size_t)k.C & 15) || k.lda % 8 || ((size_t)k.A & 15) || ((size_t)k.W & 15)) return false;
@@ -479,8 +513,10 @@ bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan)
   int bm = 0, splits = 1;
   if (t256 >= 224) bm = 256;                                 // one round or more of 256-row tiles
   else if (t128 >= 224) bm = 128;                            // (M = 8192, N = 640 at batch 8: 64 x 4)
-  else if (k.partial && ktiles >= 32 && t256 >= 16 && k.M >= 1024) {
-    // long K loops on fewer tiles than CUs: split K over workgroups (f32 slabs + the reduce kernels of gemm.hip)
+  else if (k.partial && ktiles >= 32 && t256 >= 64 && k.M >= 1024 && k.M <= 4096) {
+    // long K loops on fewer tiles than CUs: split K over workgroups (f32 slabs + the reduce kernels of gemm.hip).  Measured for
+    // the 16x16-latent level at batch 8 (M = 2048, N = 1280, K = 11520: 64 tiles x 4 splits, 74.7 -> 65.0 us); the B = 1 / B = 2
+    // shapes of this kind stay on k_gemm_dma's tiles
     bm = 256;
     splits = (int)(256 / t256);
     if (splits > ktiles / 8) splits = ktiles / 8;
@@ -495,9 +531,12 @@ bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan)
   return true;
 }
 
-// the shipped main-loop variant (see the PPV_* flags; A/B in profiles/r05_ab_pp_variants.txt)
-constexpr int PP_SHIP = 0;
-static int g_pp_variant = PP_SHIP;                  // measurement builds (-DDH_PP_VARIANTS): dh_dbg_gemm_pp_variant
+// the shipped main-loop variants (see the PPV_* flags; A/B in profiles/r05_ab_pp_variants.txt): 64-deep segments everywhere
+// (half the barriers: 256x160 conv K = 2880 64.6 -> 61.5 us); of the 7 (256-row tiles) / 5 (128-row tiles) LDS-DMA pieces of a
+// wave and tile the last 1 / 3 go out between the MFMAs of the multiply segment, which balances the two segments of an interval
+// (-> 59.7 us; 128x160 conv K = 5760 76.2 -> 65.9 us)
+constexpr int PP_SHIP_256 = PPV_K64 | (1 << PPV_NDIM_SHIFT), PP_SHIP_128 = PPV_K64 | (3 << PPV_NDIM_SHIFT);
+static int g_pp_variant = -1;                       // measurement builds (-DDH_PP_VARIANTS): dh_dbg_gemm_pp_variant; -1 = shipped
 static unsigned long long* g_pp_ts = nullptr;
 
 template <class T, int BM, int BN, int NST, int VAR>
@@ -510,17 +549,19 @@ static void pp_launch_tile(int mode, dim3 grid, hipStream_t st, const GemmK& k, 
   if (mode == PP_DENSE) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_DENSE, NST, VAR>));
   else if (mode == PP_CONV_S1) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_CONV_S1, NST, VAR>));
   else {
-    if constexpr (VAR == PP_SHIP) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_GENERIC, NST, VAR>));
+    if constexpr (VAR == (BM == 256 ? PP_SHIP_256 : PP_SHIP_128)) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_GENERIC, NST, VAR>));
   }
 #undef DH_PP_LAUNCH
 }
 
+// VAR < 0: the shipped variant of the tile
 template <class T, int VAR>
 static void pp_launch_var(const GemmK& k, const PpPlan& plan, int mode, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  if (plan.bm == 256 && plan.bn == 160) pp_launch_tile<T, 256, 160, 3, VAR>(mode, grid, st, k, e0, e1);
-  else if (plan.bm == 256) pp_launch_tile<T, 256, 128, 3, VAR>(mode, grid, st, k, e0, e1);
-  else if (plan.bn == 160) pp_launch_tile<T, 128, 160, 4, VAR>(mode, grid, st, k, e0, e1);
-  else pp_launch_tile<T, 128, 128, 4, VAR>(mode, grid, st, k, e0, e1);
+  constexpr int V256 = VAR < 0 ? PP_SHIP_256 : VAR, V128 = VAR < 0 ? PP_SHIP_128 : VAR;
+  if (plan.bm == 256 && plan.bn == 160) pp_launch_tile<T, 256, 160, 3, V256>(mode, grid, st, k, e0, e1);
+  else if (plan.bm == 256) pp_launch_tile<T, 256, 128, 3, V256>(mode, grid, st, k, e0, e1);
+  else if (plan.bn == 160) pp_launch_tile<T, 128, 160, 4, V128>(mode, grid, st, k, e0, e1);
+  else pp_launch_tile<T, 128, 128, 4, V128>(mode, grid, st, k, e0, e1);
 }
 
 template <class T>
@@ -531,18 +572,17 @@ static void pp_launch(const GemmK& k, const PpPlan& plan, int mode, dim3 grid, h
     if (mode != PP_GENERIC) {
       switch (g_pp_variant) {
 #define DH_PP_CASE(V) case V: pp_launch_var<T, V>(k, plan, mode, grid, st, e0, e1); return;
-        DH_PP_CASE(1) DH_PP_CASE(2) DH_PP_CASE(4) DH_PP_CASE(5) DH_PP_CASE(6) DH_PP_CASE(7)
+        DH_PP_CASE(0) DH_PP_CASE(1) DH_PP_CASE(2) DH_PP_CASE(4) DH_PP_CASE(5) DH_PP_CASE(6) DH_PP_CASE(7)
         DH_PP_CASE(4 + 16) DH_PP_CASE(4 + 32) DH_PP_CASE(4 + 48) DH_PP_CASE(4 + 64) DH_PP_CASE(4 + 80)
         DH_PP_CASE(5 + 16) DH_PP_CASE(5 + 32) DH_PP_CASE(5 + 48) DH_PP_CASE(5 + 64)
-        DH_PP_CASE(32) DH_PP_CASE(48)
-        DH_PP_CASE(8) DH_PP_CASE(9) DH_PP_CASE(12) DH_PP_CASE(13) DH_PP_CASE(12 + 16) DH_PP_CASE(12 + 32) DH_PP_CASE(13 + 32) DH_PP_CASE(12 + 48) DH_PP_CASE(12 + 64)
+        DH_PP_CASE(32) DH_PP_CASE(48) DH_PP_CASE(20 + 8) DH_PP_CASE(52 + 8)
 #undef DH_PP_CASE
         default: break;
       }
     }
   }
 #endif
-  pp_launch_var<T, PP_SHIP>(k, plan, mode, grid, st, e0, e1);
+  pp_launch_var<T, -1>(k, plan, mode, grid, st, e0, e1);
 }
 
 void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
@@ -575,9 +615,9 @@ void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t
 // library accepts only the shipped one) and the device buffer (2 x 512 u64) the stamping variants write their timeline to
 extern "C" int dh_dbg_gemm_pp_variant(int variant, unsigned long long* ts) {
 #ifndef DH_PP_VARIANTS
-  DH_REQUIRE(variant == dh::PP_SHIP, "this build carries the shipped k_gemm_pp variant only (tools/lab.sh build-pp-variants)");
+  DH_REQUIRE(variant < 0, "this build carries the shipped k_gemm_pp variants only (tools/lab.sh build-pp-variants)");
 #endif
-  DH_REQUIRE(variant >= 0 && variant < 128, "variant: bit 0 stamps, bit 1 all DMA inside the MFMA segment, bit 2 64-deep segments, bits 4-6 pieces inside the MFMA segment");
+  DH_REQUIRE(variant >= -1 && variant < 128, "variant: bit 0 stamps, bit 1 all DMA inside the MFMA segment, bit 2 64-deep segments, bits 4-6 pieces inside the MFMA segment");
   dh::g_pp_variant = variant;
   dh::g_pp_ts = ts;
   return DH_OK;

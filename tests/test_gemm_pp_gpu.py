@@ -44,6 +44,11 @@ def test_pp_dense_matches_torch(family, dtype, M, N, K):
     close(run_gemm(dtype, A, K, W, M, N, K, bias=bias, R=R), A.float() @ W.float().t() + bias + R.float(), tol, tol, "pp bias+R")
     close(run_gemm(dtype, A, K, W, M, N, K), A.float() @ W.float().t(), tol, tol, "pp plain")
     close(run_gemm(dtype, A, K, W, M, N, K, bias=bias, split=False), A.float() @ W.float().t() + bias, tol, tol, "pp bias")
+    # the per-image vector of a resnet's first convolution (time-embedding projection): row m belongs to image m // (M / 2)
+    if M % 2 == 0:
+        rv = torch.randn(2, N, generator=g, device=dev())
+        ref = A.float() @ W.float().t() + bias + rv.repeat_interleave(M // 2, dim=0) + R.float()
+        close(run_gemm(dtype, A, K, W, M, N, K, bias=bias, rowvec=rv, rpb=M // 2, R=R), ref, tol, tol, "pp bias + rowvec + R")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

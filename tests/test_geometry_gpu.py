@@ -314,6 +314,34 @@ def test_real_scene_edits_bit_exact_vs_reference_golden(golden):
     assert np.array_equal(corr1.numpy(), g["edit_002_corr"].astype(np.int64))
 
 
+def test_second_real_scene_edits_bit_exact_vs_reference_golden(golden):
+    """The second scene of the reference's test data (tests/golden/scene_dice, g15): both transforms (a translation and the
+    identity) in one batched call, integer maps bit-exact against what the reference produced."""
+    import os
+    from oracle import depth_ref as D
+    from diffusionhandles_amd import depth_transform as DT
+    from diffusionhandles_amd import scene_io as S
+    g = golden("g15_scene_dice.npz")
+    sc = S.load_scene(os.path.join(os.path.dirname(__file__), "golden", "scene_dice"), 512)
+    dev = _dev()
+    names = list(sc["transforms"].keys())
+    tf = []
+    for n in names:
+        kw = S.transform_args(sc["transforms"][n])
+        tf.append((kw["rot_angle"], kw["rot_axis"], kw["translation"]))
+    out, dbg = DT.reproject_edits(sc["depth"].to(dev), sc["bg_depth"].to(dev), sc["fg_mask"].to(dev), D.intrinsics_f32(), tf,
+                                  return_debug=True)
+    for e, n in enumerate(names):
+        disp, corr = out[e]
+        assert np.array_equal(corr.numpy(), g[f"{n}_corr"].astype(np.int64)), n
+        assert np.array_equal(np.packbits(dbg["raw_mask"][e].cpu().numpy() != 0), g[f"{n}_mask"]), n
+        assert np.array_equal(np.packbits(dbg["clean_mask"][e].cpu().numpy() != 0), g[f"{n}_cleaned"]), n
+        assert np.array_equal(np.packbits(dbg["vis"][e].cpu().numpy() != 0), g[f"{n}_vis"]), n
+        assert np.array_equal(dbg["zmap"][e].cpu().numpy()[::37, ::41], g[f"{n}_zmap_slice"]), n
+        d = disp[0, 0].cpu().numpy()
+        assert np.allclose(d[::5, ::7], g[f"{n}_disp_slice"], atol=2e-3, rtol=0), n
+
+
 def test_set_foreground_on_the_real_scene_vs_oracle():
     """The reference's scene at full size: two independently estimated depth maps (image / in-painted background) blended
     around the object; GPU CG vs the oracle's sparse direct solve."""

@@ -568,6 +568,60 @@ def test_scene_harness_identity_cache_round_trip_and_skip_existing(tmp_path):
     assert os.path.getmtime(os.path.join(out2, "edit_000.png")) == before
 
 
+def test_scene_harness_test_set_loop_with_a_configuration_file(tmp_path):
+    """The outer loop of the reference's harness (test/test_diffusion_handles.py:302-323, 42-75, 126-135): tools/run_edit.py
+    --test-set JSON --input-dir DIR --config YAML over TWO scenes of the reference's test data (banana_fruits, dice), one edit
+    each, under the bg_erosion_10_local_avg variant configuration (eroded background masks, local_avg background loss: the
+    general, non-planned energy path, at the full size): one output directory per scene, config.yaml and the summary page
+    beside them; a second run with --skip-existing skips both scenes without touching the GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from diffusionhandles_amd import scene_io as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    inp = tmp_path / "photogen"
+    inp.mkdir()
+    os.symlink(os.path.join(gold, "scene_banana_fruits"), inp / "banana_fruits")
+    os.symlink(os.path.join(gold, "scene_dice"), inp / "dice")
+    (inp / "mini.json").write_text(json.dumps({"banana_fruits": ["edit_001", "edit_777"], "dice": ["edit_000"]}))
+    cfg = tmp_path / "bg_erosion_10_local_avg.yaml"          # the values of the reference's test/config/bg_erosion_10_local_avg.yaml
+    cfg.write_text(yaml.safe_dump({"guided_diffuser": {"bg_weight": 0.5, "fg_weight": 1.5, "fg_patch_size": 1, "bg_patch_size": 1,
+                                                       "use_depth": True, "save_denoising_steps": False, "bg_loss_type": "local_avg",
+                                                       "num_timesteps": 50, "num_optsteps": 3, "guidance_max_step": 38,
+                                                       "guidance_schedule_type": "constant", "bg_erosion": 10, "seed": 2773},
+                                   "depth_transform_mode": "pc"}))
+    out = str(tmp_path / "results")
+    cmd = [sys.executable, os.path.join(root, "tools", "run_edit.py"), "--test-set", str(inp / "mini.json"), "--input-dir", str(inp),
+           "--config", str(cfg), "--out", out, "--skip-inversion", "--no-identity-cache"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [s_["scene"] for s_ in rep["scenes"]] == ["banana_fruits", "dice"] and rep["edits_run"] == 2 and rep["edits_skipped"] == 0
+    assert "edit_777" in r.stderr                                           # a transform the scene does not have: warned and skipped
+    saved = yaml.safe_load(open(os.path.join(out, "config.yaml")))
+    assert saved["guided_diffuser"]["bg_erosion"] == 10 and saved["guided_diffuser"]["bg_loss_type"] == "local_avg"
+    assert os.path.exists(os.path.join(out, "mini_summary.html")) and os.path.exists(os.path.join(out, "report.json"))
+    for scene, edit in (("banana_fruits", "edit_001"), ("dice", "edit_000")):
+        for f in ("recon.png", f"{edit}.png", f"{edit}_disparity.png", "summary.html", "input.png", "mask.png"):
+            assert os.path.exists(os.path.join(out, scene, f)), (scene, f)
+        assert S.read_png(os.path.join(out, scene, f"{edit}.png")).shape == (512, 512, 3)
+    assert not os.path.exists(os.path.join(out, "banana_fruits", "edit_000.png"))        # not in the test set's list
+    before = os.path.getmtime(os.path.join(out, "dice", "edit_000.png"))
+    r2 = subprocess.run(cmd + ["--skip-existing"], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    rep2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert rep2["edits_run"] == 0 and rep2["edits_skipped"] == 2 and all(s_.get("skipped_scene") for s_ in rep2["scenes"])
+    assert os.path.getmtime(os.path.join(out, "dice", "edit_000.png")) == before
+    # an unknown key in the configuration file is an error, not a silent default
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("guided_diffuser:\n  bg_errosion: 10\n")
+    r3 = subprocess.run(cmd[:-4] + ["--config", str(bad), "--out", out], capture_output=True, text=True, timeout=120)
+    assert r3.returncode != 0 and "bg_errosion" in r3.stderr
+
+
 def test_sharded_edit_driver_on_one_gpu(tmp_path):
     """tools/run_edits_sharded.py (BASELINE config 4's driver) on the one GPU of the box: 5 edits in batches of 2 (so a
     ragged last batch), identity from initial inference, images written, report with the whole-job edits/s."""

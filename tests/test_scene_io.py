@@ -444,3 +444,33 @@ def test_exr_piz_round_trip_with_independent_encoder(tmp_path, case):
         assert np.array_equal(S.read_exr(str(tmp_path / "q.exr"))["Y"], ch["Y"].astype(np.float32))
         if case == "flat":
             assert len(data) < len(norun)                       # the run-length symbol was exercised
+
+
+SCENE2 = os.path.join(os.path.dirname(__file__), "golden", "scene_dice")
+
+
+def test_second_reference_scene_exr_and_oracle_vs_reference_golden(golden):
+    """A second scene of the reference's test data (test/data/photogen/dice: other PIZ streams, another mask, a translation-only
+    and an identity transform; tools/make_golden_scene.py scene_dice g15_scene_dice.npz): the EXR reader reproduces the depth
+    the reference's functions were run on (hashes), and the oracle reproduces the reference's integer maps on it."""
+    import hashlib
+    from oracle import depth_ref as D
+    g = golden("g15_scene_dice.npz")
+    sc = S.load_scene(SCENE2, 512)
+    assert sc["prompt"] == "a dice on the table" and list(sc["transforms"].keys()) == ["edit_000", "edit_001"]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(sc["depth"].numpy()) == str(g["depth_sha"]) and sha(sc["bg_depth"].numpy()) == str(g["bg_depth_sha"])
+    assert sha(sc["img"].numpy()) == str(g["img_sha"])
+    assert np.array_equal(np.packbits(sc["fg_mask"].numpy() != 0), g["mask_bits"])
+    assert np.array_equal(sc["depth"][0, 0].numpy()[::37, ::41], g["depth_slice"])
+    d = sc["depth"][0, 0].numpy()
+    assert np.abs(np.diff(d, axis=0)).mean() < 0.02 and np.abs(np.diff(d, axis=1)).mean() < 0.02      # a decoded depth map, not noise
+    for name in ("edit_000", "edit_001"):
+        t = sc["transforms"][name]
+        disp, corr, dbg = D.transform_depth_pc(sc["depth"], sc["bg_depth"], sc["fg_mask"], D.intrinsics_f32(),
+                                               rot_angle=t["rotation_angle"], rot_axis=t["rotation_axis"],
+                                               translation=t["translation"], return_debug=True)
+        assert np.array_equal(corr.numpy(), g[f"{name}_corr"].astype(np.int64)), name
+        assert np.array_equal(np.packbits(dbg["cleaned"] != 0), g[f"{name}_cleaned"]), name
+        assert np.array_equal(dbg["zmap"][::37, ::41], g[f"{name}_zmap_slice"]), name
+        assert np.allclose(disp[0, 0].numpy()[::5, ::7], g[f"{name}_disp_slice"], atol=1e-4, rtol=0), name

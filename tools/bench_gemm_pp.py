@@ -64,7 +64,7 @@ def run(M, N, K, conv, iters=20, rounds=3):
                 e0.record(); call(); e1.record(); torch.cuda.synchronize()
                 tot += e0.elapsed_time(e1) * 1e3
             res.setdefault(("cold", fam), []).append(tot / 6)
-    L.dh_dbg_gemm_family(0); L.dh_dbg_gemm_pp_variant(0, None)
+    L.dh_dbg_gemm_family(0); L.dh_dbg_gemm_pp_variant(-1, None)
     fl = 2.0 * M * N * K
     med = lambda v: sorted(v)[len(v) // 2]
     out = f"M={M:6d} N={N:5d} K={K:6d} {'conv' if conv else 'dense':5s}:"
@@ -74,7 +74,7 @@ def run(M, N, K, conv, iters=20, rounds=3):
     print(out, flush=True)
 
 
-VARS = [int(v) for v in os.environ.get("DH_PP_VARS", "0").split(",")]
+VARS = [int(v) for v in os.environ.get("DH_PP_VARS", "-1").split(",")]
 which = sys.argv[1] if len(sys.argv) > 1 else "b8"
 KEY = [B8[0], B8[3], B8[6], B8[7], B8[9], B8[11]]       # one per class: the shapes the review names
 shapes = {"b8": B8, "l96": L96, "b16": B16, "all": B8 + B16 + L96, "key": KEY}[which]

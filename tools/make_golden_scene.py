@@ -20,12 +20,12 @@ from make_golden import D, OUT, sha  # noqa: E402
 from diffusionhandles_amd import scene_io as S  # noqa: E402
 
 
-def main():
+def main(scene="scene_banana_fruits", out_name="g11_scene.npz"):
     MG.install_stubs()
     import diffhandles.depth_transform as RD
     import diffhandles.guided_stable_diffuser as RG
     K = RG.GuidedStableDiffuser.get_depth_intrinsics()
-    sc = S.load_scene(os.path.join(OUT, "scene_banana_fruits"), 512)
+    sc = S.load_scene(os.path.join(OUT, scene), 512)
     depth, bg_depth, mask = sc["depth"], sc["bg_depth"], sc["fg_mask"]
     res = 512
     g = dict(depth_sha=sha(depth.numpy()), bg_depth_sha=sha(bg_depth.numpy()), mask_bits=np.packbits(mask.numpy() != 0),
@@ -60,9 +60,15 @@ def main():
         g[f"{name}_disp_slice"] = disp_r[0, 0].numpy()[::5, ::7].copy()
         g[f"{name}_disp_sum"] = np.float64(disp_r.double().sum().item())
         print(f"  {name}: angle {ang} t {tr}: N_vis={int(viso.sum())} N_corr={corr_r.shape[0]} inpaint={int(dbg['inpaint'].sum())}")
-    np.savez_compressed(os.path.join(OUT, "g11_scene.npz"), **g)
-    print("G11 ok")
+    np.savez_compressed(os.path.join(OUT, out_name), **g)
+    print(out_name, "ok")
 
 
 if __name__ == "__main__":
-    main()
+    # g11: test/data/photogen/banana_fruits; g15 (round 5): test/data/photogen/dice -- a second pair of estimated depth maps, so
+    # that the EXR reader and the integer maps are pinned on two scenes (copies of the reference's DATA files under tests/golden/)
+    if len(sys.argv) > 1:
+        main(sys.argv[1], sys.argv[2])
+    else:
+        main()
+        main("scene_dice", "g15_scene_dice.npz")

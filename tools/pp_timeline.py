@@ -29,7 +29,7 @@ def run(M, N, K, conv, var):
         L.dh_dbg_gemm_pp_variant(var | 1, P(ts))
         L.dh_dbg_gemm(0, P(A), lda, P(W), M, N, K, mode, *geo, P(None), P(None), 0, 1, P(None), N, P(C), N, 0, P(part), part.numel(), _lib.stream_ptr())
         torch.cuda.synchronize()
-    L.dh_dbg_gemm_family(0); L.dh_dbg_gemm_pp_variant(0, None)
+    L.dh_dbg_gemm_family(0); L.dh_dbg_gemm_pp_variant(-1, None)
     t = ts.cpu().numpy()
     seg = 1 if var & 4 else 2
     names = ["reads issued", "DMA issued", "vm wait", "lds wait", "barrier A", "MFMA", "(wait+) barrier B"]
@@ -51,6 +51,6 @@ def run(M, N, K, conv, var):
 shapes = [(32768, 320, 2880, (8, 64, 320)), (8192, 640, 5760, (8, 32, 640)), (32768, 320, 320, None)]
 if os.environ.get("DH_PP_SHAPES"):
     shapes = [shapes[int(i)] for i in os.environ["DH_PP_SHAPES"].split(",")]
-for var in [int(v) for v in os.environ.get("DH_PP_VARS", "0,2,4,6").split(",")]:
+for var in [int(v) for v in os.environ.get("DH_PP_VARS", "20,52").split(",")]:
     for s in shapes:
         run(*s, var)

@@ -199,11 +199,11 @@ def run_scene(args, conf, handles, scene, out, transform_names):
             report["edits"].append(dict(name=tf["name"], skipped=True))
             continue
         t0 = time.time()
-        out = dh.transform_foreground(depth, prompt, mask, bg_depth, null_text, noise, acts, rot_angle=tf["rot_angle"],
+        res_ = dh.transform_foreground(depth, prompt, mask, bg_depth, null_text, noise, acts, rot_angle=tf["rot_angle"],
                                       rot_axis=tf["rot_axis"], translation=tf["translation"])
         torch.cuda.synchronize()
         dt = time.time() - t0
-        edited, disparity = out[0], out[1]
+        edited, disparity = res_[0], res_[1]
         name = tf["name"]
         write_png(os.path.join(out, f"{name}.png"), edited[0].permute(1, 2, 0).float().cpu().numpy())
         write_png(os.path.join(out, f"{name}_disparity.png"), (disparity[0, 0] / disparity.max()).float().cpu().numpy())
