@@ -487,6 +487,9 @@ def main():
     # ---- secondary measurements (rank 0).  They never gate the headline line: a failure is reported in place of the numbers.
     def hbm_records(gd_, st_, depth_, bg_, mask_, res):
         def timed(fn, n=20, graph=False):
+            # (a graph-replayed record is warmed with 60 replays and timed over 100: round 4's first record -- 20 replays of a 17 us
+            #  evaluation right behind seconds of batched edits -- read 33 us where rocprofv3 says 17: 0.4 ms of tiny launches do
+            #  not bring the clocks back up)
             for _ in range(3):
                 fn()
             if graph:       # replay through a captured graph: device time of the launches, no host gaps between them
@@ -503,6 +506,10 @@ def main():
                     sections.note("hbm_records.graph_capture", exc)
                     fn = eager
                     graphed.append(False)
+            if graph and graphed and graphed[-1]:
+                n = max(n, 100)
+                for _ in range(60):
+                    fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(n):

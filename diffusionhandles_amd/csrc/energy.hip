@@ -317,8 +317,8 @@ static void pair_term(const EnergyWs& w, const int* pairs, int n, int C, int gri
 // The default configuration (maps already at the cell grid, fg_patch 1, 'global_avg' background) needs no f32
 // staging, no pooling and -- because the correspondences are fixed for an edit -- no CSR rebuild per evaluation:
 //   plan (once per edit)  : CSR target cell -> source cells, flag of the transformed-background cells
-//   per evaluation        : k_colsum16 (both background column sums, same slice order as k_colsum)
-//                           k_global_diff (sign of the mean difference per channel)
+//   per evaluation        : k_bg_sign (both background column sums in the slice order of k_colsum and the sign of the mean
+//                                      difference per channel in the order of k_global_diff: ONE launch since round 5)
 //                           k_energy_grad (pair term + background term -> one 16-byte gradient store per lane)
 //                           k_final_loss  (only when the caller wants the loss values)
 // Same arithmetic, in the same order per element, as the general path above: the gradient is bit-identical.
@@ -340,9 +340,9 @@ struct PlannedWs {
 };
 static bool carve_planned(Arena& a, int C, int grid, PlannedWs& w) {
   const size_t G2 = (size_t)grid * grid;
-  w.part1 = a.take<float>((size_t)COLSUM_S * C); w.part2 = a.take<float>((size_t)COLSUM_S * C);
+  w.part1 = nullptr; w.part2 = nullptr;          // (the slice sums meet in LDS since round 5)
   w.sgn = a.take<float>(C);
-  w.fg_part = a.take<double>(G2); w.bg_part = a.take<double>(cdiv(C, GD_BLOCK));
+  w.fg_part = a.take<double>(G2); w.bg_part = a.take<double>(C / 8 + 1);
   return a.ok();
 }
 
@@ -379,24 +379,40 @@ __global__ void k_flag_cells(const int* list, int n, uint8_t* flag) {
   if (i < n) flag[list[i]] = 1;
 }
 
-// part[z][s][c] = sum over the s-th slice of list z of X_z[cell][c]; thread = (slice, 8-channel chunk), cells in
-// list order (the order k_colsum adds them in)
+// Background (global_avg) term in ONE launch (round 5; k_colsum16 + k_global_diff used to be two dependent launches at the
+// ~4.5 us floor each): workgroup = one 8-channel chunk, 256 threads = (list z, slice s) for the two cell lists and COLSUM_S = 128
+// slices.  A thread adds the rows of its slice in list order (16 gathers in flight), the 2 x 128 slice sums meet in LDS and are
+// combined in EXACTLY the order of k_colsum (general path) + k_global_diff -- slices of a quarter in slice order, then
+// ((q0 + q1) + q2) + q3 -- so sgn[c], and with it the gradient, keeps its bits.  loss_part[chunk] = sum_i |d_i| of the chunk.
 template <class T>
-__global__ void k_colsum16(const T* X1, const int* list1, int n1, float* part1, const T* X2, const int* list2, int n2,
-                           float* part2, int C, int S) {
-  const T* X = blockIdx.y ? X2 : X1;
-  const int* list = blockIdx.y ? list2 : list1;
-  const int n = blockIdx.y ? n2 : n1;
-  float* part = blockIdx.y ? part2 : part1;
-  const int nch = C / 8, idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nch * S) return;
-  const int s = idx / nch, ch = idx - s * nch;
-  const int per = (n + S - 1) / S, b = s * per, e = b + per < n ? b + per : n;
+__global__ void __launch_bounds__(2 * COLSUM_S) k_bg_sign(const T* X1, const int* list1, int n1, const T* X2, const int* list2, int n2,
+                                                          int C, float* sgn, double* loss_part) {
+  __shared__ float sp[2][COLSUM_S][8];
+  __shared__ float sq[2][4][8];
+  const int ch = blockIdx.x, z = threadIdx.x / COLSUM_S, sl = threadIdx.x % COLSUM_S;
+  const T* X = z ? X2 : X1;
+  const int* list = z ? list2 : list1;
+  const int n = z ? n2 : n1;
+  const int per = (n + COLSUM_S - 1) / COLSUM_S, b = sl * per, e = b + per < n ? b + per : n;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   int k = b;
-  for (; k + 8 <= e; k += 8) {          // 8 gathers in flight; the adds keep the list order
+  for (; k + 16 <= e; k += 16) {          // 16 gathers in flight; the adds keep the list order
+    int id[16];
+    uint4 raw[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) id[j] = list[k + j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + (size_t)id[j] * C + ch * 8);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const T* v = reinterpret_cast<const T*>(&raw[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
+    }
+  }
+  if (k + 8 <= e) {
     int id[8];
     uint4 raw[8];
 #pragma unroll
@@ -409,6 +425,7 @@ __global__ void k_colsum16(const T* X1, const int* list1, int n1, float* part1, 
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
     }
+    k += 8;
   }
   for (; k < e; ++k) {
     const uint4 raw = *reinterpret_cast<const uint4*>(X + (size_t)list[k] * C + ch * 8);
@@ -417,7 +434,28 @@ __global__ void k_colsum16(const T* X1, const int* list1, int n1, float* part1, 
     for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) part[(size_t)s * C + ch * 8 + i] = acc[i];
+  for (int i = 0; i < 8; ++i) sp[z][sl][i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < 64) {                 // (list, quarter, channel): the slices of a quarter in slice order
+    const int zz = threadIdx.x >> 5, q = (threadIdx.x >> 3) & 3, i = threadIdx.x & 7;
+    constexpr int QP = (COLSUM_S + 3) / 4;
+    const int s0 = q * QP, s1 = s0 + QP < COLSUM_S ? s0 + QP : COLSUM_S;
+    float a = 0.f;
+    for (int s = s0; s < s1; ++s) a += sp[zz][s][i];
+    sq[zz][q][i] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int i = threadIdx.x;
+    const float a = ((sq[0][0][i] + sq[0][1][i]) + sq[0][2][i]) + sq[0][3][i];
+    const float bb = ((sq[1][0][i] + sq[1][1][i]) + sq[1][2][i]) + sq[1][3][i];
+    const float d = a / (float)n1 - bb / (float)n2;
+    sgn[ch * 8 + i] = (float)((d > 0.f) - (d < 0.f));
+    double l = (double)fabsf(d);
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+    if (i == 0) loss_part[ch] = l;
+  }
 }
 
 // thread = (target cell, 8-channel chunk); block = 256 / (C/8) cells
@@ -639,15 +677,12 @@ extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int 
   int use_bg = 0;
   if (n_bg_orig > 0 && n_bg_trans > 0) {
     DH_REQUIRE(bg_orig && bg_trans, "null bg list");
-    const int nthreads = (C / 8) * COLSUM_S;
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_colsum16<f16>), dim3(cdiv(nthreads, 256), 2), dim3(256), 0, st, (const f16*)orig, bg_orig, n_bg_orig,
-                         w.part1, (const f16*)cur, bg_trans, n_bg_trans, w.part2, C, COLSUM_S);
+      hipLaunchKernelGGL((k_bg_sign<f16>), dim3(C / 8), dim3(2 * COLSUM_S), 0, st, (const f16*)orig, bg_orig, n_bg_orig, (const f16*)cur,
+                         bg_trans, n_bg_trans, C, w.sgn, w.bg_part);
     else
-      hipLaunchKernelGGL((k_colsum16<bf16>), dim3(cdiv(nthreads, 256), 2), dim3(256), 0, st, (const bf16*)orig, bg_orig,
-                         n_bg_orig, w.part1, (const bf16*)cur, bg_trans, n_bg_trans, w.part2, C, COLSUM_S);
-    hipLaunchKernelGGL(k_global_diff, dim3(cdiv(C, GD_BLOCK)), dim3(4 * GD_BLOCK), 0, st, w.part1, w.part2, COLSUM_S, C, n_bg_orig,
-                       n_bg_trans, w.sgn, w.bg_part);
+      hipLaunchKernelGGL((k_bg_sign<bf16>), dim3(C / 8), dim3(2 * COLSUM_S), 0, st, (const bf16*)orig, bg_orig, n_bg_orig,
+                         (const bf16*)cur, bg_trans, n_bg_trans, C, w.sgn, w.bg_part);
     bg_norm = 1.f / (float)C;
     coef_bg = bg_w * bg_norm / (float)n_bg_trans;
     use_bg = 1;
@@ -666,7 +701,7 @@ extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int 
 #undef DH_EG
   if (loss_out)
     hipLaunchKernelGGL(k_final_loss, dim3(1), dim3(256), 0, st, w.fg_part, n_pairs > 0 ? nblocks : 0, fg_norm, w.bg_part,
-                       use_bg ? cdiv(C, GD_BLOCK) : 0, bg_norm, fg_w, bg_w, loss_out);
+                       use_bg ? C / 8 : 0, bg_norm, fg_w, bg_w, loss_out);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
