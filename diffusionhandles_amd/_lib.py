@@ -24,7 +24,7 @@ class UNetConfig(ctypes.Structure):
     _fields_ = [("in_channels", c_i), ("out_channels", c_i), ("n_levels", c_i),
                 ("block_out_channels", c_i * 4), ("layers_per_block", c_i), ("heads", c_i * 4),
                 ("cross_attention_dim", c_i), ("norm_groups", c_i), ("sample_size", c_i),
-                ("text_len", c_i), ("max_batch", c_i), ("dtype", c_i)]
+                ("text_len", c_i), ("max_batch", c_i), ("dtype", c_i), ("max_diff_batch", c_i)]
 
 
 class VAEConfig(ctypes.Structure):

@@ -317,9 +317,10 @@ static void pair_term(const EnergyWs& w, const int* pairs, int n, int C, int gri
 // The default configuration (maps already at the cell grid, fg_patch 1, 'global_avg' background) needs no f32
 // staging, no pooling and -- because the correspondences are fixed for an edit -- no CSR rebuild per evaluation:
 //   plan (once per edit)  : CSR target cell -> source cells, flag of the transformed-background cells
-//   per evaluation        : k_bg_sign (both background column sums in the slice order of k_colsum and the sign of the mean
-//                                      difference per channel in the order of k_global_diff: ONE launch since round 5)
-//                           k_energy_grad (pair term + background term -> one 16-byte gradient store per lane)
+//   per evaluation        : k_colsum_q (both background column sums in the slice order of k_colsum, combined per quarter of
+//                                       the slices as k_global_diff combines them)
+//                           k_energy_grad (prologue: sign of the mean difference per channel from the quarter sums -- the rest of
+//                                          k_global_diff's arithmetic; then pair term + background term -> one 16-byte gradient store per lane)
 //                           k_final_loss  (only when the caller wants the loss values)
 // Same arithmetic, in the same order per element, as the general path above: the gradient is bit-identical.
 struct EnergyPlan {
@@ -335,14 +336,13 @@ static bool carve_plan(Arena& a, int grid, int n_pairs, EnergyPlan& p) {
   return a.ok();
 }
 struct PlannedWs {
-  float *part1, *part2, *sgn;
+  float* partq;                  // [2 lists][4 quarters][C] quarter sums of the background column sums (k_colsum_q)
   double *fg_part, *bg_part;
 };
 static bool carve_planned(Arena& a, int C, int grid, PlannedWs& w) {
   const size_t G2 = (size_t)grid * grid;
-  w.part1 = nullptr; w.part2 = nullptr;          // (the slice sums meet in LDS since round 5)
-  w.sgn = a.take<float>(C);
-  w.fg_part = a.take<double>(G2); w.bg_part = a.take<double>(C / 8 + 1);
+  w.partq = a.take<float>((size_t)8 * C);
+  w.fg_part = a.take<double>(G2); w.bg_part = a.take<double>(2);
   return a.ok();
 }
 
@@ -379,95 +379,111 @@ __global__ void k_flag_cells(const int* list, int n, uint8_t* flag) {
   if (i < n) flag[list[i]] = 1;
 }
 
-// Background (global_avg) term in ONE launch (round 5; k_colsum16 + k_global_diff used to be two dependent launches at the
-// ~4.5 us floor each): workgroup = one 8-channel chunk, 256 threads = (list z, slice s) for the two cell lists and COLSUM_S = 128
-// slices.  A thread adds the rows of its slice in list order (16 gathers in flight), the 2 x 128 slice sums meet in LDS and are
-// combined in EXACTLY the order of k_colsum (general path) + k_global_diff -- slices of a quarter in slice order, then
-// ((q0 + q1) + q2) + q3 -- so sgn[c], and with it the gradient, keeps its bits.  loss_part[chunk] = sum_i |d_i| of the chunk.
+// Background (global_avg) term, first half (round 5: the evaluation is two launches, k_colsum_q -> k_energy_grad; it used to be
+// k_colsum16 -> k_global_diff -> k_energy_grad).  Workgroup = (64 channels, quarter q of the COLSUM_S = 128 slices, list z); thread
+// = (slice of the quarter, 8-channel chunk): the eight lanes of a slice read 128 contiguous bytes of a row.  A thread adds the rows
+// of its slice in list order (16 gathers in flight), the 32 slice sums of the quarter are added in slice order through LDS:
+// partq[z][q][c] -- exactly k_colsum's slices combined the way k_global_diff combines the slices of a quarter, so that
+// ((q0 + q1) + q2) + q3 in k_energy_grad's prologue reproduces sgn[c] bit for bit.
+constexpr int CQ_SL = COLSUM_S / 4;          // slices per quarter
 template <class T>
-__global__ void __launch_bounds__(2 * COLSUM_S) k_bg_sign(const T* X1, const int* list1, int n1, const T* X2, const int* list2, int n2,
-                                                          int C, float* sgn, double* loss_part) {
-  __shared__ float sp[2][COLSUM_S][8];
-  __shared__ float sq[2][4][8];
-  const int ch = blockIdx.x, z = threadIdx.x / COLSUM_S, sl = threadIdx.x % COLSUM_S;
+__global__ void __launch_bounds__(8 * CQ_SL) k_colsum_q(const T* X1, const int* list1, int n1, const T* X2, const int* list2, int n2,
+                                                       int C, float* partq) {
+  __shared__ float sp[CQ_SL][8][8];
+  const int z = blockIdx.z, q = blockIdx.y, sloc = threadIdx.x >> 3, cl = threadIdx.x & 7;
+  const int ch = blockIdx.x * 8 + cl;                       // 8-channel chunk
   const T* X = z ? X2 : X1;
   const int* list = z ? list2 : list1;
   const int n = z ? n2 : n1;
+  const int sl = q * CQ_SL + sloc;
   const int per = (n + COLSUM_S - 1) / COLSUM_S, b = sl * per, e = b + per < n ? b + per : n;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  int k = b;
-  for (; k + 16 <= e; k += 16) {          // 16 gathers in flight; the adds keep the list order
-    int id[16];
-    uint4 raw[16];
+  if (ch * 8 < C) {
+    int k = b;
+    for (; k + 16 <= e; k += 16) {          // 16 gathers in flight; the adds keep the list order
+      int id[16];
+      uint4 raw[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) id[j] = list[k + j];
+      for (int j = 0; j < 16; ++j) id[j] = list[k + j];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + (size_t)id[j] * C + ch * 8);
+      for (int j = 0; j < 16; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + (size_t)id[j] * C + ch * 8);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const T* v = reinterpret_cast<const T*>(&raw[j]);
+      for (int j = 0; j < 16; ++j) {
+        const T* v = reinterpret_cast<const T*>(&raw[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
+      }
+    }
+    if (k + 8 <= e) {
+      int id[8];
+      uint4 raw[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) id[j] = list[k + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + (size_t)id[j] * C + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const T* v = reinterpret_cast<const T*>(&raw[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
+      }
+      k += 8;
+    }
+    for (; k < e; ++k) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(X + (size_t)list[k] * C + ch * 8);
+      const T* v = reinterpret_cast<const T*>(&raw);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
     }
   }
-  if (k + 8 <= e) {
-    int id[8];
-    uint4 raw[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) id[j] = list[k + j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + (size_t)id[j] * C + ch * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const T* v = reinterpret_cast<const T*>(&raw[j]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
-    }
-    k += 8;
-  }
-  for (; k < e; ++k) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(X + (size_t)list[k] * C + ch * 8);
-    const T* v = reinterpret_cast<const T*>(&raw);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += to_f32<T>(v[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) sp[z][sl][i] = acc[i];
+  for (int i = 0; i < 8; ++i) sp[sloc][cl][i] = acc[i];
   __syncthreads();
-  if (threadIdx.x < 64) {                 // (list, quarter, channel): the slices of a quarter in slice order
-    const int zz = threadIdx.x >> 5, q = (threadIdx.x >> 3) & 3, i = threadIdx.x & 7;
-    constexpr int QP = (COLSUM_S + 3) / 4;
-    const int s0 = q * QP, s1 = s0 + QP < COLSUM_S ? s0 + QP : COLSUM_S;
+  if (threadIdx.x < 64) {                   // (chunk, channel): the quarter's slices in slice order
+    const int c2 = threadIdx.x >> 3, i = threadIdx.x & 7;
     float a = 0.f;
-    for (int s = s0; s < s1; ++s) a += sp[zz][s][i];
-    sq[zz][q][i] = a;
-  }
-  __syncthreads();
-  if (threadIdx.x < 8) {
-    const int i = threadIdx.x;
-    const float a = ((sq[0][0][i] + sq[0][1][i]) + sq[0][2][i]) + sq[0][3][i];
-    const float bb = ((sq[1][0][i] + sq[1][1][i]) + sq[1][2][i]) + sq[1][3][i];
-    const float d = a / (float)n1 - bb / (float)n2;
-    sgn[ch * 8 + i] = (float)((d > 0.f) - (d < 0.f));
-    double l = (double)fabsf(d);
-#pragma unroll
-    for (int o = 4; o >= 1; o >>= 1) l += __shfl_xor(l, o);
-    if (i == 0) loss_part[ch] = l;
+    for (int s = 0; s < CQ_SL; ++s) a += sp[s][c2][i];
+    const int c = (blockIdx.x * 8 + c2) * 8 + i;
+    if (c < C) partq[((size_t)z * 4 + q) * C + c] = a;
   }
 }
 
 // thread = (target cell, 8-channel chunk); block = 256 / (C/8) cells
 template <class T, class TG>
 __global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur, const int* off, const int* ucnt,
-                                                     const int* src, const int* mult, const uint8_t* bgflag, const float* sgn, int C, int G2, float coef_fg,
-                                                     float coef_bg, int use_bg, float scale, TG* grad, double* loss_part) {
+                                                     const int* src, const int* mult, const uint8_t* bgflag, const float* partq, int n1, int n2,
+                                                     int C, int G2, float coef_fg,
+                                                     float coef_bg, int use_bg, float scale, TG* grad, double* loss_part, double* bg_loss) {
   __shared__ double sm[4];
   const int nch = C / 8, cpb = (int)blockDim.x / nch;
   const int lc = threadIdx.x / nch, ch = threadIdx.x - lc * nch;
   const int cell = blockIdx.x * cpb + lc;
-  double la = 0.0;
+  double la = 0.0, lb = 0.0;
+  // prologue: sign of the difference of the two background means of this thread's 8 channels from the quarter sums of k_colsum_q
+  // (a 2 x 4 x C f32 table, L2-resident; every lane of a chunk reads the same 16 sectors) -- the arithmetic of k_global_diff
+  float sgn[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sgn[i] = 0.f;
+  if (use_bg && lc < cpb) {
+    float qa[4][8], qb[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(&qa[q][0]) = *reinterpret_cast<const float4*>(partq + (size_t)q * C + ch * 8);
+      *reinterpret_cast<float4*>(&qa[q][4]) = *reinterpret_cast<const float4*>(partq + (size_t)q * C + ch * 8 + 4);
+      *reinterpret_cast<float4*>(&qb[q][0]) = *reinterpret_cast<const float4*>(partq + (size_t)(4 + q) * C + ch * 8);
+      *reinterpret_cast<float4*>(&qb[q][4]) = *reinterpret_cast<const float4*>(partq + (size_t)(4 + q) * C + ch * 8 + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float a = ((qa[0][i] + qa[1][i]) + qa[2][i]) + qa[3][i];
+      const float b = ((qb[0][i] + qb[1][i]) + qb[2][i]) + qb[3][i];
+      const float d = a / (float)n1 - b / (float)n2;
+      sgn[i] = (float)((d > 0.f) - (d < 0.f));
+      if (blockIdx.x == 0 && lc == 0) lb += (double)fabsf(d);          // the loss of the term: once, by the first cell's lanes of block 0
+    }
+  }
   if (lc < cpb && cell < G2) {
     const uint4 ra = *reinterpret_cast<const uint4*>(cur + (size_t)cell * C + ch * 8);
     const T* av = reinterpret_cast<const T*>(&ra);
@@ -512,7 +528,7 @@ __global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur
     for (int i = 0; i < 8; ++i) {
       float g = 0.f;
       if (b < e) g += -coef_fg * (float)sg[i];
-      if (bg) g += -coef_bg * sgn[ch * 8 + i];
+      if (bg) g += -coef_bg * sgn[i];
       o[i] = from_f32<TG>(g * scale);
     }
     if (sizeof(TG) == 2) {
@@ -524,6 +540,10 @@ __global__ void __launch_bounds__(256) k_energy_grad(const T* orig, const T* cur
   }
   la = block_sum(la, sm);
   if (threadIdx.x == 0) loss_part[blockIdx.x] = la;
+  if (blockIdx.x == 0 && use_bg) {
+    lb = block_sum(lb, sm);
+    if (threadIdx.x == 0) bg_loss[0] = lb;
+  }
 }
 
 }  // namespace dh
@@ -649,9 +669,9 @@ extern "C" int dh_energy_planned_workspace_bytes(int C, int grid, size_t* bytes)
 template <class T, class TG>
 static void launch_energy_grad(const void* orig, const void* cur, const EnergyPlan& p, const PlannedWs& w, int C, int G2,
                                float coef_fg, float coef_bg, int use_bg, float scale, void* grad, int nblocks,
-                               hipStream_t st) {
+                               hipStream_t st, int n1, int n2) {
   hipLaunchKernelGGL((k_energy_grad<T, TG>), dim3(nblocks), dim3(256), 0, st, (const T*)orig, (const T*)cur, p.off, p.cnt,
-                     p.src, p.mult, p.bgflag, w.sgn, C, G2, coef_fg, coef_bg, use_bg, scale, (TG*)grad, w.fg_part);
+                     p.src, p.mult, p.bgflag, w.partq, n1, n2, C, G2, coef_fg, coef_bg, use_bg, scale, (TG*)grad, w.fg_part, w.bg_part);
 }
 
 extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int dtype, int C, int grid, const void* plan,
@@ -678,11 +698,11 @@ extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int 
   if (n_bg_orig > 0 && n_bg_trans > 0) {
     DH_REQUIRE(bg_orig && bg_trans, "null bg list");
     if (dtype == DH_DTYPE_F16)
-      hipLaunchKernelGGL((k_bg_sign<f16>), dim3(C / 8), dim3(2 * COLSUM_S), 0, st, (const f16*)orig, bg_orig, n_bg_orig, (const f16*)cur,
-                         bg_trans, n_bg_trans, C, w.sgn, w.bg_part);
+      hipLaunchKernelGGL((k_colsum_q<f16>), dim3(cdiv(C, 64), 4, 2), dim3(8 * CQ_SL), 0, st, (const f16*)orig, bg_orig, n_bg_orig,
+                         (const f16*)cur, bg_trans, n_bg_trans, C, w.partq);
     else
-      hipLaunchKernelGGL((k_bg_sign<bf16>), dim3(C / 8), dim3(2 * COLSUM_S), 0, st, (const bf16*)orig, bg_orig, n_bg_orig,
-                         (const bf16*)cur, bg_trans, n_bg_trans, C, w.sgn, w.bg_part);
+      hipLaunchKernelGGL((k_colsum_q<bf16>), dim3(cdiv(C, 64), 4, 2), dim3(8 * CQ_SL), 0, st, (const bf16*)orig, bg_orig, n_bg_orig,
+                         (const bf16*)cur, bg_trans, n_bg_trans, C, w.partq);
     bg_norm = 1.f / (float)C;
     coef_bg = bg_w * bg_norm / (float)n_bg_trans;
     use_bg = 1;
@@ -692,16 +712,16 @@ extern "C" int dh_energy_fwd_bwd_planned(const void* cur, const void* orig, int 
   const float coef_fg = fg_w * fg_norm;
 #define DH_EG(T_)                                                                                                          \
   do {                                                                                                                     \
-    if (grad_dtype == DH_DTYPE_F16) launch_energy_grad<T_, f16>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st);        \
-    else if (grad_dtype == DH_DTYPE_BF16) launch_energy_grad<T_, bf16>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st); \
-    else launch_energy_grad<T_, float>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st);    \
+    if (grad_dtype == DH_DTYPE_F16) launch_energy_grad<T_, f16>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st, n_bg_orig, n_bg_trans);        \
+    else if (grad_dtype == DH_DTYPE_BF16) launch_energy_grad<T_, bf16>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st, n_bg_orig, n_bg_trans); \
+    else launch_energy_grad<T_, float>(orig, cur, p, w, C, G2, coef_fg, coef_bg, use_bg, grad_scale, grad, nblocks, st, n_bg_orig, n_bg_trans);    \
   } while (0)
   if (dtype == DH_DTYPE_F16) DH_EG(f16);
   else DH_EG(bf16);
 #undef DH_EG
   if (loss_out)
     hipLaunchKernelGGL(k_final_loss, dim3(1), dim3(256), 0, st, w.fg_part, n_pairs > 0 ? nblocks : 0, fg_norm, w.bg_part,
-                       use_bg ? C / 8 : 0, bg_norm, fg_w, bg_w, loss_out);
+                       use_bg ? 1 : 0, bg_norm, fg_w, bg_w, loss_out);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

@@ -8,7 +8,9 @@
 // Parameter names are the diffusers state-dict names.
 //
 // MI355X layout decisions: channels-last 16-bit activations (a pixel row is a GEMM row and
-// a token), every tensor has its own HBM slot (288 GB: nothing is recomputed or reused),
+// a token); a forward that is SAVED for a backward pass gives every tensor its own HBM slot (288 GB: nothing is
+// recomputed, saved-for-backward is "left in place"), a forward nobody differentiates lets its tensors share the arena by
+// liveness (round 5: two layouts of one arena, dh_unet_config.max_diff_batch),
 // the 32 text K/V projections and the 22 time-embedding projections are hoisted into one
 // GEMM each, q/k/v of self-attention is one GEMM, weights are stored twice ([N][K] and the
 // transposed / tap-flipped [K][N]) so forward and input-gradient use the same NT kernel.
@@ -28,8 +30,10 @@ enum ParamKind { PK_F32, PK_MAT };
 
 struct Ten {
   size_t off = 0, goff = 0;   // element offsets into the activation / gradient arenas
+  size_t off_fo = 0;          // ... into the activation arena during a forward nobody differentiates (liveness plan, plan_forward_only)
   int rows = 0, C = 0;        // rows per batch item
   bool req_grad = true;
+  bool persistent = false;    // same slot in both layouts, max_batch items: read across passes (text K|V cache) or by the caller (captured activations)
 };
 
 struct Wt {
@@ -92,6 +96,7 @@ struct dh_unet {
   std::map<std::string, int> pindex;
   // arena sizes (elements)
   size_t w16_elems = 0, pf_elems = 0, act_elems = 0, grad_elems = 0, f32_elems = 0;
+  size_t fo_elems = 0;              // extent of the forward-only layout inside the activation arena
   size_t partial_elems = 0, scratch_elems = 0, small_elems = 0;
   // device arenas
   unsigned short *w16 = nullptr, *act = nullptr, *grad = nullptr, *scratch = nullptr;
@@ -131,7 +136,8 @@ struct dh_unet {
   double flops_fwd = 0, flops_bwd = 0;
   int64_t launches = 0;
 
-  unsigned short* aptr(int t, int B_unused = 0) { return act + tens[t].off; }
+  bool fo_mode = false;             // the pass being enqueued is a forward nobody differentiates: tensors live at off_fo
+  unsigned short* aptr(int t, int B_unused = 0) { return act + (fo_mode && !tens[t].persistent ? tens[t].off_fo : tens[t].off); }
   // gradient buffer of tensor t; a residual input whose gradient is (so far) exactly its consumer's output
   // gradient shares that buffer instead of receiving a copy (galias, reset per backward)
   std::vector<int> galias;
@@ -145,15 +151,13 @@ namespace {
 
 struct Builder {
   dh_unet& u;
-  int maxB;
-  explicit Builder(dh_unet& uu) : u(uu), maxB(uu.cfg.max_batch) {}
+  int maxB, maxBd;       // largest batch of any forward / of a forward saved for a backward pass
+  explicit Builder(dh_unet& uu) : u(uu), maxB(uu.cfg.max_batch), maxBd(uu.cfg.max_diff_batch) {}
 
+  // (offsets are assigned when the tape is complete: layout_tensors)
   int tensor(int rows, int C, bool req_grad = true) {
     Ten t;
     t.rows = rows; t.C = C; t.req_grad = req_grad;
-    t.off = u.act_elems;
-    u.act_elems += align_up((size_t)rows * C * maxB, 128);
-    if (req_grad) { t.goff = u.grad_elems; u.grad_elems += align_up((size_t)rows * C * maxB, 128); }
     u.tens.push_back(t);
     return (int)u.tens.size() - 1;
   }
@@ -363,6 +367,8 @@ void count_fused(const dh_unet_config& c, int& temb_total, int& kv_total) {
   }
 }
 
+static void layout_tensors(dh_unet& u);
+
 int build(dh_unet& u) {
   const dh_unet_config& c = u.cfg;
   Builder b(u);
@@ -471,13 +477,85 @@ int build(dh_unet& u) {
     for (const Op& o : u.ops) if (o.type == OP_LN) cmax = std::max(cmax, u.tens[o.in0].C);
     u.ones_off = (long)u.pf_elems; u.pf_elems += align_up((size_t)cmax, 64);
     u.zeros_off = (long)u.pf_elems; u.pf_elems += align_up((size_t)cmax, 64); }
-  // scratch: split-K partial slabs, upsample-backward temporary, small f32 vectors
+  layout_tensors(u);
+  // scratch: upsample-backward temporary (backward pass only: the saved batch); split-K partial slabs (GEMMs of few output
+  // tiles: never the big batches, and the dispatch clamps the splits to what fits); small f32 vectors
   size_t biggest = 0;
-  for (const Ten& t : u.tens) biggest = std::max(biggest, (size_t)t.rows * t.C * c.max_batch);
+  for (const Ten& t : u.tens) biggest = std::max(biggest, (size_t)t.rows * t.C * c.max_diff_batch);
   u.scratch_elems = biggest * 4 + 1024;
   u.partial_elems = std::max<size_t>((size_t)48 << 20, biggest * 2);
   u.small_elems = (size_t)c.max_batch * 64 * 4096 + (size_t)c.max_batch * c.norm_groups * 4 + 4096;
   return DH_OK;
+}
+
+
+// Two layouts of ONE activation arena.
+//   saved layout (off): a slot per tensor, max_diff_batch items -- a forward that a backward pass follows leaves everything in
+//     place; the gradient arena mirrors it (goff).
+//   forward-only layout (off_fo): max_batch items per tensor, tensors share the arena by LIVENESS over the tape: tensor t is
+//     live from the first op that writes it to the last op that reads it (inputs of an op: in0, in1, res, the input of a
+//     LayerNorm folded into it; outputs: out, and the GEGLU output a fused in-projection writes).  First-fit over the free gaps,
+//     in tape order.  The batched CFG pass (B = 2 K) runs in a few hundred MB this way instead of needing every slot doubled.
+//   persistent tensors (text, text K|V: cached across passes; the three captured activations: read by the caller after the pass)
+//     keep ONE slot of max_batch items in both layouts and are never shared.
+static void layout_tensors(dh_unet& u) {
+  const size_t maxB = (size_t)u.cfg.max_batch, maxBd = (size_t)u.cfg.max_diff_batch;
+  const int nt = (int)u.tens.size(), nops = (int)u.ops.size();
+  u.tens[u.t_text].persistent = true;
+  u.tens[u.t_kv].persistent = true;
+  for (int i = 0; i < 3; ++i)
+    if (u.act_ids[i] >= 0) u.tens[u.act_ids[i]].persistent = true;
+  std::vector<int> first(nt, nops), last(nt, -1);
+  auto rd = [&](int t, int oi) { if (t >= 0) { last[t] = std::max(last[t], oi); first[t] = std::min(first[t], oi); } };
+  auto wr = [&](int t, int oi) { if (t >= 0) { first[t] = std::min(first[t], oi); last[t] = std::max(last[t], oi); } };
+  for (int oi = 0; oi < nops; ++oi) {
+    const Op& o = u.ops[oi];
+    rd(o.in0, oi); rd(o.in1, oi); rd(o.res, oi); wr(o.out, oi);
+    if (o.ln_fold >= 0) rd(u.ops[o.ln_fold].in0, oi);
+    if (o.glu_op >= 0) wr(u.ops[o.glu_op].out, oi);
+  }
+  // a tensor nothing in the tape writes (an input) or that the caller reads afterwards stays for the whole pass
+  std::vector<char> written(nt, 0);
+  for (const Op& o : u.ops) { if (o.out >= 0) written[o.out] = 1; if (o.glu_op >= 0) written[u.ops[o.glu_op].out] = 1; }
+  for (int t = 0; t < nt; ++t)
+    if (!written[t] || t == u.t_final) { first[t] = 0; last[t] = nops; u.tens[t].persistent = u.tens[t].persistent || !written[t]; }
+  // saved layout + persistent slots
+  u.act_elems = 0; u.grad_elems = 0;
+  for (Ten& t : u.tens) {
+    t.off = u.act_elems;
+    u.act_elems += align_up((size_t)t.rows * t.C * (t.persistent ? maxB : maxBd), 128);
+    if (t.req_grad) { t.goff = u.grad_elems; u.grad_elems += align_up((size_t)t.rows * t.C * maxBd, 128); }
+  }
+  // forward-only layout: first fit among the tensors alive at the definition point
+  struct Live { size_t off, end; int last; };
+  std::vector<Live> live;
+  for (const Ten& t : u.tens)
+    if (t.persistent) live.push_back({t.off, t.off + align_up((size_t)t.rows * t.C * maxB, 128), nops + 1});
+  std::vector<int> order(nt);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+  size_t fo_end = 0;
+  for (const Live& l : live) fo_end = std::max(fo_end, l.end);
+  for (int t : order) {
+    Ten& tt = u.tens[t];
+    if (tt.persistent) { tt.off_fo = tt.off; continue; }
+    if (last[t] < 0) { tt.off_fo = 0; continue; }                    // never touched by the tape
+    const size_t size = align_up((size_t)tt.rows * tt.C * maxB, 128);
+    // tensors whose last reader ran BEFORE this one's first writer are dead (an op may read and write in the same launch, so
+    // "before" is strict: the inputs of op `first[t]` are still alive)
+    live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return l.last < first[t]; }), live.end());
+    std::sort(live.begin(), live.end(), [](const Live& a, const Live& b) { return a.off < b.off; });
+    size_t pos = 0;
+    for (const Live& l : live) {
+      if (pos + size <= l.off) break;
+      pos = std::max(pos, l.end);
+    }
+    tt.off_fo = pos;
+    live.push_back({pos, pos + size, last[t]});
+    fo_end = std::max(fo_end, pos + size);
+  }
+  u.fo_elems = fo_end;
+  u.act_elems = std::max(u.act_elems, fo_end);
 }
 
 // torch layout [N][C][taps] f32 -> forward matrix rows [row_off, row_off+N) x K = taps*C (k = tap*C + c; tiled 3x3:
@@ -620,6 +698,7 @@ extern "C" int dh_unet_create(const dh_unet_config* cfg, dh_unet** out) {
 static int create_engine(const dh_unet_config* cfg, dh_unet* parent, dh_unet** out) {
   dh_unet* u = new dh_unet();
   u->cfg = *cfg;
+  if (u->cfg.max_diff_batch <= 0 || u->cfg.max_diff_batch > u->cfg.max_batch) u->cfg.max_diff_batch = u->cfg.max_batch;
   u->dtype = cfg->dtype;
   int rc = build(*u);
   if (rc != DH_OK) { delete u; return rc; }
@@ -676,7 +755,7 @@ extern "C" int dh_unet_create_shared(dh_unet* parent, int max_batch, void* strea
   DH_REQUIRE(parent && out, "null pointer");
   DH_REQUIRE(parent->owns_weights, "share from the engine that owns the weights");
   dh_unet_config cfg = parent->cfg;
-  if (max_batch > 0) cfg.max_batch = max_batch;
+  if (max_batch > 0 && max_batch != cfg.max_batch) { cfg.max_batch = max_batch; cfg.max_diff_batch = 0; }      // (another size: every batch may be saved)
   DH_REQUIRE(cfg.max_batch < 4096 && (long)cfg.max_batch * cfg.sample_size * cfg.sample_size < (1L << 21), "bad max_batch");
   // W * gamma and the s / t vectors of the folded LayerNorms live in the shared arenas: finalise them before anyone reads
   if (parent->fold_dirty) {
@@ -930,6 +1009,7 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
                                int save_for_backward, float* eps_out, void* const* act_out, void* stream) {
   DH_REQUIRE(u && sample && text, "null pointer");
   DH_REQUIRE(batch >= 1 && batch <= u->cfg.max_batch, "batch exceeds max_batch");
+  DH_REQUIRE(!save_for_backward || batch <= u->cfg.max_diff_batch, "a forward saved for a backward pass exceeds max_diff_batch");
   hipStream_t st = (hipStream_t)stream;
   const int B = batch;
   const dh_unet_config& c = u->cfg;
@@ -953,8 +1033,12 @@ extern "C" int dh_unet_forward(dh_unet* u, const float* sample, float timestep, 
     DH_CHECK_HIP(hipMemcpyAsync(u->in_text, text, (size_t)B * c.text_len * c.cross_attention_dim * 4, hipMemcpyDeviceToDevice, st));
   if (!temb_hit) launch_set_scalar(u->t_dev, timestep, st);
   const bool save = save_for_backward != 0;
+  // a forward nobody differentiates runs in the forward-only layout of the arena (layout_tensors); it overwrites what a saved
+  // forward left there, which is why it also clears saved_batch below
+  u->fo_mode = !save;
   int rc = run_graphed(u, graph_key_fwd(B, n_ops, temb_hit, kv_hit, save), st, &u->flops_fwd,
                        [&]() { forward_ops(u, B, n_ops, first_op, kv_hit, save, st); });
+  u->fo_mode = false;
   if (rc != DH_OK) { u->temb_rows = 0; u->kv_key = 0; return rc; }      // nothing cached after a failed capture / launch
   if (!temb_hit) { u->temb_t = timestep; u->temb_rows = B; u->temb_stream = st; }
   if (!kv_hit) { u->kv_key = u->text_key; u->kv_rows = B; u->kv_stream = st; }   // key 0: the buffer now holds an unnamed text
@@ -1253,7 +1337,7 @@ extern "C" int dh_unet_io_ptr(dh_unet* u, int which, int index, void** ptr, size
       DH_REQUIRE(index >= 0 && index < 3 && u->act_ids[index] >= 0, "activation index out of range");
       const Ten& t = u->tens[u->act_ids[index]];
       *ptr = which == DH_IO_ACT ? (void*)(u->act + t.off) : (void*)(u->grad + t.goff);
-      n = (size_t)c.max_batch * t.rows * t.C * 2;
+      n = (size_t)(which == DH_IO_ACT ? c.max_batch : c.max_diff_batch) * t.rows * t.C * 2;
       break;
     }
     default: DH_REQUIRE(false, "unknown buffer");

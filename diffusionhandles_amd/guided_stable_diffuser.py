@@ -119,7 +119,9 @@ class GuidedStableDiffuser(GuidedDiffuser):
         _lib.require_gpu()
         with torch.cuda.device(device):
             if self.unet is None:
-                self.unet = HipUNet(self._unet_config, dtype=self.dtype, max_batch=self._max_batch, device=device)
+                # the optimisation passes (saved for their backward) run half the batch of the CFG pass: only they size the arenas
+                self.unet = HipUNet(self._unet_config, dtype=self.dtype, max_batch=self._max_batch,
+                                    max_diff_batch=max(1, self._max_batch // 2), device=device)
                 wdir = os.environ.get("DIFFHANDLES_UNET_SAFETENSORS")
                 if wdir:
                     from safetensors.torch import load_file
@@ -493,7 +495,7 @@ class GuidedStableDiffuser(GuidedDiffuser):
     def lanes(self, n, max_batch=None):
         """[self, fork, ...]: n lanes on this diffuser's weights.  ONE growing list of forks per max_batch: lanes(2) is a prefix
         of lanes(3), so a process that serves 8, 16 and 24 edits at streams = 3 holds two forks, not three sets (a fork owns a
-        full engine arena: 28.4 GB at max_batch 16).  release_lanes() destroys them."""
+        full engine arena: 28.4 GB at max_batch 16 in round 4, about half of it since the forward-only layout of round 5).  release_lanes() destroys them."""
         n = int(n)
         if n < 1:
             raise ValueError(f"lanes(n): n must be >= 1, got {n}")

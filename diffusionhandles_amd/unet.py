@@ -21,12 +21,17 @@ SD2_DEPTH = dict(in_channels=5, out_channels=4, block_out_channels=(320, 640, 12
 
 
 class HipUNet:
-    def __init__(self, cfg=None, dtype=torch.float16, max_batch=2, device=None):
+    def __init__(self, cfg=None, dtype=torch.float16, max_batch=2, device=None, max_diff_batch=None):
+        """max_batch: largest batch of any forward; max_diff_batch (default: max_batch): largest batch of a forward that is
+        saved for a backward pass.  Only the latter sizes the activation / gradient arenas: a forward nobody differentiates
+        shares the activation arena by liveness (batched edits of K transforms: max_batch = 2 K for the CFG pass,
+        max_diff_batch = K for the optimisation passes)."""
         _lib.require_gpu()
         self.cfg = dict(SD2_DEPTH if cfg is None else cfg)
         self.cfg.setdefault("text_len", 77)
         self.dtype = dtype
         self.max_batch = int(max_batch)
+        self.max_diff_batch = self.max_batch if not max_diff_batch else max(1, min(int(max_diff_batch), self.max_batch))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         c = _lib.UNetConfig()
         c.in_channels, c.out_channels, c.n_levels = self.cfg["in_channels"], self.cfg["out_channels"], 4
@@ -39,6 +44,7 @@ class HipUNet:
         c.sample_size = self.cfg["sample_size"]
         c.text_len = self.cfg["text_len"]
         c.max_batch = self.max_batch
+        c.max_diff_batch = self.max_diff_batch
         c.dtype = _lib.DTYPE_CODE[dtype]
         self._L = _lib.lib()
         h = ctypes.c_void_p()
@@ -74,6 +80,7 @@ class HipUNet:
         child = object.__new__(HipUNet)
         child.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_h", "_views", "_table")})
         child.max_batch = mb
+        child.max_diff_batch = self.max_diff_batch if mb == self.max_batch else mb
         child._table = self._table
         child._saved_batch = 0
         child._text_key = 0
@@ -221,7 +228,7 @@ class HipUNet:
             _lib.check(self._L.dh_unet_io_ptr(self._h, code, index, ctypes.byref(p), ctypes.byref(nb)), "dh_unet_io_ptr")
             s, mb = self.sample_size, self.max_batch
             if which in ("act", "act_grad"):
-                shape = (mb,) + self.act_shapes[index]
+                shape = (mb if which == "act" else self.max_diff_batch,) + self.act_shapes[index]
                 t = torch.as_tensor(HipUNet._Raw(p.value, shape, "<i2"), device=self.device).view(self.dtype)
             else:
                 shape = {"sample": (mb, s, s, self.cfg["in_channels"]), "dsample": (mb, s, s, self.cfg["in_channels"]),

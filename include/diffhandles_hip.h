@@ -184,6 +184,10 @@ typedef struct dh_unet_config {
   int text_len;               /* 77 */
   int max_batch;              /* largest batch a forward will see */
   int dtype;                  /* DH_DTYPE_F16 or DH_DTYPE_BF16 */
+  int max_diff_batch;         /* largest batch of a forward that is SAVED for a backward pass (0 = max_batch).  A forward nobody
+                               * differentiates (the CFG pass at twice the edit batch, initial inference, DDIM inversion) does not keep
+                               * a slot per tensor: its tensors share the activation arena by liveness, so only this batch sizes the
+                               * activation / gradient arenas (batched edits: max_batch = 2 K, max_diff_batch = K) */
 } dh_unet_config;
 
 int dh_unet_create(const dh_unet_config* cfg, dh_unet** out);
@@ -218,7 +222,7 @@ int dh_unet_backward(dh_unet* u, void* const* d_act, const float* d_eps, float* 
  * inputs there (dh_pack_sample) and hands the SAME pointers to dh_unet_forward / dh_unet_backward, or lets the energy kernels
  * read the captured activations and write their cotangents in place, saves the device-to-device copies either side of a pass
  * (guided_stable_diffuser.py:397-434 builds `torch.cat([latents, depth])` and reads `unet_output[4..6]` every iteration).
- * Every buffer holds max_batch items; contents are valid until the next pass that writes them.
+ * Every buffer holds max_batch items (DH_IO_ACT_GRAD: max_diff_batch); contents are valid until the next pass that writes them.
  *   which: DH_IO_SAMPLE [B][H][W][Cin] f32 | DH_IO_TEXT [B][L][D] f32 | DH_IO_EPS [B][H][W][Cout] f32 (eps out / d_eps in) |
  *          DH_IO_ACT index 0..2 [B][h][w][C] engine dtype | DH_IO_ACT_GRAD index 0..2 (cotangent of that activation) |
  *          DH_IO_DSAMPLE [B][H][W][Cin] f32 | DH_IO_DTEXT [B][L][D] f32 */

@@ -205,3 +205,42 @@ def test_engine_text_kv_cache_by_key():
         ds_ref, dt_ref = hip.backward([None, None, d], None, True, True)
         assert torch.equal(ds_hit, ds_ref) and torch.equal(dt_hit, dt_ref)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cfg_name", ["TINY", "SD2_DEPTH"])
+def test_forward_only_layout_is_bit_identical_and_smaller(cfg_name):
+    """Round 5: a forward nobody differentiates shares the activation arena by liveness (dh_unet_config.max_diff_batch,
+    csrc/unet_engine.cpp layout_tensors).  Engine A keeps a slot per tensor for every batch (max_batch = max_diff_batch = 4), engine
+    B is sized for saved forwards of 2 and forward-only passes of 4: B's forward-only pass at batch 4 gives bit for bit what A's
+    saved forward gives (same kernels, other addresses; the captured activations and eps included), with a smaller workspace; a
+    saved forward + backward on B right after a forward-only pass (which overwrote the saved layout) still equals A's; a saved
+    forward above max_diff_batch is refused."""
+    from diffusionhandles_amd.unet import HipUNet
+    from oracle import unet_torch as U
+    cfg = getattr(U, cfg_name)
+    ref, a = build(cfg, torch.float16, 4)
+    b = HipUNet(dict(cfg, text_len=77), dtype=torch.float16, max_batch=4, max_diff_batch=2)
+    b.load_state_dict(ref.state_dict())
+    assert b.workspace_bytes() < 0.72 * a.workspace_bytes(), (b.workspace_bytes(), a.workspace_bytes())
+    g = torch.Generator(device=dev()).manual_seed(17)
+    S, D = cfg["sample_size"], cfg["cross_attention_dim"]
+    x4 = torch.randn(4, S, S, cfg["in_channels"], generator=g, device=dev())
+    txt4 = torch.randn(4, 77, D, generator=g, device=dev())
+    with torch.cuda.stream(torch.cuda.Stream()):
+        ea, aa = a.forward(x4, 300.0, txt4, save_for_backward=True)
+        eb, ab = b.forward(x4, 300.0, txt4, save_for_backward=False)
+        assert torch.equal(ea, eb) and all(torch.equal(p, q) for p, q in zip(aa, ab)), "forward-only layout changed the result"
+        # truncated tape (no eps, one activation) and the in-place views
+        _, ab2 = b.forward(x4, 300.0, txt4, save_for_backward=False, want_acts=[1], want_eps=False, inplace=True)
+        assert torch.equal(ab2[1], aa[1]) and ab2[0] is None
+        # a saved forward + backward at batch 2 on B after the forward-only pass, against A
+        d2 = torch.randn((2,) + a.act_shapes[2], generator=g, device=dev()).half() * 0.05
+        outs = []
+        for eng in (a, b):
+            eng.forward(x4[:2].contiguous(), 300.0, txt4[:2].contiguous(), save_for_backward=True, want_acts=[2], want_eps=False)
+            ds, _ = eng.backward([None, None, d2], None, True, False)
+            outs.append(ds.clone())
+        assert torch.equal(outs[0], outs[1]), "backward after a forward-only pass differs"
+        with pytest.raises(RuntimeError):
+            b.forward(x4, 300.0, txt4, save_for_backward=True)
+    print(cfg_name, "workspace bytes: slot per tensor at batch 4", a.workspace_bytes(), "-> saved 2 / forward-only 4", b.workspace_bytes())

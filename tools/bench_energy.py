@@ -34,7 +34,7 @@ for C in (320, 640):
         LS.energy_and_grad_planned(cur, org, plan, 3.0, 2.0, grad_scale=256.0)
     G2 = grid * grid
     info["layers"].append(dict(C=C, algorithmic_bytes=3 * G2 * C * 2, kernels=dict(
-        k_bg_sign=(n1 + n2) * C * 2 + (n1 + n2) * 4 * (C // 8) + C * 4,
+        k_colsum_q=(n1 + n2) * C * 2 + (n1 + n2) * 4 * (C // 64) + 8 * C * 4,
         k_energy_grad=2 * G2 * C * 2 + uniq * C * 2 + uniq * 8 + G2 * 9)))
 torch.cuda.synchronize()
 print(json.dumps(info))

@@ -36,9 +36,9 @@ def energy(trace, info_path):
         C = layer["C"]
         tot_us = 0.0
         for k, nbytes in layer["kernels"].items():
-            # the launch geometry tells the layers apart: k_bg_sign C / 8 workgroups (rounds 1-4: k_colsum16 (ceil(C/8*128/256), 2) and
+            # the launch geometry tells the layers apart: k_colsum_q (C / 64, 4 quarters, 2 lists) workgroups (rounds 1-4: k_colsum16 (ceil(C/8*128/256), 2) and
             # k_global_diff C / 64), k_energy_grad G2 / (256 / (C/8))
-            want = {"k_colsum16": (-(-(C // 8) * 128 // 256), 2), "k_global_diff": (-(-C // 64), 1), "k_bg_sign": (C // 8, 1),
+            want = {"k_colsum16": (-(-(C // 8) * 128 // 256), 2), "k_global_diff": (-(-C // 64), 1), "k_colsum_q": (-(-C // 64), 4),
                     "k_energy_grad": (-(-G2 // (256 // (C // 8))), 1)}[k]
             us = [d for n, gx, gy, gz, d in rows if short(n) == k and (gx, gy) == want]
             us = us[len(us) // 5:]                 # drop the cold first fifth
