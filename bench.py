@@ -50,9 +50,11 @@ def parse():
     ap.add_argument("--res", type=int, default=512, help="image resolution of the headline (512 = BASELINE config 2)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps run with the HIP-event GEMM bracket")
     ap.add_argument("--batch-edits", type=int, default=8, help="K edits of one image per U-Net batch (config 3 / 4); 0 = skip")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="concurrent edit lanes per GPU for the edits.concurrent record (engine arenas + streams on one copy of "
-                         "the weights; never the single-edit headline); <= 1 = skip")
+                         "the weights; never the single-edit headline); <= 1 = skip.  Two since round 5: a third lane's stream can "
+                         "land on the hardware queue of another lane (profiles/r05_lanes_wide.txt: 3 lanes 2.09, 2 lanes 2.27 edits/s; "
+                         "round 4's GPU_MAX_HW_QUEUES A/B shows the same split), and with the round-5 GEMMs one stream already fills more of the chip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", dest="phases", action="store_false", help="skip inversion / initial inference / whole-edit timing")
     ap.add_argument("--no-res768", dest="res768", action="store_false", help="skip the 768x768 bf16 record (config 5)")
