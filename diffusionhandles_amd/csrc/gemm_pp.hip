@@ -93,8 +93,14 @@ enum { PPV_STAMP = 1,        // s_memtime stamps of waves 0 and 4 of workgroup 0
        PPV_K64 = 4,          // a segment covers a whole 64-deep K tile (two k-steps): half the barriers, twice the fragment registers
        PPV_NDIM_SHIFT = 4 }; // bits 4-6: only the LAST n piece slots of a tile (the W pieces first) go out inside the multiply segment
 
-template <class T, int BM, int BN, int MODE, int NST, int VAR>
+// GLU = 1: the tile is the (paired-layout) pre-activation of a GEGLU -- 16-column block 2q holds the VALUE columns of outputs
+// 16 q' .. 16 q' + 15 and block 2q + 1 their GATE columns (unet_kernels.h glu_col), so a lane owns value and gate of the same four
+// outputs: the epilogue also writes h * gelu(gate) (and the pre-activations only when p.C is set).  GLU = 2: the tile is dy of a
+// GEGLU: the epilogue reads the saved pre-activations of its outputs and writes d_value | d_gate instead of dy.  As in k_gemm_dma
+// (reference model/attention.py:345-400; diffusers GEGLU [ext]).
+template <class T, int BM, int BN, int MODE, int NST, int VAR, int GLU = 0>
 __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
+  static_assert(GLU == 0 || (MODE == 0 && (BN / 2) % 32 == 0), "the GEGLU epilogues: dense, whole (value, gate) block pairs per wave");
   constexpr int RPW = BM / 4, CPW = BN / 2;                 // rows / columns of the output tile per wave
   constexpr int TM = RPW / 16, TN = CPW / 16;
   static_assert(RPW % 16 == 0 && CPW % 16 == 0, "a wave owns whole 16 x 16 blocks");
@@ -411,6 +417,92 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   }
   typedef T T4 __attribute__((ext_vector_type(4)));
   typedef T T8 __attribute__((ext_vector_type(8)));
+  // two packed 4-column groups (8 bytes each) of the lane pair (l, l ^ 16) -> one 16-byte chunk per lane: lanes of an even quad get
+  // {their a, the partner's a}, lanes of an odd quad {the partner's b, their b} (the exchange the plain epilogue does on f32 values)
+  auto pair16 = [&](uint2 a, uint2 b) -> uint4 {
+    const lane_u2p x = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const lane_u2p y = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    return make_uint4(x[0], y[0], x[1], y[1]);
+  };
+  if constexpr (GLU == 1) {
+    // GEGLU forward.  Lane (l15, quad) owns, of block pair q = (2q, 2q + 1), the value and the gate of outputs 4 quad .. + 3 of
+    // the pair's 16 outputs.  y is computed from the ROUNDED pre-activations (what the backward pass reads back).
+    const bool hb1 = p.bias != nullptr;
+    T* Y = reinterpret_cast<T*>(p.glu_y);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * RPW + 16 * i + l15;
+      const bool mok = m < p.M;
+      uint2 yq[TN / 2];
+#pragma unroll
+      for (int q = 0; q < TN / 2; ++q) {
+        const int cv = nb + 32 * q;                       // first value column of the pair (paired layout); gates at + 16
+        float v[4], gt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * q][r]; gt[r] = acc[i][2 * q + 1][r]; }
+        if (hb1) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + cv + 4 * quad), bg = *reinterpret_cast<const float4*>(p.bias + cv + 16 + 4 * quad);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+        }
+        T4 vt, gtt, yt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vt[r] = from_f32<T>(v[r]); gtt[r] = from_f32<T>(gt[r]);
+          yt[r] = from_f32<T>(to_f32<T>(vt[r]) * gelu_f(to_f32<T>(gtt[r])));
+        }
+        yq[q] = __builtin_bit_cast(uint2, yt);
+        const uint4 pre = pair16(__builtin_bit_cast(uint2, vt), __builtin_bit_cast(uint2, gtt));
+        if (p.C && mok)
+          *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + cv + 16 * (quad & 1) + 8 * (quad >> 1)) = pre;
+      }
+      // y [M][F]: the pair's 16 outputs start at column (nb >> 1) + 16 q; two pairs trade like two blocks
+#pragma unroll
+      for (int q = 0; q + 1 < TN / 2; q += 2) {
+        const uint4 yy = pair16(yq[q], yq[q + 1]);
+        if (mok) *reinterpret_cast<uint4*>(Y + (size_t)m * p.glu_ldy + (nb >> 1) + 16 * (q + (quad & 1)) + 8 * (quad >> 1)) = yy;
+      }
+      if constexpr ((TN / 2) & 1) {
+        constexpr int q = TN / 2 - 1;
+        if (mok) *reinterpret_cast<uint2*>(Y + (size_t)m * p.glu_ldy + (nb >> 1) + 16 * q + 4 * quad) = yq[q];
+      }
+    }
+    return;
+  }
+  if constexpr (GLU == 2) {
+    // GEGLU backward.  The tile holds dy (natural output columns o); the saved pre-activations of outputs [ob, ob + 16) are the
+    // paired 32-column group at 2 ob: value columns, then gate columns.  The lane pair loads / stores 16-byte chunks of that
+    // group and trades halves so that each lane works on the value and the gate of ITS four outputs.
+    const T* X = reinterpret_cast<const T*>(p.glub_x);
+    T* DX = reinterpret_cast<T*>(p.glub_dx);
+    const size_t ldx = 2 * (size_t)p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * RPW + 16 * i + l15;
+      const bool mok = m < p.M;
+      const size_t xrow = (size_t)(mok ? m : p.M - 1) * ldx;
+      uint4 raw[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + xrow + 2 * (nb + 16 * j) + 16 * (quad & 1) + 8 * (quad >> 1));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        // chunk of an even quad = value columns 4 quad .. + 7 (its own four and the partner's), of an odd quad = gate columns of
+        // the partner's four and its own: the same exchange gives every lane (value, gate) of its own four outputs
+        const uint4 hx = pair16(make_uint2(raw[j].x, raw[j].y), make_uint2(raw[j].z, raw[j].w));
+        const T4 hh = __builtin_bit_cast(T4, make_uint2(hx.x, hx.y)), gg = __builtin_bit_cast(T4, make_uint2(hx.z, hx.w));
+        T4 oh, og;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dy = acc[i][j][r], gate = to_f32<T>(gg[r]);
+          const GeluParts gp = gelu_parts(gate);
+          oh[r] = from_f32<T>(dy * gate * gp.Phi);
+          og[r] = from_f32<T>(dy * to_f32<T>(hh[r]) * fmaf(gate, gp.pdf, gp.Phi));
+        }
+        const uint4 out = pair16(__builtin_bit_cast(uint2, oh), __builtin_bit_cast(uint2, og));
+        if (mok) *reinterpret_cast<uint4*>(DX + xrow + 2 * (nb + 16 * j) + 16 * (quad & 1) + 8 * (quad >> 1)) = out;
+      }
+    }
+    return;
+  }
   const bool hb = p.bias != nullptr, hv = p.rowvec != nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -496,24 +588,33 @@ static size_t pp_a_bytes(const GemmK& k) {
 bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan) {
   if (force == 1) return false;
   // what the kernel carries: the plain epilogue (bias, per-image vector, residual), 16-byte aligned rows, descriptors below 2 GiB
-  if (k.ln_s || k.glu_y || k.glub_x || k.act_silu) return false;
+  if (k.ln_s || k.act_silu) return false;
+  const int glu = k.glu_y ? 1 : (k.glub_x ? 2 : 0);
+  // The kernel carries the GEGLU epilogues (tests/test_gemm_pp_gpu.py), the policy does not route them here: side by side they
+  // run at k_gemm_dma's time (profiles/r05_ab_glu_pp.txt: M = 32768, F = 1280: 137 vs 139 us forward, 115 vs 114 us backward;
+  // 8192 x 2560: 98 vs 102) -- these launches move 100 - 270 MB behind five to twenty K tiles and a ~600-instruction
+  // activation epilogue per lane, and neither is what the ping-pong loop improves.
+  if (glu && force != 2) return false;
+  if (glu && (k.mode != A_DENSE || k.N % 128 || k.rowvec || k.R || (glu == 1 && (k.glu_ldy % 8 || ((size_t)k.glu_y & 15))) ||
+              (glu == 2 && (((size_t)k.glub_x & 15) || ((size_t)k.glub_dx & 15))))) return false;
   if (k.rowvec && (k.rowvec_ld % 4 || ((size_t)k.rowvec & 15))) return false;
-  if (k.K % 64 || k.M <= 0 || !k.C) return false;
+  if (k.K % 64 || k.M <= 0 || (!k.C && !glu)) return false;
   if (k.N % 160 && k.N % 128) return false;
-  if (k.ldc % 8 || ((size_t)k.C & 15) || k.lda % 8 || ((size_t)k.A & 15) || ((size_t)k.W & 15)) return false;
+  if ((k.C && (k.ldc % 8 || ((size_t)k.C & 15))) || k.lda % 8 || ((size_t)k.A & 15) || ((size_t)k.W & 15)) return false;
   if (k.R && (k.ldr % 8 || ((size_t)k.R & 15))) return false;
   if (k.mode != A_DENSE && (k.Hout <= 0 || k.Wout <= 0 || k.M % (k.Hout * k.Wout) || k.Cin % 64 || k.K != 9 * k.Cin)) return false;
   const size_t ab = pp_a_bytes(k) + (size_t)(k.Win + 1) * k.lda * 2, wb = (size_t)k.N * k.K * 2;
   if (ab >= 0x7ff00000ull || wb >= 0x7ff00000ull) return false;
   const int ktiles = k.K / 64;
-  // tile: the 160-column tile where it divides N (N = 320, 640, 960, 1280 ...), else 128 columns
-  const int bn = k.N % 160 == 0 ? 160 : 128;
+  // tile: the 160-column tile where it divides N (N = 320, 640, 960, 1280 ...), else 128 columns (the GEGLU epilogues: 128, a
+  // wave must own whole (value, gate) block pairs)
+  const int bn = (k.N % 160 == 0 && !glu) ? 160 : 128;
   const int tn = k.N / bn;
   const long t256 = (long)cdiv(k.M, 256) * tn, t128 = (long)cdiv(k.M, 128) * tn;
   int bm = 0, splits = 1;
   if (t256 >= 224) bm = 256;                                 // one round or more of 256-row tiles
   else if (t128 >= 224) bm = 128;                            // (M = 8192, N = 640 at batch 8: 64 x 4)
-  else if (k.partial && ktiles >= 32 && t256 >= 64 && k.M >= 1024 && k.M <= 4096) {
+  else if (!glu && k.partial && ktiles >= 32 && t256 >= 64 && k.M >= 1024 && k.M <= 4096) {
     // long K loops on fewer tiles than CUs: split K over workgroups (f32 slabs + the reduce kernels of gemm.hip).  Measured for
     // the 16x16-latent level at batch 8 (M = 2048, N = 1280, K = 11520: 64 tiles x 4 splits, 74.7 -> 65.0 us); the B = 1 / B = 2
     // shapes of this kind stay on k_gemm_dma's tiles
@@ -546,6 +647,10 @@ static void pp_launch_tile(int mode, dim3 grid, hipStream_t st, const GemmK& k, 
     if (e0) hipExtLaunchKernelGGL(KERNEL, grid, dim3(512), 0, st, e0, e1, 0, k);                  \
     else hipLaunchKernelGGL(KERNEL, grid, dim3(512), 0, st, k);                                   \
   } while (0)
+  if constexpr (BN == 128 && VAR == (BM == 256 ? PP_SHIP_256 : PP_SHIP_128)) {
+    if (k.glu_y) { DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_DENSE, NST, VAR, 1>)); return; }
+    if (k.glub_x) { DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_DENSE, NST, VAR, 2>)); return; }
+  }
   if (mode == PP_DENSE) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_DENSE, NST, VAR>));
   else if (mode == PP_CONV_S1) DH_PP_LAUNCH((k_gemm_pp<T, BM, BN, PP_CONV_S1, NST, VAR>));
   else {

@@ -114,3 +114,28 @@ def test_pp_policy_shapes_agree_with_k_gemm_dma(family, dtype):
         else:
             ref = A.float() @ W.float().t() + bias + R.float()
         close(outs[0], ref, tol, tol, f"policy vs torch {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,Fd,K", [(512, 256, 128), (300, 128, 64), (128, 384, 192), (2048, 1280, 320)])
+def test_pp_geglu_epilogues(family, dtype, M, Fd, K):
+    """The GEGLU epilogues of k_gemm_pp (forward: value * gelu(gate) out of the in-projection GEMM, with and without the saved
+    pre-activations; backward: d_value | d_gate out of the input-gradient GEMM of the out-projection) -- the body of
+    test_unet_kernels_gpu.test_gemm_geglu_epilogues routed to the ping-pong kernel (256x128 and 128x128 tiles, ragged M)."""
+    import test_unet_kernels_gpu as TK
+    family(2)
+    TK.test_gemm_geglu_epilogues(dtype, M, Fd, K)
+    # the policy's own shapes at batch 8 (family 0) agree with k_gemm_dma (family 1) bit-for-bit-close
+    if M == 2048:
+        g = torch.Generator(device=dev()).manual_seed(3)
+        A = torch.randn(M, K, generator=g, device=dev()).to(dtype)
+        W = (torch.randn(2 * Fd, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+        ys = {}
+        for fam in (0, 1):
+            family(fam)
+            y = torch.empty(M, Fd, dtype=dtype, device=dev())
+            L().check(L().lib().dh_dbg_gemm_glu(DT[dtype], 0, P(A), K, P(W), M, 2 * Fd, K, P(None), P(None), P(y), P(None), P(None),
+                                                L().stream_ptr()), "dh_dbg_gemm_glu")
+            ys[fam] = y
+        tol = 8e-3 if dtype == torch.float16 else 5e-2
+        close(ys[0], ys[1].float(), tol, tol, "policy vs k_gemm_dma geglu")
