@@ -440,6 +440,24 @@ def main():
                 batch_info = {"edits_in_batch": K, "ms_per_batched_step": round(tb / nb * 1e3, 2),
                               "edit_steps_per_s": round(K * nb / tb, 2),
                               "frac_of_mfma_peak": round(K * nb / tb * STEP_TFLOP[512] / MFMA_PEAK_TFLOPS, 4) if args.res == 512 else None}
+                # roofline of the GEMM launches of a batched step (k_gemm_pp: the eight-wave ping-pong loop on the grids that fill the
+                # chip; k_gemm_dma on the rest), HIP start / stop events per launch like the headline's record
+                with gd.on_stream():
+                    _lib.check(L.dh_gemm_profile_begin())
+                    for i in range(3):
+                        torch.cuda._sleep(int(0.1 * 2.4e9))
+                        gd.guided_step_batch(sts, xb, i, timesteps[i], uncond[i])
+                    bms, bn_, bfl, balg = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+                    _lib.check(L.dh_gemm_profile_end(ctypes.byref(bms), ctypes.byref(bn_), ctypes.byref(bfl)))
+                    _lib.check(L.dh_gemm_profile_bytes(ctypes.byref(balg)))
+                bach = bfl.value / (bms.value * 1e-3) / 1e12 if bms.value > 0 else 0.0
+                batch_info["roofline"] = {
+                    "bound": "mfma", "kernel": "k_gemm_pp + k_gemm_dma launches of three batched guided steps (t_idx 0, 1, 2)",
+                    "achieved": round(bach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(bach / MFMA_PEAK_TFLOPS, 4),
+                    "launches": int(bn_.value), "avg_launch_us": round(bms.value * 1e3 / max(1, bn_.value), 2),
+                    "flops_per_launch": round(bfl.value / max(1, bn_.value) / 1e9, 3),
+                    "algorithmic_bytes_per_launch": round(balg.value / max(1, bn_.value)),
+                    "algorithmic_TBps": round(balg.value / (bms.value * 1e-3) / 1e12, 3) if bms.value > 0 else None}
             del sts, edits
             # K whole edits per GPU as one batch (re-projection of K transforms, 50 batched steps, K decodes), every rank
             barrier()

@@ -104,9 +104,9 @@ NAME=${DH_NAME:-libdiffhandles_hip_tuning.so}
 OBJ=${TMPDIR:-/tmp}/dh_obj_$NAME
 mkdir -p "$OBJ" "$ROOT/tools/bin"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 ${DH_DEFS--DDH_TUNING} -Wno-unused-function -Wno-unused-result"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 ${DH_DEFS--DDH_TUNING} -Wno-unused-function -Wno-unused-result -Wno-c++20-extensions"
 pids=()
-for f in api.cpp geometry.hip mesh.hip cells.hip energy.hip loop_ops.hip gemm.hip attention.hip unet_kernels.hip unet_engine.cpp vae_engine.cpp text_engine.cpp debug_api.cpp; do
+for f in api.cpp geometry.hip mesh.hip cells.hip energy.hip loop_ops.hip gemm.hip gemm_pp.hip attention.hip unet_kernels.hip unet_engine.cpp vae_engine.cpp text_engine.cpp debug_api.cpp; do
   extra=""; case $f in geometry.hip|mesh.hip) extra="-ffp-contract=off";; esac
   ( cd "$SRC" && $HIPCC $FLAGS $extra -x hip -c $f -o "$OBJ/${f%.*}.o" ) &
   pids+=($!)
