@@ -144,7 +144,7 @@ cat $O/energy_512_kernel_gbps.csv $O/reproject_k8_512_kernel_gbps.csv $O/reproje
 recipe_pmc_traffic() { (
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/tools/time_unet.py 1 > /tmp/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/tools/time_unet.py ${DH_PMC_BATCH:-1} > /tmp/pmc_$c.log 2>&1
   echo "$c rc=$?"; tail -2 /tmp/pmc_$c.log
   ls /tmp/pmc_$c/*/ | head
 done
@@ -170,14 +170,15 @@ recipe_pmc_sq() { (
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/pmc
-timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/sq1 -- python3 $R/tools/time_unet.py 1 > /tmp/sq1.log 2>&1; echo "pass1 rc=$?"
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/sq2 -- python3 $R/tools/time_unet.py 1 > /tmp/sq2.log 2>&1; echo "pass2 rc=$?"
+timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/sq1 -- python3 $R/tools/time_unet.py ${DH_PMC_BATCH:-1} > /tmp/sq1.log 2>&1; echo "pass1 rc=$?"
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/sq2 -- python3 $R/tools/time_unet.py ${DH_PMC_BATCH:-1} > /tmp/sq2.log 2>&1; echo "pass2 rc=$?"
 python3 - <<'PY' > $R/gpurun_out/pmc/sq_summary.txt
 import csv, glob, collections, re
 def fam(n):
-    if "k_gemm_dma" in n:
+    if "k_gemm_dma" in n or "k_gemm_pp" in n:
         m = re.search(r"Li(\d+)ELi(\d+)E", n)
-        return f"k_gemm_dma {m.group(1)}x{m.group(2)}" if m else "k_gemm_dma"
+        nm = "k_gemm_pp" if "k_gemm_pp" in n else "k_gemm_dma"
+        return f"{nm} {m.group(1)}x{m.group(2)}" if m else nm
     m = re.search(r"k_[a-z0-9_]+", n)
     return m.group(0) if m else n[:30]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -194,11 +195,12 @@ for d in ("/tmp/sq1", "/tmp/sq2"):
 for f in glob.glob("/tmp/sq1/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         dur[fam(r["Kernel_Name"])] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-print("# rocprofv3 --pmc (two passes of 8 SQ counters) --kernel-trace -- python3 tools/time_unet.py 1   (B=1 U-Net forward+backward, 13 iterations; sums over all launches)")
+import os
+print("# rocprofv3 --pmc (two passes of 8 SQ counters) --kernel-trace -- python3 tools/time_unet.py " + os.environ.get("DH_PMC_BATCH", "1") + "   (U-Net forward+backward at that batch, 13 iterations; sums over all launches)")
 print("# raw sums per kernel family; lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; insts per MFMA instruction; wait = SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY")
 print("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz): share of the chip's matrix-pipe cycles the family's launches kept busy")
 print("#   (kernel time = sum of the launches' durations in the same pass's kernel trace: counter collection serialises and slows launches, so")
-print("#    this is a LOWER bound of the utilisation in the un-profiled step); mfma_busy/launch in cycles = 32 x MFMA instructions (32x32x16)")
+print("#    this is a LOWER bound of the utilisation in the un-profiled step); mfma_busy/launch in cycles = 32 x MFMA instructions (32x32x16; k_gemm_pp: 16 x its 16x16x32 instructions)")
 rows = sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))
 for k, c in rows[:22]:
     mf = max(1.0, c.get("SQ_INSTS_MFMA", 0))

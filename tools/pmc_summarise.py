@@ -11,7 +11,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for line in open(f"{sys.argv[1]}/{c}.tsv"):
         name, cnt, val = line.rstrip("\n").split("\t")
         by_kernel.setdefault(name.split("(")[0][:60], {})[c] = (int(cnt), float(val))
-        if "k_gemm_dma" in name:
+        if "k_gemm_dma" in name or "k_gemm_pp" in name:
             n += int(cnt)
             v += float(val)
     out[c] = (n, v)
@@ -19,8 +19,8 @@ launches = out["FETCH_SIZE"][0]
 f = out["FETCH_SIZE"][1] / launches
 w = out["WRITE_SIZE"][1] / out["WRITE_SIZE"][0]
 print(json.dumps({
-    "kernel": "dh::k_gemm_dma (all instantiations)",
-    "workload": "SD-2-depth U-Net fwd+bwd, B=1, 64x64 latent, fp16 (tools/time_unet.py 1, 13 iterations)",
+    "kernel": "dh::k_gemm_dma + dh::k_gemm_pp (all instantiations)",
+    "workload": f"SD-2-depth U-Net fwd+bwd, B={__import__('os').environ.get('DH_PMC_BATCH', '1')}, 64x64 latent, fp16 (tools/time_unet.py, 13 iterations)",
     "launches": int(launches), "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w,
     "fetch_correction": "x2 (gfx950 FETCH_SIZE under-count, MI355X_MICROARCH.md HBM section)",
     "traffic_bytes_per_launch": (2 * f + w) * 1024,
