@@ -1051,6 +1051,7 @@ static void attn_dkv_launch(int B, hipStream_t st, const void* q, long ldq, cons
 
 void launch_attention_fwd(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, void* o, long ldo,
                           float* lse, int B, int H, int Nq, int Nk, hipStream_t st, int causal) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return;      // (the tile fetch clamps rows to rows_total - 1: never with zero rows)
   // causal: no key split.  A wave group whose whole key range lies after a query row would carry m = -inf into the merge
   // (exp2(-inf - -inf) = NaN); with one group the first tile always holds key 0, visible to every row
   int ks = attn_key_split((Nk + 63) / 64, causal ? 1 : 4);
@@ -1081,6 +1082,7 @@ void launch_attention_delta(int dtype, const void* o, long ldo, const void* d_o,
 void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* o,
                              long ldo, const void* d_o, long lddo, const float* lse, float* delta, void* dq, long lddq,
                              int B, int H, int Nq, int Nk, hipStream_t st) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return;
   const int qw = attn_row_waves(Nq, H * B, Nk);
   // four key groups like the forward (12 waves per CU instead of 6 at N = 4096: the loop is VALU-bound and one to two waves
   // per SIMD leave the pipe idle across every LDS wait; guided step +0.45 %, profiles/r03_ab_dq_ks4.txt); the 16-wave block
@@ -1101,6 +1103,7 @@ void launch_attention_bwd_dq(int dtype, const void* q, long ldq, const void* k, 
 void launch_attention_bwd_dkv(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* d_o,
                               long lddo, const float* lse, const float* delta, void* dk, void* dv, long lddk, int B,
                               int H, int Nq, int Nk, hipStream_t st, float* scratch, size_t scratch_elems) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return;
   int ks = attn_key_split((Nq + 63) / 64, 2);
   int qw = attn_row_waves(Nk, H * B, Nq);
 #ifdef DH_TUNING
