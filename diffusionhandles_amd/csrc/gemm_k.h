@@ -50,7 +50,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   void* glu_y; long glu_ldy; const void* glub_x; void* glub_dx;                                    // GEGLU epilogues (GLU instantiations)
   // k_gemm_pp only (launch_gemm_pp fills them): row / column tile counts, work-item order (0 = column tile fastest, 1 = row
   // tile fastest), bytes the A / W buffer descriptors cover
-  int pp_tm, pp_tn, pp_order; unsigned pp_a_bytes, pp_w_bytes;
+  int pp_tm, pp_tn, pp_order, pp_nwork; unsigned pp_a_bytes, pp_w_bytes;
   unsigned long long* pp_ts;        // timeline stamps (measurement variants only)
 };
 

@@ -111,6 +111,9 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   constexpr int NPB0 = (WPIECES + 7) / 8, NPB1 = WPIECES / 8;   // W pieces per wave: waves 0-3 / waves 4-7
   constexpr int NP0 = NPA + NPB0;                           // piece slots per wave and tile (the last W slot is empty for waves 4-7 when NPB1 < NPB0)
   static_assert(NPA <= 4 && NPB0 <= 4, "immediate offsets reach 3 KiB");
+  // (a two-stage ring of the 128-row tiles -- 64 / 73 KB, <= 128 registers, two workgroups per CU -- was measured in round 5 and
+  //  dropped: -0..12 % on some short-K shapes, +20 % on others, profiles/r05_ab_pp_two_per_cu.txt; NST >= 3 is also what lets a
+  //  group issue pieces of tile t + NST - 1 AFTER its wait for tile t + 1)
   static_assert(NST >= 3 && NST * STAGE <= 160 * 1024, "ring does not fit the LDS");
   constexpr int KS = (VAR & PPV_K64) ? 2 : 1;               // 32-deep k-steps per segment
   constexpr int SEG = 2 / KS;                               // segments per K tile
@@ -128,20 +131,35 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   const int npw = g == 0 ? NP0 : NPA + NPB1;                // DMA pieces this wave issues per tile
 
   // ---- which output tile: XCD-aware order (block b runs on XCD b % 8; consecutive work items share an operand panel) ----
+  unsigned long long* ts = nullptr;
+  int tsn = 0;
+  if constexpr (STAMP) { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ts = p.pp_ts + (wave >> 2) * 512; }
+  auto stamp = [&]() { if constexpr (STAMP) { if (ts && tsn < 512) ts[tsn++] = __builtin_amdgcn_s_memtime(); } };
+  // PERSISTENT form: the grid is at most one workgroup per slot of the chip (gemm launch code); a workgroup walks the work items
+  // vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 whenever it is smaller than the item count, so an item keeps
+  // the XCD of its first-round position).  The stores of one tile's epilogue are in flight while the next tile's prologue and K loop
+  // run -- with one launch-sized round per tile every CU computed, then every CU stored, and HBM idled in between.
+  for (int vb = blockIdx.x; vb < p.pp_nwork; vb += gridDim.x) {
+  stamp();
   int m0, n0, zsplit;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int nwg = p.pp_nwork, bid = vb;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     int rt, ct;
-    if (p.pp_order == 0) { ct = idx % p.pp_tn; const int rest = idx / p.pp_tn; rt = rest % p.pp_tm; zsplit = rest / p.pp_tm; }
+    if ((p.pp_order & 1) == 0) { ct = idx % p.pp_tn; const int rest = idx / p.pp_tn; rt = rest % p.pp_tm; zsplit = rest / p.pp_tm; }
     else { rt = idx % p.pp_tm; const int rest = idx / p.pp_tm; ct = rest % p.pp_tn; zsplit = rest / p.pp_tn; }
     m0 = rt * BM; n0 = ct * BN;
   }
   int kbeg = zsplit * p.k_per_split;
   int kend = kbeg + p.k_per_split;
   if (kend > p.K) kend = p.K;
+#ifdef DH_PP_VARIANTS
+  // timing ablations (measurement build only): 0x200 = one K tile instead of all (prologue + epilogue + launch), 0x100 = no epilogue
+  const int nt = (p.pp_order & 0x200) ? 1 : (kend - kbeg) >> 6;
+#else
   const int nt = (kend - kbeg) >> 6;
+#endif
 
   // ---- descriptors (scalar) ------------------------------------------------------------------------------------------------
   // The A base is moved back by a_bias bytes and every source offset carries +a_bias: the stride-1 convolution's tap offset
@@ -271,10 +289,6 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
     if (u < NST - 1) n += rpre_n;
     pp_wait_vm_dyn<0, 31>(n);
   };
-  unsigned long long* ts = nullptr;
-  int tsn = 0;
-  if constexpr (STAMP) { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ts = p.pp_ts + (wave >> 2) * 512; }
-  auto stamp = [&]() { if constexpr (STAMP) { if (ts && tsn < 512) ts[tsn++] = __builtin_amdgcn_s_memtime(); } };
 
   v4f acc[TM][TN];
 #pragma unroll
@@ -312,6 +326,20 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
       if constexpr (NR1) rp8[i] = *reinterpret_cast<const uint2*>(rrow + nb + 16 * (TN - 1) + 4 * quad);
     }
     rpre_n = TM * (NRP + NR1);
+  }
+  // GEGLU backward: the saved pre-activations of this lane's outputs (16 bytes per row block) ride under the K loop the same way --
+  // fetched in the epilogue they were four dependent HBM round trips per tile (the tensor is 168 MB: never cached)
+  uint4 gx[GLU == 2 ? TM : 1][GLU == 2 ? TN : 1];
+  if constexpr (GLU == 2) {
+    const T* X = reinterpret_cast<const T*>(p.glub_x);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * RPW + 16 * i + l15;
+      const size_t xrow = (size_t)(m < p.M ? m : p.M - 1) * (2 * (size_t)p.N);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) gx[i][j] = *reinterpret_cast<const uint4*>(X + xrow + 2 * (nb + 16 * j) + 16 * (quad & 1) + 8 * (quad >> 1));
+    }
+    rpre_n = TM * TN;
   }
   // fragment addresses: per lane (row l15 of a 16-row block, chunk 4 s + quad of the 32-deep k-step s, swizzled); the swizzle
   // term ((row >> 1) & 7) only depends on l15 because every block starts on a multiple of 16 rows
@@ -401,6 +429,9 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   stamp();
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------------
+#ifdef DH_PP_VARIANTS
+  if (p.pp_order & 0x100) { if (acc[0][0][0] == 12345.678f) p.partial[0] = 1.f; continue; }
+#endif
   // acc[i][j][r] = D[m = m0 + wm RPW + 16 i + l15][n = n0 + g CPW + 16 j + 4 quad + r]
   if (p.splits > 1) {
     float* part = p.partial + (size_t)zsplit * p.M * p.N;
@@ -413,7 +444,7 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         *reinterpret_cast<float4*>(part + (size_t)m * p.N + nb + 16 * j + 4 * quad) =
             make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
-    return;
+    continue;
   }
   typedef T T4 __attribute__((ext_vector_type(4)));
   typedef T T8 __attribute__((ext_vector_type(8)));
@@ -429,6 +460,13 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
     // the pair's 16 outputs.  y is computed from the ROUNDED pre-activations (what the backward pass reads back).
     const bool hb1 = p.bias != nullptr;
     T* Y = reinterpret_cast<T*>(p.glu_y);
+    // bias of this lane's value / gate columns: loaded once, before the first store (see the plain epilogue)
+    float4 gbv[TN / 2], gbg[TN / 2];
+#pragma unroll
+    for (int q = 0; q < TN / 2; ++q) {
+      gbv[q] = hb1 ? *reinterpret_cast<const float4*>(p.bias + nb + 32 * q + 4 * quad) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gbg[q] = hb1 ? *reinterpret_cast<const float4*>(p.bias + nb + 32 * q + 16 + 4 * quad) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * RPW + 16 * i + l15;
@@ -440,8 +478,8 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         float v[4], gt[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * q][r]; gt[r] = acc[i][2 * q + 1][r]; }
-        if (hb1) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + cv + 4 * quad), bg = *reinterpret_cast<const float4*>(p.bias + cv + 16 + 4 * quad);
+        {
+          const float4 bv = gbv[q], bg = gbg[q];
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
         }
         T4 vt, gtt, yt;
@@ -466,13 +504,12 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         if (mok) *reinterpret_cast<uint2*>(Y + (size_t)m * p.glu_ldy + (nb >> 1) + 16 * q + 4 * quad) = yq[q];
       }
     }
-    return;
+    continue;
   }
   if constexpr (GLU == 2) {
     // GEGLU backward.  The tile holds dy (natural output columns o); the saved pre-activations of outputs [ob, ob + 16) are the
     // paired 32-column group at 2 ob: value columns, then gate columns.  The lane pair loads / stores 16-byte chunks of that
     // group and trades halves so that each lane works on the value and the gate of ITS four outputs.
-    const T* X = reinterpret_cast<const T*>(p.glub_x);
     T* DX = reinterpret_cast<T*>(p.glub_dx);
     const size_t ldx = 2 * (size_t)p.N;
 #pragma unroll
@@ -480,9 +517,7 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
       const int m = m0 + wm * RPW + 16 * i + l15;
       const bool mok = m < p.M;
       const size_t xrow = (size_t)(mok ? m : p.M - 1) * ldx;
-      uint4 raw[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) raw[j] = *reinterpret_cast<const uint4*>(X + xrow + 2 * (nb + 16 * j) + 16 * (quad & 1) + 8 * (quad >> 1));
+      const uint4 (&raw)[TN] = gx[i];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         // chunk of an even quad = value columns 4 quad .. + 7 (its own four and the partner's), of an odd quad = gate columns of
@@ -501,63 +536,90 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         if (mok) *reinterpret_cast<uint4*>(DX + xrow + 2 * (nb + 16 * j) + 16 * (quad & 1) + 8 * (quad >> 1)) = out;
       }
     }
-    return;
+    continue;
   }
   const bool hb = p.bias != nullptr, hv = p.rowvec != nullptr;
+  // The per-column vectors are loaded ONCE, before the first store: a load placed behind a store may alias it as far as the
+  // compiler knows, so a bias read inside the row loop was re-issued after every store -- ten dependent L2 round trips, 9 000
+  // cycles of epilogue on a tile whose K loop (K = 320) takes 13 000 (profiles/r05_pp_tile_timeline.txt).
+  // cbv[j] = bias (+ the per-image vector) of the four columns of block j this lane holds BEFORE the lane-pair exchange.
+  float cbv[TN][4];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * RPW + 16 * i + l15;
-    const bool mok = m < p.M;
-    T* crow = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc;
-    // per-image vector (the time-embedding projection added to a resnet's first convolution): row m belongs to image m / rows_per_batch
-    const float* vrow = hv ? p.rowvec + (size_t)div_small(mok ? m : 0, p.inv_rows_per_batch) * p.rowvec_ld : nullptr;
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int j = 0; j + 1 < TN; j += 2) {
-      // blocks j, j + 1: the lane pairs (l, l ^ 16) trade four columns so that every lane holds EIGHT consecutive columns
-      // (one 16-byte store): lanes of an even quad keep block j, lanes of an odd quad get block j + 1
-      float v[8];
+    for (int c = 0; c < 4; ++c) cbv[j][c] = 0.f;
+  auto add_cols = [&](const float* vec) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // (__builtin_bit_cast applied to the vector-ELEMENT lvalue acc[i][j][r] reads element 0 for every r with hipcc of
-        //  ROCm 7.2 -- seen in the ISA and on the device: copy the element to a float first)
-        const float fa = acc[i][j][r], fb = acc[i][j + 1][r];
-        const lane_u2p x = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, fa), __builtin_bit_cast(unsigned, fb), false, false);
-        const unsigned x0 = x[0], x1 = x[1];
-        v[r] = __builtin_bit_cast(float, x0);
-        v[4 + r] = __builtin_bit_cast(float, x1);
-      }
-      const int n = nb + 16 * (j + (quad & 1)) + 8 * (quad >> 1);
-      if (!mok) continue;
-      if (hb) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (hv) {
-        const float4 b0 = *reinterpret_cast<const float4*>(vrow + n), b1 = *reinterpret_cast<const float4*>(vrow + n + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (has_r) {
-        uint4 raw = rp16[i][j / 2];
-        if (!pre_r) raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n);
-        const T8 rv = __builtin_bit_cast(T8, raw);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] += to_f32<T>(rv[c]);
-      }
-      T8 o;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] = from_f32<T>(v[c]);
-      *reinterpret_cast<uint4*>(crow + n) = __builtin_bit_cast(uint4, o);
+    for (int j = 0; j < TN; ++j) {
+      const float4 b = *reinterpret_cast<const float4*>(vec + nb + 16 * j + 4 * quad);
+      cbv[j][0] += b.x; cbv[j][1] += b.y; cbv[j][2] += b.z; cbv[j][3] += b.w;
     }
-    if constexpr (TN & 1) {
-      constexpr int j = TN - 1;
-      const int n = nb + 16 * j + 4 * quad;
-      if (mok) {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (hb) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        if (hv) { const float4 b = *reinterpret_cast<const float4*>(vrow + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        if (has_r) {
+  };
+  if (hb) add_cols(p.bias);
+  // per-image vector (the time-embedding projection added to a resnet's first convolution): row m belongs to image
+  // m / rows_per_batch; a tile that lies inside one image (every tile when the image's rows are a multiple of BM) adds it here
+  bool hv_rows = hv;
+  if (hv) {
+    const int mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1);
+    const int im0 = div_small(m0, p.inv_rows_per_batch);
+    if (im0 == div_small(mlast, p.inv_rows_per_batch)) { add_cols(p.rowvec + (size_t)im0 * p.rowvec_ld); hv_rows = false; }
+  }
+  // The row loop exists in four straight-line versions (residual or not, per-row vector or not), chosen ONCE: as uniform branches
+  // inside the unrolled loop they were three taken branches per 16-byte store.  Per store now: the bias add lands in fresh
+  // registers (no copies in front of the in-place lane exchange), the address is one row pointer + an immediate.
+  stamp();
+  auto rows = [&](auto HRc, auto HVc) {
+    constexpr bool HR = decltype(HRc)::value, HV = decltype(HVc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * RPW + 16 * i + l15;
+      const bool mok = m < p.M;
+      // this lane's 16-byte chunk of block pair jp starts 32 jp columns further; the odd last block's 8-byte chunk at ctail
+      T* cpair = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 16 * (quad & 1) + 8 * (quad >> 1);
+      T* ctail = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 16 * (TN - 1) + 4 * quad;
+      const float* vrow = HV ? p.rowvec + (size_t)div_small(mok ? m : 0, p.inv_rows_per_batch) * p.rowvec_ld + nb : nullptr;
+      const T* rrow = HR ? reinterpret_cast<const T*>(p.R) + (size_t)(mok ? m : 0) * p.ldr + nb : nullptr;
+#pragma unroll
+      for (int jp = 0; jp < NRP; ++jp) {
+        constexpr int dummy = 0; (void)dummy;
+        const int j = 2 * jp;
+        // blocks j, j + 1: the lane pairs (l, l ^ 16) trade four columns so that every lane holds EIGHT consecutive columns
+        // (one 16-byte store): lanes of an even quad keep block j, lanes of an odd quad get block j + 1
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // (__builtin_bit_cast applied to the vector-ELEMENT lvalue acc[i][j][r] reads element 0 for every r with hipcc of
+          //  ROCm 7.2 -- seen in the ISA and on the device: the sums below are plain floats)
+          float fa = acc[i][j][r] + cbv[j][r], fb = acc[i][j + 1][r] + cbv[j + 1][r];
+          if constexpr (HV) { fa += vrow[16 * j + 4 * quad + r]; fb += vrow[16 * (j + 1) + 4 * quad + r]; }
+          const lane_u2p x = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, fa), __builtin_bit_cast(unsigned, fb), false, false);
+          const unsigned x0 = x[0], x1 = x[1];
+          v[r] = __builtin_bit_cast(float, x0);
+          v[4 + r] = __builtin_bit_cast(float, x1);
+        }
+        if constexpr (HR) {
+          uint4 raw = rp16[i][jp];
+          if (!pre_r) raw = *reinterpret_cast<const uint4*>(rrow + 16 * (j + (quad & 1)) + 8 * (quad >> 1));
+          const T8 rv = __builtin_bit_cast(T8, raw);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] += to_f32<T>(rv[c]);
+        }
+        T8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = from_f32<T>(v[c]);
+        if (mok) *reinterpret_cast<uint4*>(cpair + 32 * jp) = __builtin_bit_cast(uint4, o);
+      }
+      if constexpr (TN & 1) {
+        constexpr int j = TN - 1;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] + cbv[j][r];
+          if constexpr (HV) v[r] += vrow[16 * j + 4 * quad + r];
+        }
+        if constexpr (HR) {
           uint2 raw = rp8[i];
-          if (!pre_r) raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n);
+          if (!pre_r) raw = *reinterpret_cast<const uint2*>(rrow + 16 * j + 4 * quad);
           const T4 rv = __builtin_bit_cast(T4, raw);
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += to_f32<T>(rv[c]);
@@ -565,10 +627,15 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         T4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = from_f32<T>(v[c]);
-        *reinterpret_cast<uint2*>(crow + n) = __builtin_bit_cast(uint2, o);
+        if (mok) *reinterpret_cast<uint2*>(ctail) = __builtin_bit_cast(uint2, o);
       }
+      stamp();
     }
-  }
+  };
+  if (has_r) { if (hv_rows) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+  else       { if (hv_rows) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+  stamp();
+  }      // work items of this workgroup
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -585,16 +652,20 @@ static size_t pp_a_bytes(const GemmK& k) {
   return B * k.Hin * k.Win * (size_t)k.lda * 2;
 }
 
+static int g_pp_glu = -1;                           // dh_dbg_gemm_pp_glu: the GEGLU-epilogue launches (-1 policy, 0 never, 1 always)
 bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan) {
   if (force == 1) return false;
   // what the kernel carries: the plain epilogue (bias, per-image vector, residual), 16-byte aligned rows, descriptors below 2 GiB
   if (k.ln_s || k.act_silu) return false;
   const int glu = k.glu_y ? 1 : (k.glub_x ? 2 : 0);
-  // The kernel carries the GEGLU epilogues (tests/test_gemm_pp_gpu.py), the policy does not route them here: side by side they
-  // run at k_gemm_dma's time (profiles/r05_ab_glu_pp.txt: M = 32768, F = 1280: 137 vs 139 us forward, 115 vs 114 us backward;
-  // 8192 x 2560: 98 vs 102) -- these launches move 100 - 270 MB behind five to twenty K tiles and a ~600-instruction
-  // activation epilogue per lane, and neither is what the ping-pong loop improves.
-  if (glu && force != 2) return false;
+  // The GEGLU epilogues (tests/test_gemm_pp_gpu.py).  With the ping-pong loop alone they ran at k_gemm_dma's time
+  // (profiles/r05_ab_glu_pp.txt); persistent workgroups, the bias read once and the saved pre-activations prefetched under the K loop
+  // changed that (profiles/r05_ab_pp_shortk.txt, M = 32768, F = 1280: forward 133 -> 124 us saving / 110 -> 97 not saving, backward
+  // 121 -> 113; M = 8192, F = 2560: forward 93.5 -> 90.9 / 86.6 -> 82.3 but backward 68 -> 73; the other batch sizes in
+  // profiles/r05_ab_pp_glu_by_batch.txt): forward from M = 2048 on, backward from M = 32768 on.
+  // g_pp_glu: -1 = this policy, 0 = never, 1 = always.
+  const bool glu_here = force == 2 || g_pp_glu > 0 || (g_pp_glu < 0 && ((glu == 1 && k.M >= 2048) || k.M >= 32768));
+  if (glu && !glu_here) return false;
   if (glu && (k.mode != A_DENSE || k.N % 128 || k.rowvec || k.R || (glu == 1 && (k.glu_ldy % 8 || ((size_t)k.glu_y & 15))) ||
               (glu == 2 && (((size_t)k.glub_x & 15) || ((size_t)k.glub_dx & 15))))) return false;
   if (k.rowvec && (k.rowvec_ld % 4 || ((size_t)k.rowvec & 15))) return false;
@@ -637,6 +708,8 @@ bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan)
 // wave and tile the last 1 / 3 go out between the MFMAs of the multiply segment, which balances the two segments of an interval
 // (-> 59.7 us; 128x160 conv K = 5760 76.2 -> 65.9 us)
 constexpr int PP_SHIP_256 = PPV_K64 | (1 << PPV_NDIM_SHIFT), PP_SHIP_128 = PPV_K64 | (3 << PPV_NDIM_SHIFT);
+static int g_pp_persist = 1;                        // dh_dbg_gemm_pp_persist: 0 = one workgroup per work item (the round-by-round form)
+static int g_pp_ablate = 0;                         // dh_dbg_gemm_pp_ablate (measurement build)
 static int g_pp_variant = -1;                       // measurement builds (-DDH_PP_VARIANTS): dh_dbg_gemm_pp_variant; -1 = shipped
 static unsigned long long* g_pp_ts = nullptr;
 
@@ -707,8 +780,12 @@ void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t
   const double a_tot = (double)k.pp_a_bytes, w_tot = (double)k.pp_w_bytes;
   const double col_fastest = a_tot + 8.0 * w_tot;
   const double row_fastest = w_tot + (double)(k.pp_tn * k.splits < 8 ? k.pp_tn * k.splits : 8) * a_tot;
-  k.pp_order = row_fastest < col_fastest ? 1 : 0;
-  dim3 grid((unsigned)(k.pp_tm * k.pp_tn * k.splits));
+  k.pp_order = (row_fastest < col_fastest ? 1 : 0) | g_pp_ablate;
+  k.pp_nwork = k.pp_tm * k.pp_tn * k.splits;
+  // persistent grid: one workgroup per CU (256: a multiple of 8, the XCD order of the work items holds in every round)
+  int slots = 256;
+  if (g_pp_persist == 0 || k.pp_nwork <= slots) slots = k.pp_nwork;
+  dim3 grid((unsigned)slots);
   const int mode = pp_mode(k);
   if (dtype == DH_DTYPE_F16) pp_launch<f16>(k, plan, mode, grid, st, e0, e1);
   else pp_launch<bf16>(k, plan, mode, grid, st, e0, e1);
@@ -718,6 +795,21 @@ void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t
 
 // measurement hook: main-loop variant of the next k_gemm_pp launches (builds with -DDH_PP_VARIANTS carry them; the product
 // library accepts only the shipped one) and the device buffer (2 x 512 u64) the stamping variants write their timeline to
+extern "C" int dh_dbg_gemm_pp_glu(int on) {
+  dh::g_pp_glu = on;
+  return DH_OK;
+}
+extern "C" int dh_dbg_gemm_pp_persist(int on) {
+  dh::g_pp_persist = on;
+  return DH_OK;
+}
+extern "C" int dh_dbg_gemm_pp_ablate(int bits) {
+#ifndef DH_PP_VARIANTS
+  DH_REQUIRE(bits == 0, "timing ablations exist in the measurement build only (tools/lab.sh build-pp-variants)");
+#endif
+  dh::g_pp_ablate = bits & 0x300;
+  return DH_OK;
+}
 extern "C" int dh_dbg_gemm_pp_variant(int variant, unsigned long long* ts) {
 #ifndef DH_PP_VARIANTS
   DH_REQUIRE(variant < 0, "this build carries the shipped k_gemm_pp variants only (tools/lab.sh build-pp-variants)");

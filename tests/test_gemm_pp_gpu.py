@@ -139,3 +139,54 @@ def test_pp_geglu_epilogues(family, dtype, M, Fd, K):
             ys[fam] = y
         tol = 8e-3 if dtype == torch.float16 else 5e-2
         close(ys[0], ys[1].float(), tol, tol, "policy vs k_gemm_dma geglu")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_pp_persistent_workgroups_walk_several_tiles(family, dtype):
+    """More work items than workgroup slots (256): a workgroup then walks several tiles, the stores of one tile in flight under
+    the next tile's K loop.  Bit-identical to the one-workgroup-per-item launch; against torch; dense
+    (ragged M, residual), a stride-1 convolution, and the GEGLU forward with saved pre-activations."""
+    lib = L().lib()
+    g = torch.Generator(device=dev()).manual_seed(11)
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    try:
+        family(2)
+        for (M, N, K) in [(40000, 640, 128), (33000, 384, 192)]:        # 157 x 4 = 628 tiles of 256 x 160; 129 x 3 = 387 of 256 x 128
+            A = torch.randn(M, K, generator=g, device=dev()).to(dtype)
+            W = (torch.randn(N, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+            bias = torch.randn(N, generator=g, device=dev())
+            R = torch.randn(M, N, generator=g, device=dev()).to(dtype)
+            outs = []
+            for persist in (0, 1):
+                lib.dh_dbg_gemm_pp_persist(persist)
+                outs.append(run_gemm(dtype, A, K, W, M, N, K, bias=bias, R=R, split=False))
+            close(outs[1], A.float() @ W.float().t() + bias + R.float(), tol, tol, f"persistent dense {M}x{N}x{K}")
+            assert torch.equal(outs[0], outs[1])
+        # convolution: 9 images of 64 x 64, 64 -> 320 channels: 144 x 2 = 288 tiles
+        B, Cin, Cout, H = 9, 64, 320, 64
+        x = torch.randn(B, Cin, H, H, generator=g, device=dev()).to(dtype)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g, device=dev()) / (9 * Cin) ** 0.5).to(dtype)
+        xa = nhwc(x).reshape(B * H * H, Cin)
+        wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+        outs = []
+        for persist in (0, 1):
+            lib.dh_dbg_gemm_pp_persist(persist)
+            outs.append(run_gemm(dtype, xa, Cin, wk, B * H * H, Cout, 9 * Cin, mode=1, geo=(H, H, Cin, H, H, 1, 0), split=False))
+        ref = nhwc(F.conv2d(x.float(), w.float(), padding=1)).reshape(B * H * H, Cout)
+        close(outs[1], ref, tol, tol, "persistent conv")
+        assert torch.equal(outs[0], outs[1])
+        # GEGLU forward: 16384 x (2 x 640): 64 x 10 = 640 tiles of 256 x 128
+        M, Fd, K = 16384, 640, 64
+        A = torch.randn(M, K, generator=g, device=dev()).to(dtype)
+        W = (torch.randn(2 * Fd, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+        res = []
+        for persist in (0, 1):
+            lib.dh_dbg_gemm_pp_persist(persist)
+            pre = torch.empty(M, 2 * Fd, dtype=dtype, device=dev())
+            y = torch.empty(M, Fd, dtype=dtype, device=dev())
+            L().check(lib.dh_dbg_gemm_glu(DT[dtype], 0, P(A), K, P(W), M, 2 * Fd, K, P(None), P(pre), P(y), P(None), P(None), L().stream_ptr()),
+                      "dh_dbg_gemm_glu")
+            res.append((pre, y))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    finally:
+        lib.dh_dbg_gemm_pp_persist(1)
