@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   // the XCD of its first-round position).  The stores of one tile's epilogue are in flight while the next tile's prologue and K loop
   // run -- with one launch-sized round per tile every CU computed, then every CU stored, and HBM idled in between.
   for (int vb = blockIdx.x; vb < p.pp_nwork; vb += gridDim.x) {
+  if (vb != (int)blockIdx.x) __builtin_amdgcn_s_barrier();               // every wave has read its staged outputs back (epilogue)
   stamp();
   int m0, n0, zsplit;
   {
@@ -567,6 +568,21 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
   // The row loop exists in four straight-line versions (residual or not, per-row vector or not), chosen ONCE: as uniform branches
   // inside the unrolled loop they were three taken branches per 16-byte store.  Per store now: the bias add lands in fresh
   // registers (no copies in front of the in-place lane exchange), the address is one row pointer + an immediate.
+  // THE STORES GO THROUGH LDS.  In the MFMA layout a lane owns a ROW: the 64 lanes of a store instruction write 16 bytes each to
+  // 16 rows x 4 chunks with neighbouring lanes in different rows, and the memory pipeline takes such an instruction as 64 separate
+  // 16-byte requests -- the tile's 82 KB needed 7 500 cycles per CU, four times what the same bytes need as whole row segments
+  // (tools/ubench_store.hip, profiles/r05_ubench_store.txt; profiles/r05_pp_tile_timeline.txt).  Each wave stages its RPW x CPW
+  // outputs in its own rows of the (idle) ring, reads them back with lanes running ALONG the rows and stores 16-byte chunks of
+  // consecutive addresses: same values, same rounding, a quarter of the requests.  Wave-private rows: no barrier here (one at the
+  // top of the next tile, before its prologue overwrites the ring).
+  constexpr int SPITCH = CPW * 2 + 16;                                    // staged row: the wave's CPW outputs + 16 bytes (bank spread)
+  static_assert(8 * RPW * SPITCH <= NST * STAGE, "staging rows fit the ring");
+  unsigned char* stg = smem + wave * (RPW * SPITCH);
+  // (lane-constant address terms of the epilogue would be hoisted out of the persistent tile loop and held in registers through
+  //  every K loop -- 30 registers, spills on the 256 x 160 tile: an opaque copy of the lane id keeps them here)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int l15e = lane_e & 15, quade = lane_e >> 4;
   stamp();
   auto rows = [&](auto HRc, auto HVc) {
     constexpr bool HR = decltype(HRc)::value, HV = decltype(HVc)::value;
@@ -575,8 +591,9 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
       const int m = m0 + wm * RPW + 16 * i + l15;
       const bool mok = m < p.M;
       // this lane's 16-byte chunk of block pair jp starts 32 jp columns further; the odd last block's 8-byte chunk at ctail
-      T* cpair = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 16 * (quad & 1) + 8 * (quad >> 1);
-      T* ctail = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 16 * (TN - 1) + 4 * quad;
+      // (addresses in the wave's staging rows, see below)
+      unsigned char* cpair = stg + (16 * i + l15e) * SPITCH + (16 * (quade & 1) + 8 * (quade >> 1)) * 2;
+      unsigned char* ctail = stg + (16 * i + l15e) * SPITCH + (16 * (TN - 1) + 4 * quade) * 2;
       const float* vrow = HV ? p.rowvec + (size_t)div_small(mok ? m : 0, p.inv_rows_per_batch) * p.rowvec_ld + nb : nullptr;
       const T* rrow = HR ? reinterpret_cast<const T*>(p.R) + (size_t)(mok ? m : 0) * p.ldr + nb : nullptr;
 #pragma unroll
@@ -607,7 +624,7 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         T8 o;
 #pragma unroll
         for (int c = 0; c < 8; ++c) o[c] = from_f32<T>(v[c]);
-        if (mok) *reinterpret_cast<uint4*>(cpair + 32 * jp) = __builtin_bit_cast(uint4, o);
+        *reinterpret_cast<uint4*>(cpair + 64 * jp) = __builtin_bit_cast(uint4, o);
       }
       if constexpr (TN & 1) {
         constexpr int j = TN - 1;
@@ -627,13 +644,28 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
         T4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = from_f32<T>(v[c]);
-        if (mok) *reinterpret_cast<uint2*>(ctail) = __builtin_bit_cast(uint2, o);
+        *reinterpret_cast<uint2*>(ctail) = __builtin_bit_cast(uint2, o);
       }
+      // (LDS stores alias nothing the compiler knows of: without this fence it schedules all row blocks side by side and the
+      //  256 x 160 tile spills)
+      __builtin_amdgcn_sched_barrier(0);
       stamp();
     }
   };
   if (has_r) { if (hv_rows) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
   else       { if (hv_rows) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+  {
+    constexpr int CPR = CPW / 8, NCH = RPW * CPR;                         // 16-byte chunks per staged row / per wave
+    static_assert(NCH % 64 == 0, "whole store instructions");
+    T* cw = reinterpret_cast<T*>(p.C) + (size_t)(m0 + wm * RPW) * p.ldc + nb;
+    const int mleft = p.M - (m0 + wm * RPW);                              // rows of this wave inside the matrix
+#pragma unroll
+    for (int k = 0; k < NCH / 64; ++k) {
+      const int c = 64 * k + lane_e, row = c / CPR, cc = c - row * CPR;
+      const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + cc * 16);
+      if (row < mleft) *reinterpret_cast<uint4*>(cw + (size_t)row * p.ldc + cc * 8) = v;
+    }
+  }
   stamp();
   }      // work items of this workgroup
 }
