@@ -395,14 +395,14 @@ def main():
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, gfx950 x2 fetch
         # correction) of the same U-Net fwd+bwd launch mix; null when the workload differs from the measured one.
         traffic = None
-        for name in ("r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+        for name in ("r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.res == 512 and args.dtype == "fp16":
                 with open(pmc) as fh:
                     traffic = round(json.load(fh)["traffic_bytes_per_launch"])
                 break
         step_tf = STEP_TFLOP.get(args.res)
-        roof = {"bound": "mfma", "kernel": "k_gemm_dma (MFMA implicit GEMM: conv3x3 + linear, fwd + input-gradient)",
+        roof = {"bound": "mfma", "kernel": "k_gemm_dma (+ k_gemm_pp for the GEGLU forward launches): MFMA implicit GEMM, conv3x3 + linear, fwd + input-gradient",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "bytes/launch (offline PMC)", "launches_per_step": int(n.value // max(1, args.profile_steps)),
                 "algorithmic_bytes_per_launch": round(alg.value / max(1, n.value)),

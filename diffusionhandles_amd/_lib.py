@@ -150,6 +150,12 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         handle.dh_missing_symbols = missing
+        # measurement switches of the GEMM dispatch, for same-box A/Bs of whole programs (bench.py, the harnesses): set before any
+        # hipGraph is captured, i.e. here.  Never set in production; unknown to libraries that predate a switch.
+        for env, fn in (("DH_GEMM_FAMILY", "dh_dbg_gemm_family"), ("DH_PP_GLU", "dh_dbg_gemm_pp_glu"),
+                        ("DH_PP_PERSIST", "dh_dbg_gemm_pp_persist")):
+            if os.environ.get(env) and fn not in missing:
+                getattr(handle, fn)(int(os.environ[env]))
         _LIB = handle
     return _LIB
 

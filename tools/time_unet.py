@@ -9,13 +9,7 @@ from diffusionhandles_amd.unet import SD2_DEPTH
 dt = torch.bfloat16 if os.environ.get("DH_DTYPE") == "bf16" else torch.float16
 LAT = int(os.environ.get("DH_LATENT", "64"))           # 96 = the 768x768 configuration
 BATCHES = tuple(int(b) for b in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 2)
-if os.environ.get("DH_GEMM_FAMILY"):       # A/B of the GEMM main loops: 1 = k_gemm_dma only, 0 = the policy (set before any graph is captured)
-    from diffusionhandles_amd import _lib as _l
-    _l.check(_l.lib().dh_dbg_gemm_family(int(os.environ["DH_GEMM_FAMILY"])))
-for _env, _fn in (("DH_PP_GLU", "dh_dbg_gemm_pp_glu"), ("DH_PP_PERSIST", "dh_dbg_gemm_pp_persist")):     # k_gemm_pp switches (same rule)
-    if os.environ.get(_env):
-        from diffusionhandles_amd import _lib as _l
-        _l.check(getattr(_l.lib(), _fn)(int(os.environ[_env])))
+# (DH_GEMM_FAMILY / DH_PP_GLU / DH_PP_PERSIST: the GEMM dispatch switches are read by diffusionhandles_amd/_lib.py at load time)
 u = HipUNet(dict(SD2_DEPTH, sample_size=LAT), dtype=dt, max_batch=max(BATCHES))
 u.init_synthetic(0)
 print("weights GB", u.weight_bytes() / 1e9, "workspace GB", u.workspace_bytes() / 1e9)
