@@ -17,7 +17,8 @@ from diffusionhandles_amd.unet import SD2_DEPTH
 
 dev = torch.device("cuda:0")
 conf = C.load_default()
-dh = DiffusionHandles(conf, dtype=torch.float16, unet_config=dict(SD2_DEPTH), max_batch=16, vae="sd-native",
+MAXB = 32 if os.environ.get("DH_LANES_CASES") == "batch16" else 16
+dh = DiffusionHandles(conf, dtype=torch.float16, unet_config=dict(SD2_DEPTH), max_batch=MAXB, vae="sd-native",
                       text_encoder="sd2-native").to(dev)
 gd = dh.diffuser
 depth, bg_depth, mask = (t.to(dev) for t in make_scene(512))
@@ -35,7 +36,7 @@ def tfs(n):
     return [(TRANSFORMS[i % 8][0], Y, torch.tensor(TRANSFORMS[i % 8][1])) for i in range(n)]
 
 
-print("weights GB", gd.unet.weight_bytes() / 1e9, "workspace GB (max_batch 16)", gd.unet.workspace_bytes() / 1e9, flush=True)
+print("weights GB", gd.unet.weight_bytes() / 1e9, f"workspace GB (max_batch {MAXB})", gd.unet.workspace_bytes() / 1e9, flush=True)
 # whole edits: (edits, batch, streams)
 ref = {}
 CASES = ((8, 8, 1), (8, 4, 1), (8, 4, 2), (16, 8, 1), (16, 8, 2), (8, 2, 2), (8, 1, 2), (8, 1, 1), (12, 4, 3))
@@ -43,6 +44,8 @@ if os.environ.get("DH_LANES_CASES") == "queues":    # short list for A/Bs of run
     CASES = ((16, 8, 1), (16, 8, 2), (24, 8, 3))
 elif os.environ.get("DH_LANES_CASES") == "wide":      # more lanes of full batches
     CASES = ((24, 8, 1), (24, 8, 3), (32, 8, 1), (32, 8, 4), (16, 8, 2))
+if os.environ.get("DH_LANES_CASES") == "batch16":   # sixteen edits as ONE batch of 16 (CFG pass at 32) against 2 x 8 on one stream / two lanes
+    CASES = ((16, 8, 1), (16, 16, 1), (16, 8, 2), (32, 16, 1), (32, 16, 2))
 for n, batch, streams in CASES:
     with torch.no_grad():
         dh.transform_foreground_batch(depth, prompt, mask, bg_depth, uncond, init_noise, acts, tfs(min(n, 2 * batch)), streams=streams, batch=batch)
