@@ -91,7 +91,9 @@ enum { PPV_STAMP = 1,        // s_memtime stamps of waves 0 and 4 of workgroup 0
        PPV_DMA_IN_MFMA = 2,  // the LDS-DMA pieces are issued between the MFMAs of the multiply segment instead of in the load segment
        PPV_NO_RPRE = 8,      // the residual tile is loaded in the epilogue, chunk by chunk, instead of being prefetched behind the prologue
        PPV_K64 = 4,          // a segment covers a whole 64-deep K tile (two k-steps): half the barriers, twice the fragment registers
-       PPV_NDIM_SHIFT = 4 }; // bits 4-6: only the LAST n piece slots of a tile (the W pieces first) go out inside the multiply segment
+       PPV_NDIM_SHIFT = 4,   // bits 4-6: only the LAST n piece slots of a tile (the W pieces first) go out inside the multiply segment
+       PPV_SPLIT_ORDER = 128 }; // the odd waves of a group issue their DMA pieces BEFORE they read their fragments (the even ones after):
+                             // the LDS and the texture path are busy side by side through the load segment instead of one after the other
 
 // GLU = 1: the tile is the (paired-layout) pre-activation of a GEGLU -- 16-column block 2q holds the VALUE columns of outputs
 // 16 q' .. 16 q' + 15 and block 2q + 1 their GATE columns (unet_kernels.h glu_col), so a lane owns value and gate of the same four
@@ -385,7 +387,10 @@ __global__ void __launch_bounds__(512) k_gemm_pp(const GemmK p) {
           if (more) issue_range(nstage, std::integral_constant<int, LLO>{}, std::integral_constant<int, LHI>{});
           if constexpr (s == SEG - 1 && XL == NP0) { if (more) next_tile(); }
         };
-        { read_frags(); stamp(); issue_load_part(); }
+        if constexpr ((VAR & PPV_SPLIT_ORDER) != 0) {
+          if (wm & 1) { issue_load_part(); stamp(); read_frags(); }
+          else { read_frags(); stamp(); issue_load_part(); }
+        } else { read_frags(); stamp(); issue_load_part(); }
         stamp();
         // group 1 is in this segment when group 0 finishes MFMA(t, last) and moves on to read tile t + 1
         if constexpr (s == SEG - 1) { if (g == 1) wait_tile(t + 1); }
@@ -786,6 +791,7 @@ static void pp_launch(const GemmK& k, const PpPlan& plan, int mode, dim3 grid, h
         DH_PP_CASE(4 + 16) DH_PP_CASE(4 + 32) DH_PP_CASE(4 + 48) DH_PP_CASE(4 + 64) DH_PP_CASE(4 + 80)
         DH_PP_CASE(5 + 16) DH_PP_CASE(5 + 32) DH_PP_CASE(5 + 48) DH_PP_CASE(5 + 64)
         DH_PP_CASE(32) DH_PP_CASE(48) DH_PP_CASE(20 + 8) DH_PP_CASE(52 + 8)
+        DH_PP_CASE(20 + 128) DH_PP_CASE(52 + 128) DH_PP_CASE(21 + 128) DH_PP_CASE(53 + 128) DH_PP_CASE(4 + 128) DH_PP_CASE(36 + 128)
 #undef DH_PP_CASE
         default: break;
       }
@@ -846,7 +852,7 @@ extern "C" int dh_dbg_gemm_pp_variant(int variant, unsigned long long* ts) {
 #ifndef DH_PP_VARIANTS
   DH_REQUIRE(variant < 0, "this build carries the shipped k_gemm_pp variants only (tools/lab.sh build-pp-variants)");
 #endif
-  DH_REQUIRE(variant >= -1 && variant < 128, "variant: bit 0 stamps, bit 1 all DMA inside the MFMA segment, bit 2 64-deep segments, bits 4-6 pieces inside the MFMA segment");
+  DH_REQUIRE(variant >= -1 && variant < 256, "variant: bit 0 stamps, bit 1 all DMA inside the MFMA segment, bit 2 64-deep segments, bits 4-6 pieces inside the MFMA segment");
   dh::g_pp_variant = variant;
   dh::g_pp_ts = ts;
   return DH_OK;

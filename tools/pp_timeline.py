@@ -38,9 +38,11 @@ def run(M, N, K, conv, var):
         s = t[grp * 512:(grp + 1) * 512]
         n = int((s != 0).sum())
         s = s[:n]
-        # layout: [0] start, [1] after prologue; then 7 stamps per segment (the 7th = next segment's first); last: end
+        # layout: [0] tile start (persistent loop), [1] in front of the prologue, [2] after the first wait; then 6 stamps per segment;
+        # then the loop end and the epilogue's stamps (ignored here: tools/pp_tile_timeline.py)
+        s = s[1:]
         body = s[2:]
-        nseg = (len(body) - 1) // 6
+        nseg = min((K // 64) * (1 if var & 4 else 2), (len(body) - 1) // 6)      # (512 stamps per group: the first ~84 segments)
         import numpy as np
         d = np.diff(body[:nseg * 6 + 1].astype(np.int64)).reshape(nseg, 6)
         mid = d[nseg // 4: max(nseg // 4 + 1, nseg - 2)]
