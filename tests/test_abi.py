@@ -119,3 +119,31 @@ def test_kernel_registers_and_scratch_audit():
         assert sel, frag
         for k in sel:
             assert k["vgpr"] <= 128, k
+
+
+def test_hand_placed_vmcnt_waits_cover_their_loads():
+    """tools/check_vmcnt.py (no GPU): the attention kernels issue their tile prefetch from inline asm and wait for it by hand, which
+    the compiler's wait insertion does not see -- no instruction of any kernel may touch the destination register of a load that
+    the in-order vmcnt scoreboard still has in flight.  First the checker itself on two hand-made instruction streams."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    import check_vmcnt
+    ok = ["global_load_dwordx4 v[10:13], v[2:3], off", "global_store_dwordx4 v[4:5], v[20:23], off", "v_add_f32_e32 v1, v2, v3",
+          "s_waitcnt vmcnt(1)", "v_add_f32_e32 v1, v10, v3", "s_endpgm"]
+    assert check_vmcnt.check("ok", ok) == []
+    early = ["global_load_dwordx4 v[10:13], v[2:3], off", "global_store_dwordx4 v[4:5], v[20:23], off", "s_waitcnt vmcnt(2)",
+             "v_mov_b32_e32 v40, v12", "s_waitcnt vmcnt(0)", "s_endpgm"]
+    bad = check_vmcnt.check("early", early)
+    assert len(bad) == 1 and bad[0][1].startswith("v_mov_b32")
+    dma = ["global_load_lds_dwordx4 v[20:21], off", "v_mov_b32_e32 v20, v3", "buffer_load_dwordx4 v7, s[4:7], s9 offen lds", "v_mov_b32_e32 v7, v3"]
+    assert check_vmcnt.check("dma", dma) == []                 # LDS-DMA: the first operand is an address, nothing lands in registers
+    lib = os.path.join(ROOT, "diffusionhandles_amd", "libdiffhandles_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(check_isa.LLVM, "llvm-objdump")):
+        pytest.skip("library or llvm-objdump not present")
+    n = 0
+    for name, body in check_vmcnt.kernels_disassembly(lib):
+        if "k_attn_" in name or "k_gemm_pp" in name:
+            n += 1
+            assert check_vmcnt.check(name, body) == [], name
+    assert n >= 40
