@@ -125,6 +125,7 @@ DEBUG_SIGNATURES = {
     "dh_dbg_layernorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
     "dh_dbg_geglu": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "dh_dbg_attention": (c_i, [c_i, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dh_dbg_attention_bwd_pair": (c_i, [c_i, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "dh_dbg_pool2x2": (c_i, [c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dh_dbg_ellipse_offsets": (c_i, [c_i, ctypes.POINTER(ctypes.c_int32), c_i, ctypes.POINTER(c_i)]),
     "dh_dbg_lane_ops": (c_i, [c_p, c_p, c_p, c_p]),

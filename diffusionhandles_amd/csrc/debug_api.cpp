@@ -137,6 +137,30 @@ extern "C" int dh_dbg_attention(int dtype, const void* q, long ldq, const void* 
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+// attention backward of one layer, dQ and dK/dV either one after the other on `stream` (stream2 == NULL: dQ writes delta, dK/dV
+// reads it) or SIDE BY SIDE: delta by its own kernel, then dQ on `stream` and dK/dV on `stream2` between a fork and a join event
+// (measurement hook: what the two kernels gain from each other's idle CUs at B = 1)
+extern "C" int dh_dbg_attention_bwd_pair(int dtype, const void* q, long ldq, const void* k, const void* v, long ldk, const void* o,
+                                         long ldo, const float* lse, const void* d_o, float* delta, void* dq, void* dk, void* dv,
+                                         int B, int H, int Nq, int Nk, void* stream, void* stream2) {
+  hipStream_t st = (hipStream_t)stream, s2 = (hipStream_t)stream2;
+  if (!s2) {
+    launch_attention_bwd_dq(dtype, q, ldq, k, v, ldk, o, ldo, d_o, ldo, lse, delta, dq, ldq, B, H, Nq, Nk, st);
+    launch_attention_bwd_dkv(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dk, dv, ldk, B, H, Nq, Nk, st, nullptr, 0);
+  } else {
+    static hipEvent_t fork = nullptr, join = nullptr;
+    if (!fork) { DH_CHECK_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); DH_CHECK_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming)); }
+    launch_attention_delta(dtype, o, ldo, d_o, ldo, delta, B, H, Nq, st);
+    DH_CHECK_HIP(hipEventRecord(fork, st));
+    DH_CHECK_HIP(hipStreamWaitEvent(s2, fork, 0));
+    launch_attention_bwd_dkv(dtype, q, ldq, k, v, ldk, d_o, ldo, lse, delta, dk, dv, ldk, B, H, Nq, Nk, s2, nullptr, 0);
+    launch_attention_bwd_dq(dtype, q, ldq, k, v, ldk, o, ldo, d_o, ldo, lse, nullptr, dq, ldq, B, H, Nq, Nk, st);
+    DH_CHECK_HIP(hipEventRecord(join, s2));
+    DH_CHECK_HIP(hipStreamWaitEvent(st, join, 0));
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
 extern "C" int dh_dbg_pool2x2(int dtype, const void* src, void* dst, int B, int h, int w, int C, int accumulate, void* stream) {
   launch_pool2x2_sum(dtype, src, dst, B, h, w, C, accumulate, (hipStream_t)stream);
   DH_LAUNCH_CHECK();
