@@ -722,10 +722,11 @@ bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan)
   int bm = 0, splits = 1;
   if (t256 >= 224) bm = 256;                                 // one round or more of 256-row tiles
   else if (t128 >= 224) bm = 128;                            // (M = 8192, N = 640 at batch 8: 64 x 4)
-  else if (!glu && k.partial && ktiles >= 32 && t256 >= 64 && k.M >= 1024 && k.M <= 4096) {
+  else if (!glu && k.partial && ktiles >= 64 && t256 >= 64 && k.M >= 1024 && k.M <= 4096) {
     // long K loops on fewer tiles than CUs: split K over workgroups (f32 slabs + the reduce kernels of gemm.hip).  Measured for
     // the 16x16-latent level at batch 8 (M = 2048, N = 1280, K = 11520: 64 tiles x 4 splits, 74.7 -> 65.0 us); the B = 1 / B = 2
-    // shapes of this kind stay on k_gemm_dma's tiles
+    // shapes of this kind stay on k_gemm_dma's tiles.  From 64 K tiles on: the B = 1 input gradients with K = 2880 (45 tiles, M = 4096,
+    // N = 640 / 960) lose 7 - 18 % here, K = 5760 wins 3 - 4 % (profiles/r05_ab_pp_splitk_branch.txt)
     bm = 256;
     splits = (int)(256 / t256);
     if (splits > ktiles / 8) splits = ktiles / 8;

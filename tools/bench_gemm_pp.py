@@ -41,7 +41,7 @@ def run(M, N, K, conv, iters=20, rounds=3):
         L.dh_dbg_gemm(0, P(A), lda, P(W), M, N, K, mode, *geo, P(bias), P(None), 0, 1, P(R), N, P(C), N, 0, P(part), part.numel(), _lib.stream_ptr())
     res = {}
     # arms: k_gemm_dma (family 1), then k_gemm_pp main-loop variants (family 2; DH_PP_VARS=0,2,4,6 needs tools/bin/libdh_pp_variants.so)
-    arms = [(1, 0)] + [(2, v) for v in VARS]
+    arms = [(1, 0)] + [(0 if os.environ.get("DH_PP_FAMILY0") else 2, v) for v in VARS]
     for fam, var in arms:
         L.dh_dbg_gemm_family(fam); L.dh_dbg_gemm_pp_variant(var, None)
         for _ in range(3): call()
@@ -74,9 +74,13 @@ def run(M, N, K, conv, iters=20, rounds=3):
     print(out, flush=True)
 
 
+# the B = 1 / B = 2 launches the split-K branch of gemm_pp_plan takes (input gradients of the 64 x 64-level convolutions whose inputs
+# have 640 / 960 channels, the 32 x 32 level at B = 2 ...): policy (DH_PP_FAMILY0=1: family 0 instead of "k_gemm_pp wherever it can run")
+B1 = [(4096, 640, 2880, (1, 64, 320)), (4096, 960, 2880, (1, 64, 320)), (4096, 640, 5760, (1, 64, 640)), (2048, 1280, 5760, (2, 32, 640)),
+      (2048, 640, 5760, (2, 32, 640)), (2048, 1280, 11520, (2, 32, 1280)), (1024, 1280, 11520, (4, 16, 1280)), (4096, 1280, 5760, (4, 32, 640))]
 VARS = [int(v) for v in os.environ.get("DH_PP_VARS", "-1").split(",")]
 which = sys.argv[1] if len(sys.argv) > 1 else "b8"
 KEY = [B8[0], B8[3], B8[6], B8[7], B8[9], B8[11]]       # one per class: the shapes the review names
-shapes = {"b8": B8, "l96": L96, "b16": B16, "all": B8 + B16 + L96, "key": KEY}[which]
+shapes = {"b8": B8, "l96": L96, "b16": B16, "all": B8 + B16 + L96, "key": KEY, "b1": B1}[which]
 for s in shapes:
     run(*s)
