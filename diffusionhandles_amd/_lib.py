@@ -120,6 +120,7 @@ DEBUG_SIGNATURES = {
     "dh_dbg_gemm_pp_ablate": (c_i, [c_i]),
     "dh_dbg_gemm_pp_persist": (c_i, [c_i]),
     "dh_dbg_gemm_pp_glu": (c_i, [c_i]),
+    "dh_dbg_gemm_pp_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_sz, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
     "dh_dbg_touch_tiled": (c_i, [c_sz, c_p]),
     "dh_dbg_groupnorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "dh_dbg_layernorm": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),

@@ -834,6 +834,24 @@ void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t
 
 // measurement hook: main-loop variant of the next k_gemm_pp launches (builds with -DDH_PP_VARIANTS carry them; the product
 // library accepts only the shipped one) and the device buffer (2 x 512 u64) the stamping variants write their timeline to
+// host-only query of the policy (no launch, no device): which tile / K split gemm_pp_plan gives a launch of this shape, or 0 in *bm when
+// it stays on k_gemm_dma.  conv: 0 dense, 1 = 3x3 stride-1 convolution of hw x hw images (K = 9 Cin); glu: 0 plain, 1 GEGLU forward,
+// 2 GEGLU backward; partial_elems: f32 elements of split-K workspace.  tests/test_layout_models.py pins the table on CPU.
+extern "C" int dh_dbg_gemm_pp_plan(int M, int N, int K, int conv, int hw, int glu, size_t partial_elems, int* bm, int* bn, int* splits) {
+  DH_REQUIRE(bm && bn && splits, "null pointer");
+  static __attribute__((aligned(16))) unsigned char dummy[16];
+  dh::GemmK k{};
+  k.A = dummy; k.W = dummy; k.C = dummy; k.M = M; k.N = N; k.K = K; k.lda = conv ? K / 9 : K; k.ldc = N;
+  k.mode = conv ? dh::A_CONV3 : dh::A_DENSE;
+  if (conv) { k.Hin = k.Win = k.Hout = k.Wout = hw; k.Cin = K / 9; k.stride = 1; k.up = 0; k.pad = 1; }
+  k.partial = partial_elems ? reinterpret_cast<float*>(dummy) : nullptr;
+  if (glu == 1) { k.glu_y = dummy; k.glu_ldy = N / 2; }
+  if (glu == 2) { k.glub_x = dummy; k.glub_dx = dummy; k.C = nullptr; }
+  dh::PpPlan plan;
+  const bool use = dh::gemm_pp_plan(k, partial_elems, 0, &plan);
+  *bm = use ? plan.bm : 0; *bn = use ? plan.bn : 0; *splits = use ? plan.splits : 0;
+  return DH_OK;
+}
 extern "C" int dh_dbg_gemm_pp_glu(int on) {
   dh::g_pp_glu = on;
   return DH_OK;

@@ -140,3 +140,41 @@ def test_gemm_128x160_tile_pieces_and_wave_blocks():
                     assert key not in owned
                     owned.add(key)
     assert len(owned) == 128 * 160
+
+
+def test_gemm_pp_policy_table():
+    """gemm_pp_plan (csrc/gemm_pp.hip), queried on the host (dh_dbg_gemm_pp_plan: no device): which launches of the SD-2-depth passes
+    run on the eight-wave ping-pong loop and with which tile -- pinned so that a threshold edit shows up as a diff of THIS table.
+    (bm, bn, K splits); (0, 0, 0) = stays on k_gemm_dma."""
+    import ctypes
+    from diffusionhandles_amd import _lib
+    L = _lib.lib()
+    if "dh_dbg_gemm_pp_plan" in L.dh_missing_symbols:
+        pytest.skip("library predates dh_dbg_gemm_pp_plan")
+
+    def plan(M, N, K, conv=0, hw=0, glu=0, part=64 << 20):
+        bm, bn, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(L.dh_dbg_gemm_pp_plan(M, N, K, conv, hw, glu, part, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp)))
+        return bm.value, bn.value, sp.value
+
+    # batch 8, 64 x 64 latents: convolutions of the three upper levels, dense projections
+    assert plan(32768, 320, 2880, 1, 64) == (256, 160, 1)
+    assert plan(8192, 640, 5760, 1, 32) == (128, 160, 1)          # 32 x 4 tiles of 256 rows would leave half the chip idle
+    assert plan(2048, 1280, 11520, 1, 16) == (256, 160, 4)        # 64 tiles x 4 K splits
+    assert plan(2048, 1280, 11520, 1, 16, part=0) == (0, 0, 0)    # ... only with a split-K workspace
+    assert plan(32768, 320, 320) == (256, 160, 1) and plan(32768, 960, 320) == (256, 160, 1)
+    assert plan(8192, 640, 640) == (128, 160, 1)
+    assert plan(512, 1280, 11520, 1, 8) == (0, 0, 0)
+    # the B = 16 CFG pass of batched edits, the 96 x 96 level at B = 2
+    assert plan(65536, 320, 2880, 1, 64) == (256, 160, 1)
+    assert plan(18432, 320, 2880, 1, 96) == (128, 160, 1)
+    # a single edit stays on k_gemm_dma's tiles (40 - 160 workgroups) ...
+    assert plan(4096, 320, 2880, 1, 64) == (0, 0, 0) and plan(4096, 320, 320) == (0, 0, 0) and plan(9216, 320, 2880, 1, 96) == (0, 0, 0)
+    assert plan(4096, 640, 2880, 1, 64) == (0, 0, 0)              # (45 K tiles: the split-K branch starts at 64)
+    assert plan(4096, 640, 5760, 1, 64) == (256, 160, 4)
+    # ... except the GEGLU forward from M = 2048 on; the GEGLU backward from M = 32768 on
+    assert plan(32768, 2560, 320, glu=1) == (256, 128, 1) and plan(4096, 2560, 320, glu=1) == (256, 128, 1)
+    assert plan(1024, 5120, 640, glu=1) == (0, 0, 0)
+    assert plan(32768, 1280, 320, glu=2) == (256, 128, 1) and plan(8192, 2560, 640, glu=2) == (0, 0, 0)
+    # what the kernel cannot carry: K not a multiple of 64, N neither a multiple of 160 nor of 128
+    assert plan(32768, 320, 352) == (0, 0, 0) and plan(32768, 192, 320) == (0, 0, 0)
