@@ -147,6 +147,7 @@ def test_gemm_pp_policy_table():
     run on the eight-wave ping-pong loop and with which tile -- pinned so that a threshold edit shows up as a diff of THIS table.
     (bm, bn, K splits); (0, 0, 0) = stays on k_gemm_dma."""
     import ctypes
+    import pytest
     from diffusionhandles_amd import _lib
     L = _lib.lib()
     if "dh_dbg_gemm_pp_plan" in L.dh_missing_symbols:
