@@ -80,6 +80,14 @@ def masked_centroid_f32(points_hw3, mask_hw):
     return np.mean(sel, axis=0)
 
 
+# `q . axis` of the Rodrigues formula: the reference calls np.dot (BLAS sgemv), whose summation order -- and use of fused
+# multiply-adds -- belongs to the BLAS build and the host CPU, so for a general axis the reference's own result is machine-dependent
+# in the last bit.  DOT_ORDER = "blas" follows the reference literally; "explicit" is one admissible order written out,
+# (q0 a0 + q1 a1) + q2 a2 with every product and sum rounded to f32 -- the order the HIP kernel uses (csrc/geometry.hip k_points).
+# tests/test_geometry_gpu.py holds the product to the explicit order bit for bit and to the BLAS order within a handful of pairs.
+DOT_ORDER = "blas"
+
+
 def rigid_transform(points_hw3, axis, angle_deg, translation, mask_hw):
     """Rodrigues rotation about the masked centroid + translation -> float64 [H,W,3].
 
@@ -101,7 +109,10 @@ def rigid_transform(points_hw3, axis, angle_deg, translation, mask_hw):
     cr[:, 1] = ax[2] * q[:, 0] - ax[0] * q[:, 2]
     cr[:, 2] = ax[0] * q[:, 1] - ax[1] * q[:, 0]
     t2 = cr * s                                       # f64
-    d = np.dot(q, ax)                                 # f32 (BLAS order for general axes)
+    if DOT_ORDER == "explicit":
+        d = (q[:, 0] * ax[0] + q[:, 1] * ax[1]) + q[:, 2] * ax[2]        # f32 elementwise: one rounding per operation
+    else:
+        d = np.dot(q, ax)                             # f32 (BLAS order for general axes)
     t3 = ax * d[:, None] * (1 - c)                    # f32*f32 -> f32, then f64
     out = (t1 + t2 + t3).reshape(h, w, 3) + cen + np.array([translation[0], translation[1], translation[2]], dtype=np.float64)
     return out

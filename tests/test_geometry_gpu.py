@@ -74,6 +74,14 @@ def test_general_axis_and_small_res_vs_oracle():
     disp_o, corr_o = D.transform_depth_pc(depth, bg, mask, K, rot_angle=25.0, rot_axis=axis.numpy(), translation=[0.1, -0.05, 0.2])
     a = set(map(tuple, corr.numpy().tolist())); b = set(map(tuple, corr_o.numpy().tolist()))
     assert len(a ^ b) <= 4
+    # ... and EXACT against the oracle with the dot product's order written out (the only machine-dependent operation of the path)
+    D.DOT_ORDER = "explicit"
+    try:
+        disp_x, corr_x = D.transform_depth_pc(depth, bg, mask, K, rot_angle=25.0, rot_axis=axis.numpy(), translation=[0.1, -0.05, 0.2])
+    finally:
+        D.DOT_ORDER = "blas"
+    assert np.array_equal(corr.numpy(), corr_x.numpy()), len(a ^ set(map(tuple, corr_x.numpy().tolist())))
+    assert np.abs(disp.cpu().numpy() - disp_x.numpy()).max() < 2e-3
     # axis-aligned at the same size must be exact
     (disp, corr), = DT.reproject_edits(depth.to(dev), bg.to(dev), mask.to(dev), K, [(40.0, torch.tensor([0.0, 1.0, 0.0]), torch.tensor([0.2, 0.0, 0.1]))])
     disp_o, corr_o = D.transform_depth_pc(depth, bg, mask, K, rot_angle=40.0, rot_axis=[0, 1, 0], translation=[0.2, 0.0, 0.1])
