@@ -5,7 +5,6 @@ convolution, every combination of bias / residual / per-image vector, fp16 and b
     python3 tools/fuzz_gemm_pp.py [cases] [seed]       exit code 1 on the first mismatch (the case is printed)"""
 import ctypes, os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("DH_DBG_PRETILED", "1")
 import torch
 import torch.nn.functional as F
 from diffusionhandles_amd import _lib
