@@ -22,6 +22,14 @@
 //   s_barrier of all eight waves.  While one wave of a SIMD multiplies, its partner loads: the matrix pipe never waits for a
 //   fragment, fragments are single-buffered (the wave that loads does not multiply), and the DMA queue is never drained:
 //   each wave waits with a COUNTED vmcnt for its own pieces of tile t + 1 once per tile, NST - 2 tiles stay in flight.
+//   (The table shows the 32-deep form, VAR without PPV_K64; the SHIPPED variants run a whole 64-deep K tile per segment --
+//   LOAD(t) then MFMA(t), two intervals per K tile -- and issue the last one / three pieces of a tile between the MFMAs.)
+//
+// Around the loop (all measured in DESIGN.md section 4, "What a short-K launch waits for"): the workgroups are PERSISTENT (at most
+// 256, each walks the work items blockIdx.x, + gridDim.x, ... in XCD order) so that a tile's stores drain under the next tile's
+// prologue and loop; the residual tile and the GEGLU backward's saved pre-activations are fetched behind the prologue's DMA; the
+// per-column vectors are read once in front of the first store; the plain epilogue stages a wave's outputs in its own rows of
+// the idle ring and stores whole row segments (in the MFMA layout a store instruction is 64 scattered 16-byte requests).
 //
 // Tiles: 256 x 160 (N = 320, 640, 960: two / four / six column tiles), 256 x 128, 128 x 160, 128 x 128; wave layout 4 (M) x 2 (N),
 // the column half = the group; a wave owns (BM / 4) x (BN / 2) outputs = TM x TN blocks of 16 x 16 (operands swapped as in
