@@ -116,6 +116,7 @@ DEBUG_SIGNATURES = {
     "dh_dbg_gemm_lnfold": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
     "dh_dbg_gemm_glu": (c_i, [c_i, c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dh_dbg_gemm_family": (c_i, [c_i]),
+    "dh_dbg_gemm_stage": (c_i, [c_i]),
     "dh_dbg_gemm_pp_variant": (c_i, [c_i, c_p]),
     "dh_dbg_gemm_pp_ablate": (c_i, [c_i]),
     "dh_dbg_gemm_pp_persist": (c_i, [c_i]),
@@ -155,7 +156,7 @@ def lib():
         # measurement switches of the GEMM dispatch, for same-box A/Bs of whole programs (bench.py, the harnesses): set before any
         # hipGraph is captured, i.e. here.  Never set in production; unknown to libraries that predate a switch.
         for env, fn in (("DH_GEMM_FAMILY", "dh_dbg_gemm_family"), ("DH_PP_GLU", "dh_dbg_gemm_pp_glu"),
-                        ("DH_PP_PERSIST", "dh_dbg_gemm_pp_persist")):
+                        ("DH_PP_PERSIST", "dh_dbg_gemm_pp_persist"), ("DH_GEMM_STAGE", "dh_dbg_gemm_stage")):
             if os.environ.get(env) and fn not in missing:
                 getattr(handle, fn)(int(os.environ[env]))
         _LIB = handle

@@ -35,6 +35,7 @@ struct GemmProf {
   hipEvent_t e0 = nullptr, e1 = nullptr;      // start / stop events of the launch being issued (hipExtLaunchKernelGGL)
 };
 static GemmProf g_prof;
+static int g_buf_stage = 1;     // test hook (dh_dbg_gemm_stage): 0 = the address form of rounds 1-5 everywhere
 static int g_pp_force = 0;      // test hook (dh_dbg_gemm_family): 0 = policy, 1 = never k_gemm_pp, 2 = k_gemm_pp whenever it can carry the launch
 #ifdef DH_TUNING
 static unsigned long long* g_gemm_ts = nullptr;      // device buffer of 8 stamps (dh_dbg_gemm_timeline)
@@ -129,6 +130,24 @@ __device__ __forceinline__ void dma16_nt(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// LDS-DMA through a buffer descriptor (BUF instantiations; the form of gemm_pp.hip pp_dma): M0 = LDS destination of the piece (not
+// saved: nothing else in these kernels reads M0 -- LDS instructions need none on gfx9+, tests/test_abi.py audits the ISA), the
+// scalar offset copied by an s_mov inside the statement (MUBUF's soffset must be an SGPR; a VALU-written SGPR -- v_readfirstlane --
+// must not be read by a VMEM instruction for five wait states and hipcc pads nothing for asm operands; the copy also is the wait
+// state M0 needs in front of the DMA).
+typedef int buf_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_dma16(unsigned voff, buf_v4i rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned tmp;
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 m0, %4\n\ts_mov_b32 %0, %3\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds"
+               : "=&s"(tmp) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+// voff with bit 31 set (out of range for every descriptor below 2 GiB: the DMA writes zeros) when bit (31 - sh) of nt is set
+__device__ __forceinline__ unsigned buf_mask_oob(unsigned nt, unsigned sh, unsigned voff) {
+  return ((nt << sh) & 0x80000000u) | voff;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
@@ -189,8 +208,14 @@ template <> __device__ __forceinline__ void frag_sums<bf16>(const uint4& f_in, f
 // pre-activations only when p.C is set); GLU = 2: the tile is dy of a GEGLU: the epilogue reads the saved pre-activations of its
 // rows and writes d_value / d_gate instead of dy.  Both keep the activation where the data already sits in registers
 // (reference model/attention.py:345-400; diffusers GEGLU [ext]).
-template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1, bool LNF = false, int GLU = 0>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
+// BUF (round 6): the staging of k_gemm_pp under this kernel's loop -- the LDS-DMA goes through a buffer descriptor
+// (`buffer_load_dwordx4 ... lds`): one 32-bit lane offset per piece computed once, the K cursor / the 3x3 tap in the scalar
+// offset, rows past M and taps outside the image = an out-of-range offset that the hardware turns into zeros (no zero page, no
+// 64-bit address arithmetic, no select pair, no M0 save / restore per piece).  Dense and stride-1 3x3 operands; the generic
+// gather (stride 2, up-sampled source, transposed stride 2) keeps the address form.
+template <class T, int BM, int BN, int ST, int MODE, int ABL = 0, int WG = 1, int KG = 1, int MW = 1, bool LNF = false, int GLU = 0, bool BUF = false>   // ABL: diagnostics (1 = no LDS reads/MFMA, 2 = no DMA in the loop)
 __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) {
+  static_assert(!BUF || MODE != GM_GENERIC, "the generic gather stages through addresses");
   static_assert((WG == 1) + (KG == 1) + (MW == 1) >= 2, "one kind of wave grouping per instantiation");
   static_assert(!LNF || (WG == 1 && MODE == GM_DENSE), "the folded LayerNorm needs every k-step of a row in one wave group");
   DH_STAMP(0);
@@ -277,12 +302,65 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   }
   int tap = 0, c0 = 0;
   if (MODE != GM_DENSE) { const int kt0 = kbeg >> 6, ch = kt0 / 9; tap = kt0 - ch * 9; c0 = ch * BK; }    // conv_k_index order
+  // BUF: descriptors (scalar), one 32-bit source offset per A piece, one scalar offset per W piece.  The A base is moved back by
+  // one image row + one pixel (a_bias) so that the tap offset (ky Win + kx) lda in the scalar offset is never negative.
+  typedef int bv4i __attribute__((ext_vector_type(4)));
+  bv4i ra = {0, 0, 0, 0}, rw = {0, 0, 0, 0};
+  unsigned bv_a[NPA], bv_nt[NPA], bs_w[NPB];
+  unsigned bs_tap = 0, bs_sh = 0;                     // conv: scalar offset and validity shift of the tile at the issue cursor
+  unsigned bs_step_px = 0, bs_step_row = 0; int bs_kx = 0;
+  const unsigned bv_w = lane * 16;
+  if constexpr (BUF) {
+    const unsigned a_bias = MODE == GM_CONV_S1 ? (unsigned)((p.Win + 1) * (int)p.lda * 2) : 0u;
+    const size_t a_base = (size_t)p.A - a_bias;
+    ra[0] = (int)(unsigned)a_base; ra[1] = (int)((a_base >> 32) & 0xffff); ra[2] = (int)(p.pp_a_bytes + a_bias); ra[3] = 0x00020000;
+    rw[0] = (int)(unsigned)(size_t)p.W; rw[1] = (int)(((size_t)p.W >> 32) & 0xffff); rw[2] = (int)p.pp_w_bytes; rw[3] = 0x00020000;
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const int m = m0 + 8 * (wave + NWV * (j * WG + grp)) + prow;
+      if (MODE == GM_DENSE) {
+        bv_a[j] = a_ok[j] ? (unsigned)m * (unsigned)((int)p.lda * 2) + (unsigned)lchunk * 16u : 0x80000000u;
+        bv_nt[j] = 0;
+      } else {
+        const int hw = p.Hout * p.Wout;
+        const int b = div_small(m, inv_hw);
+        (void)hw;
+        bv_a[j] = (unsigned)((b * p.Hin + a_oy[j]) * p.Win + a_ox[j]) * (unsigned)((int)p.lda * 2) + (unsigned)lchunk * 16u;
+        bv_nt[j] = ~a_taps[j];                        // bit t set: tap t of this lane's pixel lies outside the image (or the row is past M)
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const int n = n0 + 8 * (wave_s + NWV * (j * WG + grp));
+      bs_w[j] = (unsigned)(((n >> 6) * KT) * 8192 + (n & 63) * 128);
+    }
+    if (MODE == GM_CONV_S1) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      bs_tap = (unsigned)((ky * p.Win + kx) * (int)p.lda + c0) * 2u;
+      bs_sh = 31u - (unsigned)tap;
+      bs_kx = kx;
+      bs_step_px = (unsigned)((int)p.lda * 2);
+      bs_step_row = (unsigned)((p.Win - 2) * (int)p.lda * 2);
+    }
+  }
 
   // one 1-KiB piece q (0..NPA-1: A rows, NPA..NP-1: W rows) of K tile kt into ring slot `stage`;
   // the conv (tap, c0) cursor belongs to the tile currently being issued and advances with next_tile()
   auto issue_piece = [&](int kt, int stage, int q) {
     const int k0 = kbeg + kt * BK;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave_s * 1024);
+    if constexpr (BUF) {
+      if (q < NPA) {
+        const int j = q;
+        const unsigned dst = sbase + (j * WG + grp) * (NWV * 1024);
+        if (MODE == GM_DENSE) buf_dma16(bv_a[j], ra, (unsigned)k0 * 2u, dst);
+        else buf_dma16(buf_mask_oob(bv_nt[j], bs_sh, bv_a[j]), ra, bs_tap, dst);
+      } else {
+        const int j = q - NPA;
+        buf_dma16(bv_w, rw, bs_w[j] + (unsigned)(k0 >> 6) * 8192u, sbase + BM * 128 + (j * WG + grp) * (NWV * 1024));
+      }
+      return;
+    }
     if (q < NPA) {
       const int j = q;
       if (MODE == GM_DENSE) {
@@ -322,6 +400,17 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     }
   };
   auto next_tile = [&]() {
+    if constexpr (BUF && MODE == GM_CONV_S1) {
+      // scalar cursor: one pixel to the right, at the end of a kernel row down to the start of the next, after nine taps the next
+      // 64-channel chunk (uniform selects: the offset stays in a scalar register)
+      ++tap; ++bs_kx;
+      const bool row_end = bs_kx == 3;
+      bs_tap += row_end ? bs_step_row : bs_step_px;
+      bs_kx = row_end ? 0 : bs_kx;
+      if (tap == 9) { tap = 0; c0 += BK; bs_tap = (unsigned)c0 * 2u; }
+      bs_sh = 31u - (unsigned)tap;
+      return;
+    }
     if (MODE != GM_DENSE) { if (++tap == 9) { tap = 0; c0 += BK; } }
   };
   auto issue = [&](int kt, int stage) {
@@ -950,26 +1039,32 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_gn(const GemmK p) {
     if (g_prof.e0) hipExtLaunchKernelGGL(KERNEL, grid, dim3(TH), 0, st, g_prof.e0, g_prof.e1, 0, k);        \
     else hipLaunchKernelGGL(KERNEL, grid, dim3(TH), 0, st, k);                                              \
   } while (0)
-template <class T, int BM, int BN, int ST, int WG, int KG, int MW>
-static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k, int glu = 0) {
+template <class T, int BM, int BN, int ST, int WG, int KG, int MW, bool BUF>
+static void launch_tile_b(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k, int glu) {
   constexpr int TH = 256 * WG * KG * MW;
   // the tiles that carry the GEGLU epilogues (gemm_dispatch picks only these when glu != 0)
   constexpr bool GLUOK = WG == 1 && KG == 1 && ((BM == 256 && BN == 128 && MW == 2) || (BM == 128 && BN == 128 && MW == 2 && ST == 4) || (BM == 64 && BN == 64));
   if constexpr (GLUOK) {
-    if (glu == 1 && lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true, 1>)); return; }
-    if (glu == 1) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 1>)); return; }
-    if (glu == 2) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 2>)); return; }
+    if (glu == 1 && lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true, 1, BUF>)); return; }
+    if (glu == 1) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 1, BUF>)); return; }
+    if (glu == 2) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 2, BUF>)); return; }
   }
   if (gm == GM_DENSE) {
     if constexpr (WG == 1 && BN != 320 && BN != 160) {      // (the 128x320 / 128x160 tiles are never asked for the folded LayerNorm)
-      if (lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true>)); return; }
+      if (lnf) { DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, true, 0, BUF>)); return; }
     }
-    DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW>));
+    DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_DENSE, 0, WG, KG, MW, false, 0, BUF>));
   } else if (gm == GM_CONV_S1) {
-    DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_CONV_S1, 0, WG, KG, MW>));
+    DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_CONV_S1, 0, WG, KG, MW, false, 0, BUF>));
   } else {
     DH_GEMM_LAUNCH((k_gemm_dma<T, BM, BN, ST, GM_GENERIC, 0, WG, KG, MW>));
   }
+}
+// k.pp_a_bytes != 0: the operands fit buffer descriptors (gemm_dispatch) -- dense and stride-1 3x3 launches stage through them
+template <class T, int BM, int BN, int ST, int WG, int KG, int MW>
+static void launch_tile(int gm, bool lnf, dim3 grid, hipStream_t st, const GemmK& k, int glu = 0) {
+  if (k.pp_a_bytes != 0 && gm != GM_GENERIC) launch_tile_b<T, BM, BN, ST, WG, KG, MW, true>(gm, lnf, grid, st, k, glu);
+  else launch_tile_b<T, BM, BN, ST, WG, KG, MW, false>(gm, lnf, grid, st, k, glu);
 }
 #undef DH_GEMM_LAUNCH
 
@@ -1109,6 +1204,21 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   int gm = GM_GENERIC;
   if (k.mode == A_DENSE) gm = GM_DENSE;
   else if (k.mode == A_CONV3 && k.stride == 1 && k.up == 0 && k.pad == 1) gm = GM_CONV_S1;
+  // buffer-descriptor staging (BUF instantiations) whenever both operands lie below 2 GiB and the rows are 16-byte aligned
+  // (every launch of the U-Net / VAE / text engines; anything else keeps the address form)
+  if (!use_pp) {
+    k.pp_a_bytes = 0; k.pp_w_bytes = 0;
+    size_t ab = 0;
+    if (k.mode == A_DENSE) ab = ((size_t)(k.M - 1) * k.lda + k.K) * 2;
+    else if (k.Hout > 0 && k.Wout > 0 && k.M % (k.Hout * k.Wout) == 0)
+      ab = (size_t)(k.M / (k.Hout * k.Wout)) * k.Hin * k.Win * (size_t)k.lda * 2;
+    const size_t wb = (size_t)align_up((size_t)k.N, 64) * k.K * 2;
+    const bool conv_ok = k.mode == A_DENSE || (k.Cin % 64 == 0 && k.K == 9 * k.Cin);
+    if (g_buf_stage && ab > 0 && conv_ok && ab + (size_t)(k.Win + 1) * k.lda * 2 < 0x7ff00000ull && wb < 0x7ff00000ull && k.lda % 8 == 0 &&
+        ((size_t)k.A & 15) == 0 && ((size_t)k.W & 15) == 0) {
+      k.pp_a_bytes = (unsigned)ab; k.pp_w_bytes = (unsigned)wb;
+    }
+  }
 #ifdef DH_TUNING
   // ablations of the K loop (timing only): 1 = no LDS reads / MFMA, 2 = no DMA in the loop, 3 = 1 on the dense kernel
   static const int kAbl = getenv("DH_GEMM_ABLATE") ? atoi(getenv("DH_GEMM_ABLATE")) : 0;
@@ -1208,6 +1318,12 @@ extern "C" int dh_dbg_gemm_timeline(unsigned long long* ts) { dh::g_gemm_ts = ts
 extern "C" int dh_dbg_gemm_family(int force) {
   DH_REQUIRE(force >= 0 && force <= 2, "family: 0 policy, 1 k_gemm_dma, 2 k_gemm_pp");
   dh::g_pp_force = force;
+  return DH_OK;
+}
+
+// test hook: 1 = dense / stride-1 3x3 operands of k_gemm_dma stage through buffer descriptors (shipped), 0 = through addresses
+extern "C" int dh_dbg_gemm_stage(int buf) {
+  dh::g_buf_stage = buf ? 1 : 0;
   return DH_OK;
 }
 

@@ -432,19 +432,14 @@ def load_image(path):
     return torch.from_numpy(a.astype(np.float32) / scale).permute(2, 0, 1).contiguous()
 
 
-def load_scene(scene_dir, img_res=512):
-    """`load_diffhandles_inputs` (test/test_diffusion_handles.py:208-263) -> dict(transforms, prompt, img [1,3,R,R],
-    fg_mask [1,1,R,R] in {0,1}, depth [1,1,R,R], bg_depth [1,1,R,R])."""
+def load_scene_geometry(scene_dir, img_res=512):
+    """The geometric inputs of a scene only -- what `transform_depth` needs (test/test_diffusion_handles.py:213-215, 247-261):
+    dict(transforms, fg_mask [1,1,R,R] in {0,1}, depth [1,1,R,R], bg_depth [1,1,R,R]).  Needs transforms.json, mask.png,
+    depth.exr / .npy, bg_depth.exr / .npy; no image, no prompt."""
     import torch
     j = os.path.join
     with open(j(scene_dir, "transforms.json")) as f:
         transforms = json.load(f, object_pairs_hook=OrderedDict)
-    with open(j(scene_dir, "prompt.txt")) as f:
-        lines = [ln for ln in f.read().splitlines() if len(ln) > 0]
-    if not lines:
-        raise ValueError(f"{scene_dir}: empty prompt")
-    img = load_image(j(scene_dir, "input.png"))[None]
-    img = crop_and_resize(img[:, :3], img_res)
     mask = load_image(j(scene_dir, "mask.png"))[None]
     if mask.shape[1] > 1:
         mask = mask.mean(dim=1, keepdim=True)
@@ -459,8 +454,22 @@ def load_scene(scene_dir, img_res=512):
             raise FileNotFoundError(j(scene_dir, stem + ".exr"))
         return crop_and_resize(torch.from_numpy(np.ascontiguousarray(d))[None, None], img_res).to(torch.float32)
 
-    return dict(transforms=transforms, prompt=lines[0], img=img, fg_mask=mask, depth=depth_of("depth"),
-                bg_depth=depth_of("bg_depth"))
+    return dict(transforms=transforms, fg_mask=mask, depth=depth_of("depth"), bg_depth=depth_of("bg_depth"))
+
+
+def load_scene(scene_dir, img_res=512):
+    """`load_diffhandles_inputs` (test/test_diffusion_handles.py:208-263) -> dict(transforms, prompt, img [1,3,R,R],
+    fg_mask [1,1,R,R] in {0,1}, depth [1,1,R,R], bg_depth [1,1,R,R])."""
+    j = os.path.join
+    with open(j(scene_dir, "prompt.txt")) as f:
+        lines = [ln for ln in f.read().splitlines() if len(ln) > 0]
+    if not lines:
+        raise ValueError(f"{scene_dir}: empty prompt")
+    img = load_image(j(scene_dir, "input.png"))[None]
+    img = crop_and_resize(img[:, :3], img_res)
+    geo = load_scene_geometry(scene_dir, img_res)
+    return dict(transforms=geo["transforms"], prompt=lines[0], img=img, fg_mask=geo["fg_mask"], depth=geo["depth"],
+                bg_depth=geo["bg_depth"])
 
 
 def transform_args(t):

@@ -57,6 +57,23 @@ class StableNullInverter(NullInverter):
         return eps
 
     @torch.no_grad()
+    def get_noise_pred(self, latents, t, context, depth=None, is_forward=True):
+        """One classifier-free-guidance DDIM move of `latents` (reference stable_null_inverter.py:55-70): a B = 2 engine pass
+        over [uncond | cond] = `context`, eps = eps_u + w (eps_c - eps_u) with w = 1 on the way up (is_forward: next_step,
+        the inversion direction) and w = guidance_scale on the way down (prev_step).  latents / depth are channels-last
+        ([1,H,W,4] / [1,H,W,1]) like everywhere in this class; returns the moved latents [1,H,W,4]."""
+        with self.model.on_stream():
+            sample = self.model._unet_input(latents, depth, 2)
+            text = context.to(self.model.device, torch.float32).contiguous()
+            eps, _ = self.model.unet.forward(sample, float(t), text, save_for_backward=False, want_acts=False)
+            eps_u, eps_c = eps[0:1].contiguous(), eps[1:2].contiguous()
+            if is_forward:
+                a_from, a_to = self.scheduler.inversion_alphas(t)
+                return self._step(latents, eps_u, eps_c, 1.0, a_from, a_to)
+            a_t, a_p = self.scheduler.step_alphas(t)
+            return self._step(latents, eps_u, eps_c, self.guidance_scale, a_t, a_p)
+
+    @torch.no_grad()
     def latent2image(self, latents_nchw):
         image = self.model.vae.decode(1 / VAE_SCALE * latents_nchw.detach())["sample"]
         return (image + 1) / 2

@@ -145,6 +145,19 @@ def _eps_single(unet, x, depth64, t, ctx):
     return unet(torch.cat([x, depth64[0].view(1, 1, *depth64.shape[2:])], dim=1), t, encoder_hidden_states=ctx)["sample"]
 
 
+@torch.no_grad()
+def get_noise_pred(unet, sched, latents, depth64, t, context, guidance_scale=CFG_SCALE, is_forward=True):
+    """Reference stable_null_inverter.py:55-70 (StableNullInverter.get_noise_pred): one classifier-free-guidance DDIM move --
+    a B = 2 pass over context = [uncond | cond], guidance scale 1 and next_step on the way up (is_forward), the configured
+    scale and prev_step on the way down."""
+    inp = _with_depth(torch.cat([latents] * 2), None if depth64 is None else torch.cat([depth64] * 2))
+    e = unet(inp, t, encoder_hidden_states=context)["sample"]
+    eu, ec = e.chunk(2)
+    w = 1.0 if is_forward else guidance_scale
+    eps = eu + w * (ec - eu)
+    return sched.invert_step(eps, t, latents) if is_forward else sched.step(eps, t, latents)
+
+
 def null_text_inversion(unet, sched, latent0, disparity, uncond0, cond, num_inner_steps=5, eps0=1e-5,
                         num_steps=50, null_steps=None, record=None):
     """Returns (ddim_latents list[51], uncond [50,1,77,C]).  `record` (a list) receives per timestep a dict with the

@@ -75,6 +75,12 @@ def test_api_surface_matches_reference_names():
     assert inspect.signature(compute_background_loss).parameters["loss_type"].default == "global_avg"
     sig = inspect.signature(pkg.StableNullInverter.invert)
     assert sig.parameters["num_inner_steps"].default == 10 and sig.parameters["early_stop_epsilon"].default == 1e-5
+    # every public method of the reference class (stable_null_inverter.py:12-181)
+    for m in ("to", "prev_step", "next_step", "get_noise_pred_single", "get_noise_pred", "latent2image", "image2latent",
+              "ddim_loop", "ddim_inversion", "null_optimization", "invert"):
+        assert hasattr(pkg.StableNullInverter, m), m
+    sig = inspect.signature(pkg.StableNullInverter.get_noise_pred)
+    assert list(sig.parameters)[1:] == ["latents", "t", "context", "depth", "is_forward"] and sig.parameters["is_forward"].default is True
     import diffhandles
     assert diffhandles.DiffusionHandles is dh
 

@@ -85,13 +85,15 @@ def full():
     return _rig(torch.float16, 64, 16)
 
 
-def test_guided_step_full_size_matches_oracle(full):
-    """Three teacher-forced guided steps (t_idx 0, 1, 2: the three layer phases act2 / act1 / act1 + act2 of the weight
-    schedule, all three iteration multipliers each) and one unguided step (t_idx 38 = guidance_max_step) of
-    GuidedStableDiffuser.guided_step on HipUNet(SD2_DEPTH) fp16 against oracle.loop_ref.guided_inference(steps=[i]) on
-    UNetTorch(SD2_DEPTH) fp32, the real 512 x 512 re-projection, at the gates of the TINY teacher-forced loop test:
-    latent after the step rel-L2 < 5e-3, first-iteration update (the guidance gradient through the engine's backward)
-    < 6e-2, three-iteration update < 0.2."""
+def test_guided_loop_full_size_all_50_steps_teacher_forced(full):
+    """ALL 50 timesteps of the default loop at the size bench.py times (round 6; round 5 held t_idx 0, 1, 2 and 38 only):
+    38 guided steps (every layer phase of the weight schedule, all three iteration multipliers, the late small-t steps where the
+    activation scale and the fp16 headroom of grad_scale = 256 differ from the first steps) and 12 unguided steps of
+    GuidedStableDiffuser.guided_step on HipUNet(SD2_DEPTH) fp16, teacher-forced -- every step starts from the ORACLE's latent --
+    against oracle.loop_ref.guided_inference(steps=[i]) on UNetTorch(SD2_DEPTH) fp32, with the original activations of all 50
+    timesteps from the oracle's initial inference and the real 512 x 512 re-projection.  Gates (those of the TINY teacher-forced
+    loop test): latent after the step rel-L2 < 5e-3, first-iteration update (the guidance gradient through the engine's
+    backward) < 6e-2, three-iteration update < 0.2.  Prints the worst step of each."""
     from diffusionhandles_amd.depth_transform import transform_depth
     from oracle import loop_ref as L
     r = full
@@ -99,35 +101,42 @@ def test_guided_step_full_size_matches_oracle(full):
     ang, tr = TRANSFORMS[2]
     disp_e, corr = transform_depth(r.depth.to(dev()), r.bg.to(dev()), r.mask.to(dev()), gd.get_depth_intrinsics(), rot_angle=ang,
                                    rot_axis=torch.tensor([0.0, 1.0, 0.0]), translation=torch.tensor(tr))
-    acts = _orig_activations(r, 3)
+    acts = _orig_activations(r, 50)
     assert acts[0].shape == (50, 1280, 32, 32) and acts[1].shape == (50, 640, 64, 64) and acts[2].shape == (50, 320, 64, 64)
     gmax = r.conf.guidance_max_step
-    worst = dict(step=0.0, upd=0.0, upd3=0.0)
+    worst = dict(step=(0.0, -1), upd=(0.0, -1), upd3=(0.0, -1))
+    failures = []
     with torch.no_grad(), gd.on_stream():
         gd.scheduler.set_timesteps(50)
         ts = gd.scheduler.timesteps
         st = gd.prepare_guidance(disp_e, r.prompt, acts, corr)
         assert st.plan is not None and st.n_pairs > 1000
         x_in = r.noise
-        for i in (0, 1, 2, gmax):
+        for i in range(50):
             rec_o, rec_p = {}, {}
             L.guided_inference(r.ref, L.DDIM(), x_in, disp_e, r.unc, r.cond, acts, corr.numpy(), r.conf, record=rec_o, steps=[i])
             x_out = gd.guided_step(st, x_in.permute(0, 2, 3, 1).contiguous(), i, ts[i], r.unc[i], record=rec_p)
             e = rel(x_out.permute(0, 3, 1, 2), rec_o["step"][0])
-            worst["step"] = max(worst["step"], e)
-            assert e < 5e-3, f"t_idx {i}: latent after the step rel-L2 {e:.3e} >= gate 5e-3"
+            worst["step"] = max(worst["step"], (e, i))
+            line = f"t_idx {i:2d} (t = {int(ts[i]):3d}): latent after the step {e:.3e}"
+            if e >= 5e-3:
+                failures.append(f"t_idx {i}: latent after the step rel-L2 {e:.3e} >= gate 5e-3")
             if i < gmax:
                 assert len(rec_p["opt"]) == 3 and len(rec_o["opt"]) == 3
                 eu = rel(rec_p["opt"][0] - x_in, rec_o["opt"][0] - x_in)
                 eu3 = rel(rec_p["opt"][2] - x_in, rec_o["opt"][2] - x_in)
-                worst["upd"], worst["upd3"] = max(worst["upd"], eu), max(worst["upd3"], eu3)
-                assert eu < 6e-2 and eu3 < 0.2, (f"t_idx {i}: first-iteration update rel-L2 {eu:.3e} (gate 6e-2), three-iteration "
-                                                 f"update {eu3:.3e} (gate 0.2), update norm {(rec_o['opt'][0] - x_in).norm().item():.3e}")
+                worst["upd"], worst["upd3"] = max(worst["upd"], (eu, i)), max(worst["upd3"], (eu3, i))
+                line += f", first-iteration update {eu:.3e}, three-iteration update {eu3:.3e}, update norm {(rec_o['opt'][0] - x_in).norm().item():.3e}"
+                if eu >= 6e-2 or eu3 >= 0.2:
+                    failures.append(f"t_idx {i}: first-iteration update rel-L2 {eu:.3e} (gate 6e-2), three-iteration update {eu3:.3e} (gate 0.2)")
             else:
                 assert len(rec_o.get("opt", [])) == 0 and len(rec_p.get("opt", [])) == 0
+            print(line)
             x_in = rec_o["step"][0]                    # teacher forcing: the next step starts from the oracle's latent
-    print(f"full-size guided step vs oracle: worst latent-after-step rel-L2 {worst['step']:.3e} (gate 5e-3), first-iteration "
-          f"update {worst['upd']:.3e} (gate 6e-2), three-iteration update {worst['upd3']:.3e} (gate 0.2)")
+    print(f"full-size guided loop vs oracle, 50 teacher-forced steps: worst latent-after-step rel-L2 {worst['step'][0]:.3e} at t_idx "
+          f"{worst['step'][1]} (gate 5e-3), first-iteration update {worst['upd'][0]:.3e} at t_idx {worst['upd'][1]} (gate 6e-2), "
+          f"three-iteration update {worst['upd3'][0]:.3e} at t_idx {worst['upd3'][1]} (gate 0.2)")
+    assert not failures, failures
     full.acts, full.disp_e, full.corr = acts, disp_e, corr
 
 
@@ -141,7 +150,7 @@ def test_guided_step_batch8_full_size_matches_single_steps(full):
     r = full
     gd = r.gd
     if not hasattr(r, "acts"):
-        r.acts = _orig_activations(r, 3)
+        r.acts = _orig_activations(r, 50)
     K = 8
     Y = torch.tensor([0.0, 1.0, 0.0])
     tfs = [(TRANSFORMS[i][0], Y, torch.tensor(TRANSFORMS[i][1])) for i in range(K)]
