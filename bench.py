@@ -41,6 +41,36 @@ MFMA_PEAK_TFLOPS = 2500.0              # dense fp16/bf16 MFMA peak, MI355X_MICRO
 HBM_PEAK = 8000.0
 
 
+GEMM_SOURCES = ("gemm.hip", "gemm_pp.hip", "gemm_k.h", "unet_kernels.h", "unet_engine.cpp")
+
+
+def gemm_sources_sha(root=ROOT):
+    """SHA-256 over the sources that decide which GEMM launches a pass makes and what they move (tile policy, split-K slabs,
+    staging): a committed PMC traffic figure is only reported next to a live measurement when it was collected on THIS code
+    (tools/pmc_summarise.py stamps the same hash into profiles/rNN_pmc_gemm_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        with open(os.path.join(root, "diffusionhandles_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def committed_traffic(root=ROOT, res=512, dtype="fp16"):
+    """(bytes per launch, file name, note) of the newest profiles/rNN_pmc_gemm_traffic.json -- or (None, name, why) when it was
+    collected on other GEMM sources than the ones in the tree (stale), or for another workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_pmc_gemm_traffic.json")), reverse=True)
+    if not files or res != 512 or dtype != "fp16":
+        return None, None, "no PMC collection for this workload"
+    name = os.path.basename(files[0])
+    with open(files[0]) as fh:
+        rec = json.load(fh)
+    if rec.get("sources_sha256") != gemm_sources_sha(root):
+        return None, name, f"{name} was collected on other GEMM sources (sources_sha256 differs): stale, not reported"
+    return round(rec["traffic_bytes_per_launch"]), name, "offline PMC (separate FETCH_SIZE / WRITE_SIZE passes) on these sources"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +327,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def per_rank(seconds):
+        """every rank's own figure, in rank order (a slow rank stays visible next to the MAX the headline uses)"""
+        if dist is None:
+            return [seconds]
+        mine = torch.tensor([seconds], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        return [float(g.item()) for g in got]
+
     K = max(0, args.batch_edits)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     conf = C.load_default()
@@ -370,6 +409,7 @@ def main():
             one_step()
         barrier()
         elapsed = time.perf_counter() - t0
+    elapsed_by_rank = per_rank(elapsed)
     elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(state["x"]).all(), "latents diverged"
 
@@ -393,24 +433,36 @@ def main():
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         # HBM traffic per k_gemm launch: PMC counters cannot be read from inside the process, so this is the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, gfx950 x2 fetch
-        # correction) of the same U-Net fwd+bwd launch mix; null when the workload differs from the measured one.
-        traffic = None
-        for name in ("r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
-            pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc) and args.res == 512 and args.dtype == "fp16":
-                with open(pmc) as fh:
-                    traffic = round(json.load(fh)["traffic_bytes_per_launch"])
-                break
+        # correction) of the same U-Net fwd+bwd launch mix -- reported only when it was collected on the GEMM sources in the
+        # tree (committed_traffic: a hash of csrc/gemm*.hip, gemm_k.h, unet_kernels.h, unet_engine.cpp), null otherwise.
+        traffic, traffic_file, traffic_note = committed_traffic(ROOT, args.res, args.dtype)
         step_tf = STEP_TFLOP.get(args.res)
-        roof = {"bound": "mfma", "kernel": "k_gemm_dma (+ k_gemm_pp for the GEGLU forward launches): MFMA implicit GEMM, conv3x3 + linear, fwd + input-gradient",
-                "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes/launch (offline PMC)", "launches_per_step": int(n.value // max(1, args.profile_steps)),
-                "algorithmic_bytes_per_launch": round(alg.value / max(1, n.value)),
-                "traffic_over_algorithmic": round(traffic / (alg.value / max(1, n.value)), 2) if traffic and alg.value > 0 else None,
+        nl = max(1, n.value)
+        sec = ms.value * 1e-3
+        alg_per = alg.value / nl
+        gbps = alg.value / sec / 1e9 if sec > 0 else 0.0
+        intensity = fl.value / alg.value if alg.value > 0 else 0.0          # algorithmic FLOP per algorithmic byte of the launch mix
+        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK * 1e9)                   # 312.5 FLOP/B: below it the HBM side of the roofline bounds the mix
+        hbm_side = intensity < ridge
+        roof = {"bound": "hbm" if hbm_side else "mfma",
+                "kernel": "k_gemm_dma (+ k_gemm_pp for the GEGLU forward launches): MFMA implicit GEMM, conv3x3 + linear, fwd + input-gradient",
+                "achieved": round(gbps, 1) if hbm_side else round(ach, 2), "peak": HBM_PEAK if hbm_side else MFMA_PEAK_TFLOPS,
+                "unit": "GB/s" if hbm_side else "TFLOP/s",
+                "frac": round(gbps / HBM_PEAK, 4) if hbm_side else round(ach / MFMA_PEAK_TFLOPS, 4),
+                "bound_note": f"algorithmic intensity of the launch mix {intensity:.0f} FLOP/B against the ridge {ridge:.1f} FLOP/B (2.5 PFLOP/s / 8 TB/s): "
+                              + ("the HBM side bounds it; " if hbm_side else "the MFMA side bounds it; ") + "both fractions are given (frac_mfma, frac_hbm)",
+                "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                "achieved_tflops": round(ach, 2), "frac_mfma": round(ach / MFMA_PEAK_TFLOPS, 4),
+                "achieved_gbps_algorithmic": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK, 4),
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_file, "traffic_note": traffic_note,
+                "launches_per_step": int(n.value // max(1, args.profile_steps)),
+                "algorithmic_bytes_per_launch": round(alg_per),
+                "traffic_over_algorithmic": round(traffic / alg_per, 2) if traffic and alg.value > 0 else None,
+                "frac_hbm_traffic": round(traffic * nl / sec / 1e9 / HBM_PEAK, 4) if traffic and sec > 0 else None,
                 "algorithmic_bytes_note": "every operand once in 16-bit storage (A source, W, output, residual; include/diffhandles_hip.h "
                                           "dh_gemm_profile_bytes), live over the profiled guided steps; traffic = PMC of the U-Net fwd+bwd launch mix",
-                "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
-                "flops_per_launch": round(fl.value / max(1, n.value) / 1e9, 3),
+                "avg_launch_us": round(ms.value * 1e3 / nl, 2),
+                "flops_per_launch": round(fl.value / nl / 1e9, 3),
                 "step_tflop_algorithmic": step_tf,
                 "step_frac_of_mfma_peak": round(args.steps / elapsed * step_tf / MFMA_PEAK_TFLOPS, 4) if step_tf else None,
                 "step_frac_note": "algorithmic TFLOP of the reference's step (the truncated optimisation forwards execute less)"}
@@ -464,9 +516,14 @@ def main():
             te = time.perf_counter()
             imgs, _ = dh.transform_foreground_batch(depth, prompt, mask, bg_depth, uncond, init_noise, acts, tfs)
             barrier()
-            te = max_over_ranks(time.perf_counter() - te)
+            te_mine = time.perf_counter() - te
+            te_by_rank = per_rank(te_mine)
+            te = max_over_ranks(te_mine)
             assert torch.isfinite(imgs).all()
             edits_info = {"edits_per_gpu": K, "edits_per_s": round(world * K / te, 4), "s_per_batch": round(te, 3),
+                          "per_rank": {"s_per_batch": [round(v, 3) for v in te_by_rank],
+                                       "edits_per_s": [round(K / v, 4) for v in te_by_rank],
+                                       "what": "each rank's own wall time / rate for its batch (rank order); the whole-job figure divides by the MAX"},
                           "concurrent_streams": 1,
                           "what": f"{K} edits of one image per GPU as one batch: re-projection of {K} transforms, 38 guided + 12 "
                                   "unguided batched steps, AutoencoderKL decode (native decoder, random weights); identity cached; MAX over ranks"}
@@ -614,6 +671,9 @@ def main():
             "metric": f"guided-denoise steps/sec at {args.res}x{args.res} (SD2-depth)",
             "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "per_rank": {"ms_per_step": [round(v / args.steps * 1e3, 3) for v in elapsed_by_rank],
+                         "steps_per_s": [round(args.steps / v, 3) for v in elapsed_by_rank], "backend": backend if world > 1 else None,
+                         "what": "each rank's own timed region (rank order); value = world x steps / MAX over ranks"},
             "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": f"single {args.res}x{args.res} edit per GPU, SD2-depth (865.9M params, seeded random weights), guided "
                                    "phase: 3 x (fwd + energy + bwd-to-latent) + CFG fwd (B=2) + DDIM step",

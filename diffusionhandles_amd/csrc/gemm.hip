@@ -155,7 +155,10 @@ enum { GM_DENSE = 0, GM_CONV_S1 = 1, GM_GENERIC = 2 };
 #define LNF_ABL(bit) && !(p.lnf_abl & (bit))
 #define LEAN_ABL && !(p.lnf_abl & 8)
 #define DH_STAMP(i) do { if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) p.ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// per-K-tile stamps of the same wave (slots 8 ..): 3 per tile -- loop top, tile landed + barrier passed, multiplies and next issue done
+#define DH_STAMP_T(kt, j) do { if (p.ts && (kt) < 40 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) p.ts[8 + 3 * (kt) + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define DH_STAMP_T(kt, j) do { } while (0)
 #define LNF_ABL(bit)
 #define LEAN_ABL
 #define DH_STAMP(i) do { } while (0)
@@ -502,9 +505,11 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   int stg = 0;                     // kt % ST
   DH_STAMP(2);
   for (int kt = 0; kt < loop_tiles; ++kt) {
+    DH_STAMP_T(kt, 0);
     // tile kt has landed once at most (ST-2) later tiles' loads are still outstanding
     if (ntiles - 1 - kt >= ST - 2) wait_vmcnt<NP * (ST - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    DH_STAMP_T(kt, 1);
     if (kt == 0) DH_STAMP(3);
     if (KG > 1 && kt >= ntiles) continue;           // a group with a shorter K range only keeps the barrier count
     const bool more = ABL != 2 && kt + ST - 1 < ntiles;
@@ -550,6 +555,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
       }
     }
     if (more) next_tile();
+    DH_STAMP_T(kt, 2);
   }
   DH_STAMP(4);
 
@@ -752,6 +758,74 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
     return;
   }
   DH_STAMP(5);
+  // GroupNorm statistics of the output in THIS kernel's epilogue (p.gn_epi, round 6): the next op normalises the tensor being
+  // written, and where K is not split there is no reduce kernel to carry the slice statistics, so a k_gn_partial launch re-read
+  // the tensor just to sum it.  The rounded outputs are still in registers here: per lane column sums over its TM rows, a
+  // half-wave reduction over the 32 rows of a block (DPP), the wave rows and the columns of a group through LDS in a fixed
+  // order, and the tile leaves (n, mean, M2) of every group fragment it covers as "slice" 2 * row_tile + part of the
+  // [b][g][3][S] layout k_gn_apply merges (part 1 = the tail of a group whose first channel lies in the previous column tile;
+  // a group wholly inside the tile writes an empty part 1).
+  constexpr bool GNE = WNS == 2 && GLU == 0 && BN <= 128 && BN % 64 == 0;
+  const bool gn_epi = GNE && p.gn_epi != 0 && p.splits == 1;
+  float gsa[GNE ? TN : 1][16], gsq[GNE ? TN : 1][16];
+  if (GNE) {
+#pragma unroll
+    for (int j = 0; j < (GNE ? TN : 1); ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { gsa[j][r] = 0.f; gsq[j][r] = 0.f; }
+  }
+  auto gn_acc = [&](int j, int g, uint2 packed) {
+    if constexpr (GNE) {
+      typedef T T4g __attribute__((ext_vector_type(4)));
+      const T4g ov = __builtin_bit_cast(T4g, packed);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float v = to_f32<T>(ov[c]); gsa[j][4 * g + c] += v; gsq[j][4 * g + c] += v * v; }
+    }
+  };
+  auto gn_finish = [&]() {
+    if constexpr (GNE) {
+      constexpr int CS_BYTES = WMS * BN * 2 * 4;
+      static_assert(CS_BYTES <= 4096 && KG * ST * STAGE >= 8192, "column-sum scratch lives in the last 4 KiB of the ring");
+      float* cs = reinterpret_cast<float*>(smem_all + KG * ST * STAGE - 4096);
+      __syncthreads();                               // every wave is done with the rings / the merge buffers
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float a = gsa[j][r], q = gsq[j][r];
+          a = oct_sum(a); q = oct_sum(q);
+          a += dpp_f32<DPP_ROW_MIRROR>(a); q += dpp_f32<DPP_ROW_MIRROR>(q);
+          { const LanePair pa = row_pair(a); a = pa.a + pa.b; }
+          { const LanePair pq = row_pair(q); q = pq.a + pq.b; }
+          if (ln == 0) {
+            const int col = wn * CPW + j * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+            *reinterpret_cast<float2*>(cs + (wm * BN + col) * 2) = make_float2(a, q);
+          }
+        }
+      __syncthreads();
+      const int cpg = p.gn_cpg, G = p.gn_G, Sx = p.gn_S;
+      const int f = tid >> 3, sub = tid & 7;
+      const int g = n0 / cpg + f;
+      if (tid < (BN / 8) * 8 && g < G && g * cpg < n0 + BN) {
+        const int lo = g * cpg, hi_c = lo + cpg;
+        const int c_lo = (lo > n0 ? lo : n0) - n0, c_hi = (hi_c < n0 + BN ? hi_c : n0 + BN) - n0;
+        float a = 0.f, q = 0.f;
+        for (int c = c_lo + sub; c < c_hi; c += 8) {
+#pragma unroll
+          for (int w2 = 0; w2 < WMS; ++w2) { const float2 v = *reinterpret_cast<const float2*>(cs + (w2 * BN + c) * 2); a += v.x; q += v.y; }
+        }
+        a = oct_sum(a); q = oct_sum(q);
+        if (sub == 0) {
+          const int b = m0 / p.gn_HW, rt = (m0 - b * p.gn_HW) / BM;
+          const int part = lo < n0 ? 1 : 0;
+          const float n = (float)BM * (float)(c_hi - c_lo);
+          float* o = p.gn_part + ((size_t)(b * G + g) * 3) * Sx + 2 * rt + part;
+          o[0] = n; o[Sx] = a / n; o[2 * Sx] = q - a * a / n;
+          if (part == 0 && hi_c <= n0 + BN) { o[1] = 0.f; o[Sx + 1] = 0.f; o[2 * Sx + 1] = 0.f; }      // the whole group lies in this tile
+        }
+      }
+    }
+  };
   // the common epilogue as straight-line code: bias and residual already sit in registers (prefetched under the K loop), no
   // per-image vector, no SiLU.  The general path below carries a fallback load and a ~90-instruction SiLU block per 4-column
   // group behind uniform branches; jumping over them costs an instruction-cache line fetch per hop in a kernel whose
@@ -783,12 +857,14 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
           T4 o;
           o[0] = from_f32<T>(v0); o[1] = from_f32<T>(v1); o[2] = from_f32<T>(v2); o[3] = from_f32<T>(v3);
           w[g] = __builtin_bit_cast(uint2, o);
+          if (gn_epi) gn_acc(j, g, w[g]);
         }
         const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
         *reinterpret_cast<uint4*>(orow + j * 32) = ca;
         *reinterpret_cast<uint4*>(orow + j * 32 + 16) = cb;
       }
     }
+    if (gn_epi) gn_finish();
     DH_STAMP(6);
 #ifdef DH_TUNING
     if (p.ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DH_STAMP(7); }
@@ -809,15 +885,18 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         if (nb >= p.N) continue;                    // N is a multiple of 32 on this path
         uint2 w[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
           w[g] = epilogue_pack<T>(p, m, nb + 8 * g + 4 * hi, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
                                   acc[i][j][4 * g + 3], pre_r, rpre[i][j][g], pre_b, bpre[PRE_B ? j : 0][g]);
+          if (gn_epi) gn_acc(j, g, w[g]);
+        }
         const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
         T* out = reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + nb + 8 * hi;
         *reinterpret_cast<uint4*>(out) = ca;
         *reinterpret_cast<uint4*>(out + 16) = cb;
       }
     }
+    if (gn_epi) gn_finish();
     DH_STAMP(6);
 #ifdef DH_TUNING
     if (p.ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DH_STAMP(7); }
@@ -1169,6 +1248,15 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   splits = cdiv(ktiles, tiles_per_split);
   k.splits = splits;
   k.k_per_split = tiles_per_split * BK;
+  // GroupNorm statistics in the epilogue: an unsplit k_gemm_dma launch whose output the next op normalises (forward statistics
+  // only; tiles of whole images' rows, groups no wider than a column tile, at most 64 "slices" = 2 per row tile for the merge
+  // in k_gn_apply).  *gn_done then carries the slice count (> 1) instead of 1.
+  k.gn_epi = 0; k.gn_cpg = 0;
+  if ((g_buf_stage & 4) == 0 && splits == 1 && !use_pp && !t160 && !n320 && !glu && k.gn_part && !k.gnb_x && gn_done && k.gn_G > 0 && k.gn_HW > 0 && k.C &&
+      k.wide_store && k.M % k.gn_HW == 0 && k.gn_HW % BM == 0 && k.N % k.gn_G == 0 && k.N % BN == 0 && BN % 64 == 0 && BN <= 128) {
+    const int cpg = k.N / k.gn_G, sx = 2 * (k.gn_HW / BM);
+    if (cpg >= 8 && cpg <= BN && sx <= 64) { k.gn_epi = 1; k.gn_cpg = cpg; k.gn_S = sx; }
+  }
 #ifdef DH_TUNING
   k.w_nt = kWnt > 0 && tm <= kWnt;
   static const int kLnfAbl = getenv("DH_LNF_ABL") ? atoi(getenv("DH_LNF_ABL")) : 0;
@@ -1214,7 +1302,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
       ab = (size_t)(k.M / (k.Hout * k.Wout)) * k.Hin * k.Win * (size_t)k.lda * 2;
     const size_t wb = (size_t)align_up((size_t)k.N, 64) * k.K * 2;
     const bool conv_ok = k.mode == A_DENSE || (k.Cin % 64 == 0 && k.K == 9 * k.Cin);
-    if (g_buf_stage && ab > 0 && conv_ok && ab + (size_t)(k.Win + 1) * k.lda * 2 < 0x7ff00000ull && wb < 0x7ff00000ull && k.lda % 8 == 0 &&
+    if ((g_buf_stage & 1) && ab > 0 && conv_ok && ab + (size_t)(k.Win + 1) * k.lda * 2 < 0x7ff00000ull && wb < 0x7ff00000ull && k.lda % 8 == 0 &&
         ((size_t)k.A & 15) == 0 && ((size_t)k.W & 15) == 0) {
       k.pp_a_bytes = (unsigned)ab; k.pp_w_bytes = (unsigned)wb;
     }
@@ -1262,6 +1350,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
   else if (BN == 128) launch_tile<T, 128, 128, 4, 1, 1, 1>(gm, lnf, grid, st, k);
   else launch_tile<T, 128, 64, 5, 1, 1, 1>(gm, lnf, grid, st, k);
   g_prof.e0 = g_prof.e1 = nullptr;
+  if (k.gn_epi) *gn_done = k.gn_S;
   if (splits > 1) {
     if (k.gn_part && k.gn_G > 0 && k.gn_HW > 0 && k.N % k.gn_G == 0 && (GN_GB * (k.N / k.gn_G)) % 8 == 0 &&
         GN_GB * (k.N / k.gn_G) <= 2048 && k.M % k.gn_HW == 0) {
@@ -1323,7 +1412,7 @@ extern "C" int dh_dbg_gemm_family(int force) {
 
 // test hook: 1 = dense / stride-1 3x3 operands of k_gemm_dma stage through buffer descriptors (shipped), 0 = through addresses
 extern "C" int dh_dbg_gemm_stage(int buf) {
-  dh::g_buf_stage = buf ? 1 : 0;
+  dh::g_buf_stage = buf;          // bit 0: buffer staging; bit 2 (value 4): NO GroupNorm statistics in the GEMM epilogue (A/B of that fusion)
   return DH_OK;
 }
 

@@ -716,6 +716,10 @@ bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan)
   if (k.rowvec && (k.rowvec_ld % 4 || ((size_t)k.rowvec & 15))) return false;
   if (k.K % 64 || k.M <= 0 || (!k.C && !glu)) return false;
   if (k.N % 160 && k.N % 128) return false;
+  // the W descriptor covers N * K * 2 bytes of [N / 64][K / 64] tiles: a last partial 64-row tile would lie partly beyond it (the
+  // LDS-DMA then returns zeros); the bias is read as float4
+  if (k.N % 64) return false;
+  if (k.bias && ((size_t)k.bias & 15)) return false;
   if ((k.C && (k.ldc % 8 || ((size_t)k.C & 15))) || k.lda % 8 || ((size_t)k.A & 15) || ((size_t)k.W & 15)) return false;
   if (k.R && (k.ldr % 8 || ((size_t)k.R & 15))) return false;
   if (k.mode != A_DENSE && (k.Hout <= 0 || k.Wout <= 0 || k.M % (k.Hout * k.Wout) || k.Cin % 64 || k.K != 9 * k.Cin)) return false;

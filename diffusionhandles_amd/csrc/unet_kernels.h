@@ -110,7 +110,7 @@ void launch_conv_small_bwd(int dtype, const void* dy, int dy_is_f32, const float
 
 // GroupNorm (+SiLU): y = act(gn(x));  stats = [B*G][2] (mean, rstd) saved for backward.
 // have_partials != 0: the slice statistics in `scratch` were already left by the producer of x
-// (split-K reduce / concat), only the apply kernel runs.
+// (split-K reduce / concat: 1 = gn_slices(HW, B) slices; a GEMM epilogue: the slice count itself, > 1), only the apply kernel runs.
 void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                           int have_partials = 0);

@@ -391,7 +391,8 @@ void launch_groupnorm_fwd(int dtype, const void* x, const float* gamma, const fl
                           float* scratch, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                           int have_partials) {
   DH_ABLATE(2);
-  const int S = gn_slices(HW, B);
+  // have_partials > 1: the producer was a GEMM whose epilogue left that many slices per group (two per row tile, gemm.hip gn_epi)
+  const int S = have_partials > 1 ? have_partials : gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);

@@ -94,6 +94,13 @@ class GuidedStableDiffuser(GuidedDiffuser):
 
     def __init__(self, conf, unet=None, vae=None, text_encoder=None, tokenizer=None, dtype=torch.float16,
                  unet_config=None, max_batch=2, synthetic_seed=0):
+        """max_batch sizes the engine this diffuser builds in .to(device) (ignored when `unet` is handed in): the largest batch of
+        ANY U-Net pass.  Contract (since round 5): K batched edits need max_batch >= 2 K (their CFG pass runs [uncond | cond] for
+        every edit; guided_step_batch / guided_inference_batch / guided_inference_streams raise RuntimeError otherwise, lanes are
+        never silently re-sized), and a forward that is SAVED for a backward pass -- unet.forward(save_for_backward=True), i.e.
+        the optimisation passes and null-text inversion -- may be at most max_batch // 2 wide (the engine's max_diff_batch:
+        only those passes keep every activation, which is what halves the arenas); a wider saved forward fails with the
+        engine's "exceeds max_diff_batch" error.  Build a HipUNet yourself (max_diff_batch=...) for any other split."""
         super().__init__(conf=conf)
         self.scheduler = DDIMScheduler()
         self.dtype = dtype

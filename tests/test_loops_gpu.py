@@ -442,11 +442,12 @@ def test_null_text_five_timesteps_full_size_match_oracle():
     (round 6; round 5 held one timestep with a synthetic target).  The oracle runs the real chain -- 50 DDIM-inversion forwards
     of a latent, then oracle.loop_ref.null_text_inversion(null_steps=5) on UNetTorch(SD2_DEPTH) fp32 with autograd -- and
     records the state every timestep started from; StableNullInverter.null_step is teacher-forced from that state (reference
-    stable_null_inverter.py:135-167).  Per timestep: the first loss within 2 %, the later losses within 10 % (Adam's sign noise
-    on near-zero-gradient elements, see test_null_inversion_matches_oracle), the text gradient of the first inner step end to end
-    < 6e-2 (its cotangent is the small difference of two latents: the 16-bit forward's error in eps is a few per cent of it) and
-    -- what the engine's BACKWARD is accountable for -- against the oracle's autograd seeded with the product's own cotangent
-    < 1e-2 (measured 2.4e-3 by tools/probe_text_grad.py), five inner steps taken."""
+    stable_null_inverter.py:135-167).  Per timestep: the first loss within 1 % (measured 0.08 %), the later losses within 2 %
+    (0.06 %; Adam's sign noise on near-zero-gradient elements, see test_null_inversion_matches_oracle), the text gradient of the
+    first inner step END TO END < 1e-2 (measured 2.0e-3: on the real chain the cotangent 2 (rec - target) / n is not the tiny
+    difference the synthetic-target test above constructs, so the 16-bit forward's error in eps does not dominate it) and --
+    what the engine's BACKWARD alone is accountable for -- against the oracle's autograd seeded with the product's own
+    cotangent < 5e-3 (measured 1.2e-3), five inner steps taken."""
     from diffusionhandles_amd import conf as C
     from diffusionhandles_amd.guided_stable_diffuser import GuidedStableDiffuser
     from diffusionhandles_amd.stable_null_inverter import StableNullInverter
@@ -496,9 +497,9 @@ def test_null_text_five_timesteps_full_size_match_oracle():
         worst["loss0"], worst["loss"] = max(worst["loss0"], l0), max(worst["loss"], ll)
         worst["grad"], worst["grad_iso"] = max(worst["grad"], e0), max(worst["grad_iso"], e_iso)
         assert all(s_ > 0 and (s_ == 2.0 ** round(np.log2(s_))) for s_ in prec["scale"]), prec["scale"]
-        assert l0 < 2e-2, (i, prec["loss"], r["loss"])
-        assert e0 < 6e-2 and e_iso < 1e-2, (i, e0, e_iso)
-        assert ll < 0.1, (i, prec["loss"], r["loss"])
+        assert l0 < 1e-2, (i, prec["loss"], r["loss"])              # measured 0.08 %
+        assert e0 < 1e-2 and e_iso < 5e-3, (i, e0, e_iso)           # measured 2.0e-3 / 1.2e-3
+        assert ll < 2e-2, (i, prec["loss"], r["loss"])              # measured 0.06 %
     print("full-size null-text, five timesteps, worst:", worst)
 
 

@@ -33,7 +33,41 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["errors"] == [] and out["roofline"]["frac"] > 0
     assert abs(out["value"] - 2 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-2 * out["value"]      # whole-job rate = 2 ranks x steps / MAX time
-    print("two ranks on one GPU over gloo:", out["value"], "steps/s in total")
+    # every rank's own figure is in the line (a slow rank is visible), and the headline divides by the slowest
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["steps_per_s"]) == 2 and pr["backend"] == "gloo"
+    assert abs(max(pr["ms_per_step"]) - out["ms_per_step"]) < 0.05 * out["ms_per_step"]
+    print("two ranks on one GPU over gloo:", out["value"], "steps/s in total; per rank", pr["steps_per_s"])
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()      # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="the RCCL branch needs two devices (RCCL refuses two ranks on one GPU); runs wherever >= 2 GPUs exist")
+def test_bench_two_ranks_over_rccl_one_rank_per_gpu():
+    """The branch an 8-GPU node runs (round 6): backend "nccl" (= RCCL), one rank per device, init_process_group(device_id),
+    device-side barrier / MAX / all_gather of the timings, the batched section on every rank.  Skipped on a 1-GPU box -- there
+    the same control flow runs over gloo (tests above) and this branch stays unmeasured."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--batch-edits", "2", "--streams", "1", "--no-phases", "--no-res768", "--no-cpu-baseline"],
+                       env=dict(_env(), DH_BENCH_BACKEND="nccl"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["errors"] == [] and out["per_rank"]["backend"] == "nccl"
+    assert len(out["per_rank"]["steps_per_s"]) == 2 and len(out["edits"]["per_rank"]["edits_per_s"]) == 2
+    assert out["edits"]["edits_per_gpu"] == 2 and out["edits"]["edits_per_s"] > 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="the RCCL branch needs two devices")
+def test_sharded_driver_two_ranks_over_rccl(tmp_path):
+    out = str(tmp_path / "rccl")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_edits_sharded.py"), "--edits", "4", "--batch", "2", "--out", out,
+                        "--gpus", "2"], env=dict(_env(), DH_BENCH_BACKEND="nccl"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["edits"] == 4 and rep["n_gpus"] == 2 and rep["edits_per_s"] > 0
 
 
 def test_bench_reports_a_failed_secondary_section_and_exits_non_zero():

@@ -55,7 +55,7 @@ def main():
             g[key + "/corr_sha"] = sha(corr)
             g[key + "/raw_mask_sha"] = sha(np.packbits(dbg["raw_mask"] != 0))
             g[key + "/cleaned_sha"] = sha(np.packbits(dbg["cleaned"] != 0))
-            g[key + "/vis_sha"] = sha(np.packbits(dbg["vis"] != 0))
+            g[key + "/vis_sha"] = sha(np.packbits(dbg["vis"][512 * 512:] != 0))      # the foreground points (the background grid comes first)
             g[key + "/n_corr"] = np.int64(corr.shape[0])
             g[key + "/n_inpaint"] = np.int64(int(dbg["inpaint"].sum()))
             g[key + "/disp_slice"] = disp_r[0, 0].numpy()[::17, ::19].copy()
