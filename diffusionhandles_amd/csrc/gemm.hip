@@ -1412,7 +1412,7 @@ extern "C" int dh_dbg_gemm_family(int force) {
 
 // test hook: 1 = dense / stride-1 3x3 operands of k_gemm_dma stage through buffer descriptors (shipped), 0 = through addresses
 extern "C" int dh_dbg_gemm_stage(int buf) {
-  dh::g_buf_stage = buf;          // bit 0: buffer staging; bit 2 (value 4): NO GroupNorm statistics in the GEMM epilogue (A/B of that fusion)
+  dh::g_buf_stage = buf;          // bit 0: buffer staging; bit 2 (value 4): NO GroupNorm statistics in the GEMM epilogue
   return DH_OK;
 }
 
