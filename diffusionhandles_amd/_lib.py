@@ -113,6 +113,8 @@ c_l = ctypes.c_long
 DEBUG_SIGNATURES = {
     "dh_dbg_gemm": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i,
                           c_p, c_l, c_p, c_l, c_i, c_p, c_sz, c_p]),
+    "dh_dbg_gemm_groupnorm": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_i, c_i, c_p, c_p, c_f, c_i,
+                                    c_p, c_p, c_p, ctypes.POINTER(c_i), c_p]),
     "dh_dbg_gemm_lnfold": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
     "dh_dbg_gemm_glu": (c_i, [c_i, c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dh_dbg_gemm_family": (c_i, [c_i]),

@@ -49,6 +49,36 @@ extern "C" int dh_dbg_gemm(int dtype, const void* A, long lda, const void* W, in
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+// GEMM (dense or 3x3 convolution) followed by the GroupNorm(+SiLU) of its output, the way the engine's forward runs the pair: the
+// GroupNorm's slice statistics come from the GEMM launch when it can leave them (split-K reduce, or -- round 6 -- the epilogue of an
+// unsplit k_gemm_dma launch: gemm.hip gn_epi) and from the statistics kernel otherwise.  *have_out = what the GEMM reported
+// (0 = statistics kernel, 1 = reduce, > 1 = slices left by the epilogue); stats [B * G][2] = (mean, rstd).
+extern "C" int dh_dbg_gemm_groupnorm(int dtype, const void* A, long lda, const void* W, int M, int N, int K, int mode, int Hin, int Win,
+                                     int Cin, const float* bias, void* C, float* partial, size_t partial_elems, int HW, int G,
+                                     const float* gamma, const float* beta, float eps, int silu, void* Y, float* stats, float* scratch,
+                                     int* have_out, void* stream) {
+  DH_REQUIRE(A && W && C && Y && stats && scratch && gamma && beta && K % 64 == 0 && N % 64 == 0 && HW > 0 && M % HW == 0, "bad arguments");
+  void*& tiled = g_dbg_tiled;
+  static size_t cap = 0;
+  const size_t need = (size_t)N * K * 2;
+  if (need > cap) {
+    if (tiled) (void)hipFree(tiled);
+    DH_CHECK_HIP(hipMalloc(&tiled, need));
+    cap = need;
+  }
+  launch_tile_weights(dtype, W, tiled, N, K, (hipStream_t)stream, mode != 0 ? Cin : 0);
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = tiled; g.M = M; g.N = N; g.K = K; g.mode = mode; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
+  g.Hout = Hin; g.Wout = Win; g.stride = 1; g.up = 0; g.bias = bias; g.C = C; g.ldc = N;
+  g.partial = partial; g.partial_elems = partial_elems;
+  int have = 0;
+  g.gn_part = scratch; g.gn_HW = HW; g.gn_G = G; g.gn_done = &have;
+  launch_gemm(dtype, g, (hipStream_t)stream);
+  launch_groupnorm_fwd(dtype, C, gamma, beta, Y, stats, scratch, M / HW, HW, N, G, eps, silu, (hipStream_t)stream, have);
+  if (have_out) *have_out = have;
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
 // the LayerNorm-folded form of the dense GEMM (engine: qkv / cross-attention q / GEGLU in-projection at B <= 3): A is the
 // LayerNorm INPUT, W already carries gamma, ln_s[n] = sum_k W[n][k], ln_t[n] = sum_k beta[k] W0[n][k] (+ bias);
 // out = rstd (A W^T - mean ln_s) + ln_t, and (mean, rstd) per row land in ln_stats

@@ -310,3 +310,52 @@ def test_cross_lane_helpers():
             up = lane + 32
             assert e[lane].tolist() == [4 * lane, 4 * lane + 1, 4 * up, 4 * up + 1]
             assert e[up].tolist() == [4 * lane + 2, 4 * lane + 3, 4 * up + 2, 4 * up + 3]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,HW,N,K,conv,expect", [
+    (1, 4096, 320, 320, False, "epilogue"),      # 128x64 tiles; 10-channel groups straddle the 64-column tiles
+    (1, 4096, 320, 2880, True, "epilogue"),      # the 64^2-level convolution (two K groups inside the workgroup)
+    (2, 1024, 640, 640, False, "epilogue"),      # 64x64 tiles, two images
+    (2, 1024, 256, 1152, True, "epilogue"),      # 8-channel groups (the narrowest the epilogue takes); 18 K tiles: not split
+    (1, 256, 1280, 1280, False, "epilogue"),     # 40-channel groups
+    (1, 1024, 640, 5760, True, "reduce"),        # K split: the reduce kernel leaves the statistics (unchanged path)
+    (1, 4096, 64, 320, False, "kernel"),         # 2-channel groups: the statistics kernel
+])
+def test_gemm_groupnorm_statistics_by_producer(dtype, B, HW, N, K, conv, expect):
+    """GEMM -> GroupNorm(+SiLU) as the engine's forward runs the pair (dh_dbg_gemm_groupnorm): whichever launch leaves the slice
+    statistics -- the unsplit GEMM's own epilogue (round 6: two slices per row tile, groups that straddle column tiles), the split-K
+    reduce, or the statistics kernel -- the published (mean, rstd) equal those of the GEMM's ROUNDED output computed in f64 by torch to
+    1e-5 (mean: of the group's standard deviation; rstd: relative), and the normalised tensor is the GroupNorm of that output."""
+    lib = L().lib()
+    G, M = 32, B * HW
+    H = int(round(HW ** 0.5))
+    g = torch.Generator(device=dev()).manual_seed(N + K + HW)
+    if conv:
+        Cin = K // 9
+        A = torch.randn(M, Cin, generator=g, device=dev()).to(dtype); lda = Cin; mode = 1
+    else:
+        Cin = 0
+        A = torch.randn(M, K, generator=g, device=dev()).to(dtype); lda = K; mode = 0
+    W = (torch.randn(N, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+    bias = torch.randn(N, generator=g, device=dev()) * 3.0             # a DC offset per channel: the unshifted sums must survive it
+    gamma = torch.randn(N, generator=g, device=dev()); beta = torch.randn(N, generator=g, device=dev())
+    C = torch.empty(M, N, dtype=dtype, device=dev()); Y = torch.empty_like(C)
+    stats = torch.zeros(B * G, 2, device=dev()); scratch = torch.zeros(1 << 20, device=dev())
+    part = torch.empty(16 << 20, dtype=torch.float32, device=dev())
+    have = ctypes.c_int(-1)
+    L().check(lib.dh_dbg_gemm_groupnorm(DT[dtype], P(A), lda, P(W), M, N, K, mode, H, H, Cin, P(bias), P(C), P(part), part.numel(), HW, G,
+                                        P(gamma), P(beta), 1e-5, 1, P(Y), P(stats), P(scratch), ctypes.byref(have), L().stream_ptr()),
+              "dh_dbg_gemm_groupnorm")
+    torch.cuda.synchronize()
+    assert {"epilogue": have.value > 1, "reduce": have.value == 1, "kernel": have.value == 0}[expect], (expect, have.value)
+    x = C.double().view(B, HW, G, N // G)
+    mean = x.mean(dim=(1, 3)); var = x.var(dim=(1, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    got = stats.double().view(B, G, 2)
+    em = float(((got[..., 0] - mean).abs() / var.sqrt()).max()); er = float(((got[..., 1] - rstd).abs() / rstd).max())
+    print(f"{expect}: slices {have.value}, mean err / sigma {em:.2e}, rstd rel err {er:.2e}")
+    assert em < 1e-5 and er < 1e-5, (em, er)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(C.float().view(B, HW, N).permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1)
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    close(Y.view(B, HW, N), ref, tol, tol, "GroupNorm of the GEMM output")
