@@ -153,3 +153,34 @@ def test_hand_placed_vmcnt_waits_cover_their_loads():
             n += 1
             assert check_vmcnt.check(name, body) == [], name
     assert n >= 40
+
+
+def test_m0_belongs_to_the_lds_dma_statements_only():
+    """The descriptor-addressed LDS-DMA of k_gemm_pp (round 5) and of the BUF instantiations of k_gemm_dma (round 6) writes M0 from
+    inline asm WITHOUT saving it and without an "m0" clobber: correct only while nothing else in those kernels touches M0 (LDS
+    instructions need none on gfx9+).  Audit of the disassembly (no GPU): in every such kernel M0 appears in `s_mov_b32 m0, ...`
+    (the DMA statements' own writes; the address form's save / restore pairs) and nowhere else -- no s_movrel*, no v_readlane /
+    v_writelane / v_interp / ds_gws / s_sendmsg operand, no read of M0 into a general register in the BUF kernels."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    import check_vmcnt
+    lib = os.path.join(ROOT, "diffusionhandles_amd", "libdiffhandles_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(check_isa.LLVM, "llvm-objdump")):
+        pytest.skip("library or llvm-objdump not present")
+    n_buf = n_pp = 0
+    for name, body in check_vmcnt.kernels_disassembly(lib):
+        is_pp = "k_gemm_pp" in name
+        is_buf = "k_gemm_dma" in name and name.endswith("ELb1EEEvNS_5GemmKE")          # the last template argument: BUF = true
+        if not (is_pp or is_buf):
+            continue
+        n_pp += is_pp
+        n_buf += is_buf
+        dma = [ln for ln in body if re.search(r"buffer_load_dwordx4 .* lds$", ln)]
+        assert dma, name
+        for ln in body:
+            if not re.search(r"\bm0\b", ln):
+                continue
+            assert re.match(r"s_mov_b32 m0, (s\d+|0x[0-9a-f]+|\d+)$", ln), (name, ln)
+    assert n_buf >= 60 and n_pp >= 20, (n_buf, n_pp)
