@@ -96,6 +96,7 @@ def test_sharded_driver_two_ranks_write_the_one_rank_images(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         rep = json.loads(r.stdout.strip().splitlines()[-1])
         assert rep["edits"] == 4 and rep["n_gpus"] == gpus and rep["batch"] == 2 and rep["edits_per_s"] > 0
+        assert rep["per_rank"]["edits"] == [4 // gpus] * gpus and len(rep["per_rank"]["edits_s"]) == gpus      # every rank's share and time
         outs[gpus] = out
     for i in range(4):
         for suffix in ("", "_disparity"):

@@ -140,12 +140,20 @@ def main():
     # ---- the edits: this rank's share, `batch` at a time ------------------------------------------------------------
     t0 = time.perf_counter()
     local = parallel.run_edits(dh, identity, edits, depth, mask, bg_depth, prompt, batch=args.batch, streams=args.streams)
+    torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0                  # this rank's own share, before it waits for the others
     barrier()
     t_edits = time.perf_counter() - t0
+    per_rank = [t_own]
     if world > 1:
-        tt = torch.tensor([t_edits], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        wire = dev if backend == "nccl" else "cpu"
+        tt = torch.tensor([t_edits], dtype=torch.float64, device=wire)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_edits = float(tt.item())
+        mine = torch.tensor([t_own], dtype=torch.float64, device=wire)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        per_rank = [float(g.item()) for g in got]
     results = parallel.gather_results([(gi, None if args.no_images else im, None if args.no_images else dp) for gi, im, dp in local])
     if rank == 0:
         os.makedirs(args.out, exist_ok=True)
@@ -159,6 +167,9 @@ def main():
                "resolution": args.res, "identity_s": round(t_identity, 3), "identity": ("inversion + " if args.invert else "") +
                "initial inference on " + ("every rank" if args.recompute_identity else "rank 0, broadcast"),
                "edits_s": round(t_edits, 3), "edits_per_s": round(len(edits) / t_edits, 4),
+               "per_rank": {"edits": [len(parallel.shard_edits(list(range(len(edits))), r, world)) for r in range(world)],
+                            "edits_s": [round(v, 3) for v in per_rank],
+                            "what": "each rank's share and its own wall time for it (rank order); edits_per_s divides by the MAX incl. the barrier"},
                "edits_per_s_with_identity": round(len(edits) / (t_edits + t_identity), 4)}
         with open(os.path.join(args.out, "report.json"), "w") as f:
             json.dump(rep, f, indent=1)
