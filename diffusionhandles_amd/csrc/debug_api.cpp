@@ -58,7 +58,7 @@ extern "C" int dh_dbg_gemm_groupnorm(int dtype, const void* A, long lda, const v
                                      const float* gamma, const float* beta, float eps, int silu, void* Y, float* stats, float* scratch,
                                      int* have_out, void* stream) {
   DH_REQUIRE(A && W && C && Y && stats && scratch && gamma && beta && K % 64 == 0 && N % 64 == 0 && HW > 0 && M % HW == 0, "bad arguments");
-  void*& tiled = g_dbg_tiled;
+  static void* tiled = nullptr;        // (this hook's own tiled copy: dh_dbg_gemm keeps the capacity of ITS buffer)
   static size_t cap = 0;
   const size_t need = (size_t)N * K * 2;
   if (need > cap) {

@@ -178,6 +178,44 @@ def test_guided_step_batch8_full_size_matches_single_steps(full):
     print(f"K = 8 full-size batched step vs eight single steps: worst post-step latent rel-L2 {worst:.3e} (gate 5e-3)")
 
 
+def test_guided_step_batch_full_size_matches_oracle(full):
+    """BASELINE config 3 against the ORACLE (round 6; the K = 8 test above compares the batched path with eight single steps): two
+    edits of one image as ONE batched guided step (B = 2 optimisation passes, B = 4 CFG pass) for t_idx 0 and 1 against
+    oracle.loop_ref.guided_inference run once per edit on UNetTorch(SD2_DEPTH) fp32 -- distinct latents and transforms per edit,
+    teacher-forced from the oracle's latents; the gates of the single-edit loop test (5e-3 / 6e-2 / 0.2)."""
+    from diffusionhandles_amd.depth_transform import reproject_edits
+    from oracle import loop_ref as L
+    r = full
+    gd = r.gd
+    if not hasattr(r, "acts"):
+        r.acts = _orig_activations(r, 50)
+    K = 2
+    Y = torch.tensor([0.0, 1.0, 0.0])
+    tfs = [(TRANSFORMS[i][0], Y, torch.tensor(TRANSFORMS[i][1])) for i in (2, 5)]
+    worst = dict(step=0.0, upd=0.0)
+    with torch.no_grad(), gd.on_stream():
+        gd.scheduler.set_timesteps(50)
+        ts = gd.scheduler.timesteps
+        edits = reproject_edits(r.depth.to(dev()), r.bg.to(dev()), r.mask.to(dev()), gd.get_depth_intrinsics(), tfs)
+        sts = [gd.prepare_guidance(d, r.prompt, r.acts, c) for d, c in edits]
+        g = torch.Generator(device=dev()).manual_seed(91)
+        x_in = [(r.noise + 0.05 * torch.randn(1, 4, 64, 64, generator=g, device=dev())) for _ in range(K)]
+        for i in (0, 1):
+            recs = []
+            for e in range(K):
+                rec_o = {}
+                L.guided_inference(r.ref, L.DDIM(), x_in[e], edits[e][0], r.unc, r.cond, r.acts, edits[e][1].numpy(), r.conf, record=rec_o, steps=[i])
+                recs.append(rec_o)
+            xb = torch.cat([x.permute(0, 2, 3, 1) for x in x_in]).contiguous()
+            out = gd.guided_step_batch(sts, xb, i, ts[i], r.unc[i]).clone()
+            for e in range(K):
+                es = rel(out[e:e + 1].permute(0, 3, 1, 2), recs[e]["step"][0])
+                worst["step"] = max(worst["step"], es)
+                assert es < 5e-3, f"t_idx {i}, edit {e}: latent after the batched step rel-L2 {es:.3e} >= gate 5e-3"
+                x_in[e] = recs[e]["step"][0]
+    print(f"K = 2 full-size batched guided step vs the oracle, per edit: worst latent-after-step rel-L2 {worst['step']:.3e} (gate 5e-3)")
+
+
 def test_guided_step_768_full_size_bf16_matches_oracle():
     """BASELINE config 5 at its real size: one guided-denoise step at 768 x 768 on HipUNet(SD2_DEPTH at 96 x 96 latents) in bf16
     (fp32 guidance energy / backward seed) against the oracle on UNetTorch of the same configuration in fp32: the first latent
