@@ -184,3 +184,35 @@ def test_m0_belongs_to_the_lds_dma_statements_only():
                 continue
             assert re.match(r"s_mov_b32 m0, (s\d+|0x[0-9a-f]+|\d+)$", ln), (name, ln)
     assert n_buf >= 60 and n_pp >= 20, (n_buf, n_pp)
+
+
+def test_gemm_main_loops_carry_only_lds_dma_on_the_vector_memory_queue():
+    """k_gemm_dma waits for its LDS-DMA tiles with hand-COUNTED `s_waitcnt vmcnt(N)` (pieces per stage).  A count is only right while
+    nothing else sits in the wave's in-order vector-memory queue inside the K loop -- a compiler-generated spill, a hoisted or sunk
+    global access would make the wait too lax and stale LDS tiles would be multiplied without any fault.  Audit of the disassembly
+    (no GPU): between the first and the last MFMA of every k_gemm_dma kernel (the K loop, however it is unrolled) the only
+    vector-memory instructions are the LDS-DMA ones (`global_load_lds_dwordx4`, `buffer_load_dwordx4 ... lds`); no scratch access
+    anywhere in the k_gemm_dma / k_gemm_pp kernels."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    import check_vmcnt
+    lib = os.path.join(ROOT, "diffusionhandles_amd", "libdiffhandles_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(check_isa.LLVM, "llvm-objdump")):
+        pytest.skip("library or llvm-objdump not present")
+    n = 0
+    for name, body in check_vmcnt.kernels_disassembly(lib):
+        if "k_gemm_dma" in name or "k_gemm_pp" in name:
+            assert not any(ln.startswith("scratch_") for ln in body), name
+        if "k_gemm_dma" not in name:      # (k_gemm_pp's persistent tile loop puts its residual prefetch between copies of the K loop in
+            continue                      #  address order: a range check cannot tell them apart; its registers are covered by check_vmcnt above)
+        mf = [i for i, ln in enumerate(body) if ln.startswith("v_mfma")]
+        assert mf, name
+        for ln in body[mf[0]:mf[-1] + 1]:
+            op = ln.split()[0]
+            if op.startswith(check_vmcnt.VMEM):
+                is_dma = op == "global_load_lds_dwordx4" or (op == "buffer_load_dwordx4" and ln.rstrip().endswith(" lds"))
+                assert is_dma, (name, ln)
+        n += 1
+    assert n >= 120, n
