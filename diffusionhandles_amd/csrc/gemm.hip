@@ -15,6 +15,9 @@
 // output row m and 4 consecutive n per accumulator group: 8-byte stores, per-lane row
 // scalars.  f32 accumulate; optional split-K through f32 partial slabs + a reduce kernel
 // that applies the same epilogue (and, when a GroupNorm follows, leaves its slice statistics).
+// Round 6: the LDS-DMA of the dense and stride-1 3x3 forms goes through buffer descriptors (BUF instantiations: scalar K cursor /
+// tap offset, hardware zero fill; bit-identical to the address form, tools/fuzz_gemm_stage.py), and an UNSPLIT launch whose output a
+// GroupNorm consumes leaves that GroupNorm's slice statistics from its own epilogue (gn_epi).
 #include <stdlib.h>
 
 #include <vector>

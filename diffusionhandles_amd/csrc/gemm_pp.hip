@@ -697,6 +697,19 @@ static size_t pp_a_bytes(const GemmK& k) {
   return B * k.Hin * k.Win * (size_t)k.lda * 2;
 }
 
+// Compute units of the current device (cached): the persistent grid has one workgroup per CU and the policy asks for 7/8 of a
+// round of tiles.  256 on an MI355X in SPX mode (what every measurement of this file was taken on) and the fallback without a device
+// (dh_dbg_gemm_pp_plan on the CPU); a partitioned (CPX) or smaller device gets its own count instead of a mistuned 256.
+static int pp_device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) cus = n - n % 8;
+    else { (void)hipGetLastError(); cus = 256; }
+  }
+  return cus;
+}
+
 static int g_pp_glu = -1;                           // dh_dbg_gemm_pp_glu: the GEGLU-epilogue launches (-1 policy, 0 never, 1 always)
 bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan) {
   if (force == 1) return false;
@@ -732,15 +745,16 @@ bool gemm_pp_plan(const GemmK& k, size_t partial_elems, int force, PpPlan* plan)
   const int tn = k.N / bn;
   const long t256 = (long)cdiv(k.M, 256) * tn, t128 = (long)cdiv(k.M, 128) * tn;
   int bm = 0, splits = 1;
-  if (t256 >= 224) bm = 256;                                 // one round or more of 256-row tiles
-  else if (t128 >= 224) bm = 128;                            // (M = 8192, N = 640 at batch 8: 64 x 4)
+  const int cus = pp_device_cus(), fill = cus - cus / 8;      // 256 / 224 on the MI355X
+  if (t256 >= fill) bm = 256;                                // one round or more of 256-row tiles
+  else if (t128 >= fill) bm = 128;                           // (M = 8192, N = 640 at batch 8: 64 x 4)
   else if (!glu && k.partial && ktiles >= 64 && t256 >= 64 && k.M >= 1024 && k.M <= 4096) {
     // long K loops on fewer tiles than CUs: split K over workgroups (f32 slabs + the reduce kernels of gemm.hip).  Measured for
     // the 16x16-latent level at batch 8 (M = 2048, N = 1280, K = 11520: 64 tiles x 4 splits, 74.7 -> 65.0 us); the B = 1 / B = 2
     // shapes of this kind stay on k_gemm_dma's tiles.  From 64 K tiles on: the B = 1 input gradients with K = 2880 (45 tiles, M = 4096,
     // N = 640 / 960) lose 7 - 18 % here, K = 5760 wins 3 - 4 % (profiles/r05_ab_pp_splitk_branch.txt)
     bm = 256;
-    splits = (int)(256 / t256);
+    splits = (int)(cus / t256);
     if (splits > ktiles / 8) splits = ktiles / 8;
     if (splits > 8) splits = 8;
     const size_t fit = partial_elems / ((size_t)k.M * k.N);
@@ -834,7 +848,7 @@ void launch_gemm_pp(int dtype, const GemmK& kin, const PpPlan& plan, hipStream_t
   k.pp_order = (row_fastest < col_fastest ? 1 : 0) | g_pp_ablate;
   k.pp_nwork = k.pp_tm * k.pp_tn * k.splits;
   // persistent grid: one workgroup per CU (256: a multiple of 8, the XCD order of the work items holds in every round)
-  int slots = 256;
+  int slots = pp_device_cus();
   if (g_pp_persist == 0 || k.pp_nwork <= slots) slots = k.pp_nwork;
   dim3 grid((unsigned)slots);
   const int mode = pp_mode(k);
