@@ -115,6 +115,9 @@ DEBUG_SIGNATURES = {
                           c_p, c_l, c_p, c_l, c_i, c_p, c_sz, c_p]),
     "dh_dbg_gemm_groupnorm": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_i, c_i, c_p, c_p, c_f, c_i,
                                     c_p, c_p, c_p, ctypes.POINTER(c_i), c_p]),
+    # (dtype, A, lda, W, M, N, K, mode, Hin, Win, Cin, C, partial, partial_elems, HW, G, x, gamma, beta, stats, silu, dx, scratch, have_out, stream)
+    "dh_dbg_gemm_groupnorm_bwd": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_p, c_p, c_p, c_p, c_i,
+                                        c_p, c_p, ctypes.POINTER(c_i), c_p]),
     "dh_dbg_gemm_lnfold": (c_i, [c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
     "dh_dbg_gemm_glu": (c_i, [c_i, c_i, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dh_dbg_gemm_family": (c_i, [c_i]),

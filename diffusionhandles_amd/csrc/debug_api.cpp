@@ -79,6 +79,36 @@ extern "C" int dh_dbg_gemm_groupnorm(int dtype, const void* A, long lda, const v
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+// ... and the backward twin: C = A W^T is dy of GroupNorm(x) (+ SiLU) with saved (mean, rstd) in `stats`; the GEMM (its split-K
+// reduce, or its own epilogue: *have_out > 1 = that many slices per group) leaves the backward slice statistics in `scratch` and
+// the GroupNorm backward writes dx.  (engine: every input-gradient GEMM in front of a GroupNorm backward)
+extern "C" int dh_dbg_gemm_groupnorm_bwd(int dtype, const void* A, long lda, const void* W, int M, int N, int K, int mode, int Hin,
+                                         int Win, int Cin, void* C, float* partial, size_t partial_elems, int HW, int G, const void* x,
+                                         const float* gamma, const float* beta, const float* stats, int silu, void* dx,
+                                         float* scratch, int* have_out, void* stream) {
+  DH_REQUIRE(A && W && C && x && dx && stats && scratch && gamma && beta && K % 64 == 0 && N % 64 == 0 && HW > 0 && M % HW == 0, "bad arguments");
+  static void* tiled = nullptr;
+  static size_t cap = 0;
+  const size_t need = (size_t)N * K * 2;
+  if (need > cap) {
+    if (tiled) (void)hipFree(tiled);
+    DH_CHECK_HIP(hipMalloc(&tiled, need));
+    cap = need;
+  }
+  launch_tile_weights(dtype, W, tiled, N, K, (hipStream_t)stream, mode != 0 ? Cin : 0);
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = tiled; g.M = M; g.N = N; g.K = K; g.mode = mode; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
+  g.Hout = Hin; g.Wout = Win; g.stride = 1; g.up = 0; g.C = C; g.ldc = N;
+  g.partial = partial; g.partial_elems = partial_elems;
+  int have = 0;
+  g.gnb_x = x; g.gnb_ldx = N; g.gnb_gamma = gamma; g.gnb_beta = beta; g.gnb_stats = stats; g.gnb_silu = silu;
+  g.gn_part = scratch; g.gn_HW = HW; g.gn_G = G; g.gn_done = &have;
+  launch_gemm(dtype, g, (hipStream_t)stream);
+  launch_groupnorm_bwd(dtype, x, C, gamma, beta, stats, dx, scratch, M / HW, HW, N, G, silu, 0, (hipStream_t)stream, have, GnBwdSplit());
+  if (have_out) *have_out = have;
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
 // the LayerNorm-folded form of the dense GEMM (engine: qkv / cross-attention q / GEGLU in-projection at B <= 3): A is the
 // LayerNorm INPUT, W already carries gamma, ln_s[n] = sum_k W[n][k], ln_t[n] = sum_k beta[k] W0[n][k] (+ bias);
 // out = rstd (A W^T - mean ln_s) + ln_t, and (mean, rstd) per row land in ln_stats

@@ -475,8 +475,23 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         ltp[PRE_LN ? j : 0][g] = n < p.N ? *reinterpret_cast<const float4*>(p.ln_t + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
+  // GroupNorm BACKWARD statistics in the epilogue (p.gn_epi == 2, round 6; see the epilogue): the tile is dy of a GroupNorm whose
+  // input tile x rides under the K loop in the residual's prefetch registers (the dispatch takes the form only when there is no
+  // residual), and thread n of the first wave fetches (gamma, beta, mean, rstd) of tile column n for the table the epilogue
+  // builds in LDS -- four registers across the loop instead of 64
+  constexpr bool GNB = WNS == 2 && GLU == 0 && BN == 64 && WG == 1 && PRE && !LNF;
+  const bool gnb = GNB && p.gn_epi == 2 && p.splits == 1;
+  const bool pre_x = gnb && (KG == 1 || kg == 0);
+  float4 gnb_col = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (GNB && pre_x && tid < BN) {
+    const int n = n0 + tid, grp_n = (int)(((float)n + 0.5f) / (float)p.gn_cpg);
+    const float2 st2 = *reinterpret_cast<const float2*>(p.gnb_stats + 2 * ((m0 / p.gn_HW) * p.gn_G + grp_n));
+    gnb_col = make_float4(p.gnb_gamma[n], p.gnb_beta[n], st2.x, st2.y);
+  }
   uint2 rpre[TM][TN][4];
-  if (pre_r) {
+  if (pre_r || pre_x) {
+    const T* rsrc = reinterpret_cast<const T*>(pre_x ? p.gnb_x : p.R);
+    const long rld = pre_x ? p.gnb_ldx : p.ldr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * RPW + i * 32 + ln;
@@ -485,9 +500,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + wn * CPW + j * 32 + 8 * g + 4 * hi;
-          rpre[i][j][g] = (m < p.M && n < p.N)
-                              ? *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(p.R) + (size_t)m * p.ldr + n)
-                              : make_uint2(0, 0);
+          rpre[i][j][g] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(rsrc + (size_t)m * rld + n) : make_uint2(0, 0);
         }
     }
   }
@@ -785,10 +798,39 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
       for (int c = 0; c < 4; ++c) { const float v = to_f32<T>(ov[c]); gsa[j][4 * g + c] += v; gsq[j][4 * g + c] += v * v; }
     }
   };
+  // BACKWARD flavour (gnb): the tile is dy of the GroupNorm (+ SiLU) whose input tile sits in rpre; the per-element terms are
+  // k_gn_partial<bwd>'s -- d = dy * gamma * act'(xhat gamma + beta), the sums of d and d * xhat -- and the slices carry the plain
+  // sums ([b][g][S][2], what k_gn_bwd_apply adds up).  The per-column constants come from a 64-entry table in LDS.
+  const float4* gnb_tab = reinterpret_cast<const float4*>(smem_all + KG * ST * STAGE - 2048) + wn * CPW + 4 * hi;
+  if constexpr (GNB) {
+    if (gnb) {
+      float4* tab = reinterpret_cast<float4*>(smem_all + KG * ST * STAGE - 2048);
+      __syncthreads();                               // every wave is done with the rings / the merge buffers
+      if (tid < BN) tab[tid] = gnb_col;
+      __syncthreads();
+    }
+  }
+  // (the four table entries of a chunk are read where they are used, once per row block: all sixteen of a lane held across the
+  //  epilogue were 64 more registers, which took the 74-KB 128x64 tile from two workgroups per CU to one)
+  auto gnb_acc = [&](int g, uint2 packed, uint2 xraw) {
+    if constexpr (GNB) {
+      typedef T T4g __attribute__((ext_vector_type(4)));
+      const T4g ov = __builtin_bit_cast(T4g, packed), xv = __builtin_bit_cast(T4g, xraw);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = gnb_tab[8 * g + c];
+        const float xh = (to_f32<T>(xv[c]) - t.z) * t.w;
+        float d = to_f32<T>(ov[c]);
+        if (p.gnb_silu) d *= silu_grad(xh * t.x + t.y);
+        d *= t.x;
+        gsa[0][4 * g + c] += d; gsq[0][4 * g + c] += d * xh;
+      }
+    }
+  };
   auto gn_finish = [&]() {
     if constexpr (GNE) {
       constexpr int CS_BYTES = WMS * BN * 2 * 4;
-      static_assert(CS_BYTES <= 4096 && KG * ST * STAGE >= 8192, "column-sum scratch lives in the last 4 KiB of the ring");
+      static_assert(CS_BYTES <= (GNB ? 2048 : 4096) && KG * ST * STAGE >= 8192, "column-sum scratch lives in the last 4 KiB of the ring (the backward table in its upper half)");
       float* cs = reinterpret_cast<float*>(smem_all + KG * ST * STAGE - 4096);
       __syncthreads();                               // every wave is done with the rings / the merge buffers
 #pragma unroll
@@ -821,10 +863,16 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
         if (sub == 0) {
           const int b = m0 / p.gn_HW, rt = (m0 - b * p.gn_HW) / BM;
           const int part = lo < n0 ? 1 : 0;
-          const float n = (float)BM * (float)(c_hi - c_lo);
-          float* o = p.gn_part + ((size_t)(b * G + g) * 3) * Sx + 2 * rt + part;
-          o[0] = n; o[Sx] = a / n; o[2 * Sx] = q - a * a / n;
-          if (part == 0 && hi_c <= n0 + BN) { o[1] = 0.f; o[Sx + 1] = 0.f; o[2 * Sx + 1] = 0.f; }      // the whole group lies in this tile
+          if (GNB && gnb) {
+            float2* o = reinterpret_cast<float2*>(p.gn_part) + (size_t)(b * G + g) * Sx + 2 * rt + part;
+            o[0] = make_float2(a, q);
+            if (part == 0 && hi_c <= n0 + BN) o[1] = make_float2(0.f, 0.f);
+          } else {
+            const float n = (float)BM * (float)(c_hi - c_lo);
+            float* o = p.gn_part + ((size_t)(b * G + g) * 3) * Sx + 2 * rt + part;
+            o[0] = n; o[Sx] = a / n; o[2 * Sx] = q - a * a / n;
+            if (part == 0 && hi_c <= n0 + BN) { o[1] = 0.f; o[Sx + 1] = 0.f; o[2 * Sx + 1] = 0.f; }      // the whole group lies in this tile
+          }
         }
       }
     }
@@ -860,12 +908,13 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
           T4 o;
           o[0] = from_f32<T>(v0); o[1] = from_f32<T>(v1); o[2] = from_f32<T>(v2); o[3] = from_f32<T>(v3);
           w[g] = __builtin_bit_cast(uint2, o);
-          if (gn_epi) gn_acc(j, g, w[g]);
+          if (gn_epi) { if (GNB && gnb) gnb_acc(g, w[g], rpre[i][j][g]); else gn_acc(j, g, w[g]); }
         }
         const uint4 ca = half_exchange(w[0], w[1]), cb = half_exchange(w[2], w[3]);
         *reinterpret_cast<uint4*>(orow + j * 32) = ca;
         *reinterpret_cast<uint4*>(orow + j * 32 + 16) = cb;
       }
+      if (GNB && gnb) asm volatile("" ::: "memory");      // the next row block re-reads its table entries
     }
     if (gn_epi) gn_finish();
     DH_STAMP(6);
@@ -1260,6 +1309,15 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
     const int cpg = k.N / k.gn_G, sx = 2 * (k.gn_HW / BM);
     if (cpg >= 8 && cpg <= BN && sx <= 64) { k.gn_epi = 1; k.gn_cpg = cpg; k.gn_S = sx; }
   }
+  // ... and the BACKWARD slice statistics (sum d, sum d * xhat) when the output is dy of a GroupNorm: 64-column tiles of up to 128
+  // rows, no bias / residual / per-image vector (an input-gradient GEMM has none; the residual's prefetch registers carry the
+  // GroupNorm's input tile).  *gn_done = the slice count, as above.
+  if ((g_buf_stage & 8) == 0 && splits == 1 && !use_pp && !glu && !lnf && k.gn_part && k.gnb_x && gn_done && k.gn_G > 0 && k.gn_HW > 0 && k.C &&
+      k.wide_store && k.pre_r && !k.R && !k.bias && !k.rowvec && !k.act_silu && k.M % k.gn_HW == 0 && k.gn_HW % BM == 0 && k.N % k.gn_G == 0 &&
+      k.N % BN == 0 && BN == 64 && BM <= 128 && (((size_t)k.gnb_x | (size_t)(k.gnb_ldx * 2)) & 7) == 0) {
+    const int cpg = k.N / k.gn_G, sx = 2 * (k.gn_HW / BM);
+    if (cpg >= 8 && cpg <= BN && sx <= 64) { k.gn_epi = 2; k.gn_cpg = cpg; k.gn_S = sx; }
+  }
 #ifdef DH_TUNING
   k.w_nt = kWnt > 0 && tm <= kWnt;
   static const int kLnfAbl = getenv("DH_LNF_ABL") ? atoi(getenv("DH_LNF_ABL")) : 0;
@@ -1289,6 +1347,7 @@ static void gemm_dispatch(GemmK k, size_t partial_elems, hipStream_t st, int* gn
     double c_elems = (double)k.M * k.N * (k.C ? 1.0 : 0.0) + (k.R ? (double)k.M * k.N : 0.0);
     if (k.glu_y) c_elems += 0.5 * (double)k.M * k.N;
     if (k.glub_x) c_elems += 4.0 * (double)k.M * k.N;      // saved pre-activations read [M][2N], their gradient written [M][2N]
+    if (k.gn_epi == 2) c_elems += (double)k.M * k.N;       // the GroupNorm input tile the backward statistics read
     g_prof.bytes += esz * (a_elems + (double)k.N * k.K + c_elems);
     g_prof.e0 = e0; g_prof.e1 = e1;
   }
@@ -1415,7 +1474,7 @@ extern "C" int dh_dbg_gemm_family(int force) {
 
 // test hook: 1 = dense / stride-1 3x3 operands of k_gemm_dma stage through buffer descriptors (shipped), 0 = through addresses
 extern "C" int dh_dbg_gemm_stage(int buf) {
-  dh::g_buf_stage = buf;          // bit 0: buffer staging; bit 2 (value 4): NO GroupNorm statistics in the GEMM epilogue
+  dh::g_buf_stage = buf;          // bit 0: buffer staging; bit 2 (value 4): NO GroupNorm forward statistics in the GEMM epilogue; bit 3 (8): NO backward ones
   return DH_OK;
 }
 

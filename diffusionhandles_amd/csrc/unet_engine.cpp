@@ -1146,6 +1146,19 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
             g.lnb_done = &lnb_have;
             lnb_for = oi - 1;
           }
+          if (oi > 0 && u->ops[oi - 1].type == OP_GN && u->ops[oi - 1].out == o.in0 && !u->gready[o.in0] && o.in_col == 0 &&
+              w.K == ti.C) {
+            // ... or dy of the GroupNorm processed next (a transformer's norm in front of proj_in): the split-K reduce or the
+            // GEMM's own epilogue leaves that GroupNorm's backward slice statistics, as for the convolutions below
+            const Op& gn = u->ops[oi - 1];
+            const Ten& tx = u->tens[gn.in0];
+            g.gnb_x = u->aptr(gn.in0); g.gnb_ldx = tx.C;
+            g.gnb_gamma = u->pf + gn.gamma_off; g.gnb_beta = u->pf + gn.beta_off; g.gnb_stats = u->f32a + gn.stats_off;
+            g.gnb_silu = gn.silu;
+            g.gn_part = u->small; g.gn_HW = tx.rows; g.gn_G = gn.groups; g.gn_done = &gnb_have;
+            gnb_have = 0;
+            gnb_for = oi - 1;
+          }
           if (o.glub_op >= 0 && o.glub_op == oi - 1 && !u->gready[o.in0] && o.in_col == 0 && w.K == ti.C) {
             // the gradient being written is dy of the GEGLU processed next and this GEMM is its only consumer: the epilogue
             // applies the GEGLU backward to its tile and writes the gradient of the pre-activations (dy never goes to memory)
@@ -1208,7 +1221,7 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
         }
         launch_groupnorm_bwd(dt, u->aptr(o.in0), u->gptr(o.out), u->pf + o.gamma_off, u->pf + o.beta_off,
                              u->f32a + o.stats_off, u->gptr(o.in0), u->small, B, t.rows, t.C, o.groups, o.silu,
-                             u->gready[o.in0] ? 1 : 0, st, gnb_have && gnb_for == oi, split);
+                             u->gready[o.in0] ? 1 : 0, st, gnb_for == oi ? gnb_have : 0, split);
         gnb_have = 0;
         u->gready[o.in0] = 1;
         if (split.out0) { u->gready[u->ops[oi - 1].in0] = 1; u->gready[u->ops[oi - 1].in1] = 1; }

@@ -501,7 +501,8 @@ void launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const float*
                           const float* stats, void* dx, float* scratch, int B, int HW, int C, int G, int silu,
                           int accumulate, hipStream_t st, int have_partials, GnBwdSplit split) {
   DH_ABLATE(2);
-  const int S = gn_slices(HW, B);
+  // have_partials > 1: the slices were left by a GEMM epilogue, that many per (image, group) (gemm.hip gn_epi == 2)
+  const int S = have_partials > 1 ? have_partials : gn_slices(HW, B);
   const size_t blocks0 = ((size_t)HW * (C / 8) + 255) / 256;
   const int iters = gn_apply_iters(blocks0 * B);
   dim3 g1(S, cdiv(G, GN_GB), B), g2((unsigned)((blocks0 + iters - 1) / iters), B);

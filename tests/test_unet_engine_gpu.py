@@ -249,8 +249,9 @@ def test_forward_only_layout_is_bit_identical_and_smaller(cfg_name):
 def test_groupnorm_statistics_from_the_gemm_epilogue_match_the_statistics_kernel():
     """Round 6: an UNSPLIT k_gemm_dma launch whose output a GroupNorm consumes leaves that GroupNorm's slice statistics from its own
     epilogue (gemm.hip gn_epi: two "slices" per row tile, groups that straddle two 64-column tiles) instead of a k_gn_partial launch.
-    Two engines on the same weights, one captured with the fusion (the shipped path), one with dh_dbg_gemm_stage(1 | 4) = statistics
-    kernel as in round 5: a network whose groups are 8 / 16 channels wide (the fusion needs >= 8; the TINY net's 2-channel groups never
+    The input-gradient GEMMs in front of a GroupNorm backward do the same for the BACKWARD statistics (gn_epi == 2, stage bit 3).
+    Two engines on the same weights, one captured with both fusions (the shipped path), one with dh_dbg_gemm_stage(1 | 4 | 8) = statistics
+    kernels as in round 5: a network whose groups are 8 / 16 channels wide (the fusion needs >= 8; the TINY net's 2-channel groups never
     take it) and whose GEMMs at the 32 x 32 / 16 x 16 levels are short enough not to split K.  The two differ by the f32 summation order
     of the statistics only (see the comment at the asserts for what can be asserted about two fp16 runs)."""
     from diffusionhandles_amd import _lib
@@ -270,7 +271,7 @@ def test_groupnorm_statistics_from_the_gemm_epilogue_match_the_statistics_kernel
     d_act = [None, None, (torch.randn(B, 32, 32, 256, generator=g, device=dev()) * 0.05).half()]
     outs = {}
     try:
-        for name, stage in (("epilogue", 1), ("kernel", 1 | 4)):
+        for name, stage in (("epilogue", 1), ("kernel", 1 | 4 | 8)):
             _lib.check(lib.dh_dbg_gemm_stage(stage), "dh_dbg_gemm_stage")
             hip = HipUNet(dict(cfg, text_len=77), dtype=torch.float16, max_batch=B)
             hip.load_state_dict(ref.state_dict())

@@ -359,3 +359,68 @@ def test_gemm_groupnorm_statistics_by_producer(dtype, B, HW, N, K, conv, expect)
     ref = torch.nn.functional.silu(torch.nn.functional.group_norm(C.float().view(B, HW, N).permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1)
     tol = 4e-3 if dtype == torch.float16 else 2.5e-2
     close(Y.view(B, HW, N), ref, tol, tol, "GroupNorm of the GEMM output")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,HW,N,K,conv,silu,expect", [
+    (1, 4096, 320, 320, False, 0, "epilogue"),      # a transformer's norm in front of proj_in: dense, no activation, 128x64 tiles
+    (1, 4096, 320, 2880, True, 1, "epilogue"),      # the 64^2-level input-gradient convolution (two K groups inside the workgroup)
+    (2, 1024, 640, 640, False, 1, "epilogue"),      # 64x64 tiles, two images
+    (2, 1024, 256, 1152, True, 1, "epilogue"),      # 8-channel groups (the narrowest the epilogue takes)
+    (1, 256, 1280, 1280, False, 0, "epilogue"),     # 40-channel groups
+    (1, 1024, 640, 5760, True, 1, "reduce"),        # K split: the reduce kernel leaves the statistics (unchanged path)
+    (1, 4096, 64, 320, False, 1, "kernel"),         # 2-channel groups: the statistics kernel
+])
+def test_gemm_groupnorm_backward_statistics_by_producer(dtype, B, HW, N, K, conv, silu, expect):
+    """input-gradient GEMM -> GroupNorm(+SiLU) backward as the engine's backward pass runs the pair (dh_dbg_gemm_groupnorm_bwd): the GEMM's
+    output is dy of the GroupNorm; whichever launch leaves the backward slice statistics (sum d, sum d xhat) -- the unsplit GEMM's own
+    epilogue (round 6), the split-K reduce, or the statistics kernel -- dx equals torch autograd's on the ROUNDED dy, and the three
+    producers agree with one another far below that tolerance (the epilogue form is switched off through dh_dbg_gemm_stage bit 3)."""
+    lib = L().lib()
+    G, M = 32, B * HW
+    H = int(round(HW ** 0.5))
+    g = torch.Generator(device=dev()).manual_seed(N + K + HW + 7)
+    if conv:
+        Cin = K // 9
+        A = torch.randn(M, Cin, generator=g, device=dev()).to(dtype); lda = Cin; mode = 1
+    else:
+        Cin = 0
+        A = torch.randn(M, K, generator=g, device=dev()).to(dtype); lda = K; mode = 0
+    W = (torch.randn(N, K, generator=g, device=dev()) / K ** 0.5).to(dtype)
+    x = (torch.randn(M, N, generator=g, device=dev()) * 1.5 + torch.randn(N, generator=g, device=dev())).to(dtype)
+    gamma = torch.randn(N, generator=g, device=dev()); beta = torch.randn(N, generator=g, device=dev())
+    xd = x.double().view(B, HW, G, N // G)
+    mean = xd.mean(dim=(1, 3)); rstd = (xd.var(dim=(1, 3), unbiased=False) + 1e-5).rsqrt()
+    stats = torch.stack([mean, rstd], dim=-1).float().contiguous()
+    part = torch.empty(16 << 20, dtype=torch.float32, device=dev())
+
+    def run(stage):
+        C = torch.empty(M, N, dtype=dtype, device=dev()); dx = torch.empty_like(C)
+        scratch = torch.full((1 << 20,), float("nan"), device=dev())
+        have = ctypes.c_int(-1)
+        L().check(lib.dh_dbg_gemm_stage(stage), "stage")
+        try:
+            L().check(lib.dh_dbg_gemm_groupnorm_bwd(DT[dtype], P(A), lda, P(W), M, N, K, mode, H, H, Cin, P(C), P(part), part.numel(), HW, G,
+                                                    P(x), P(gamma), P(beta), P(stats), silu, P(dx), P(scratch), ctypes.byref(have),
+                                                    L().stream_ptr()), "dh_dbg_gemm_groupnorm_bwd")
+            torch.cuda.synchronize()
+        finally:
+            L().check(lib.dh_dbg_gemm_stage(1), "stage")
+        return C, dx, have.value
+
+    C, dx, have = run(1)
+    assert {"epilogue": have > 1, "reduce": have == 1, "kernel": have == 0}[expect], (expect, have)
+    C0, dx0, have0 = run(1 | 8)            # the statistics kernel (or the reduce) instead of the epilogue
+    assert have0 <= 1 and torch.equal(C, C0)
+    xin = x.float().view(B, HW, N).permute(0, 2, 1).clone().requires_grad_(True)
+    y = torch.nn.functional.group_norm(xin, G, gamma, beta, 1e-5)
+    if silu:
+        y = torch.nn.functional.silu(y)
+    y.backward(C.float().view(B, HW, N).permute(0, 2, 1))
+    ref = xin.grad.permute(0, 2, 1).reshape(M, N)
+    scale = float(ref.abs().max())
+    e_ref = float((dx.float() - ref).abs().max()) / scale
+    e_ab = float((dx.float() - dx0.float()).abs().max()) / scale
+    print(f"{expect}: slices {have}, dx vs autograd {e_ref:.2e}, vs the statistics kernel {e_ab:.2e} (of max |dx|)")
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    assert e_ref < tol and e_ab <= (1e-3 if dtype == torch.float16 else 8e-3), (e_ref, e_ab)
