@@ -400,11 +400,34 @@ recipe_evidence() { (
   python3 tools/step_by_level.py gpurun_out/final/step_breakdown_by_grid.txt > gpurun_out/final/step_by_level.txt
   cat gpurun_out/pmc/gemm_traffic.json
 ) }
+
+# same-box A/B of DH_GEMM_STAGE values (gemm.hip dh_dbg_gemm_stage: bit 0 descriptor staging, bit 2 = no GroupNorm forward statistics
+# in the GEMM epilogue, bit 3 = no backward ones): U-Net passes at B = 1, 2 and the bench line, each value twice, interleaved
+recipe_ab_stage() {
+  local out=gpurun_out/ab_stage.txt
+  mkdir -p gpurun_out; : > "$out"
+  [ $# -ge 2 ] || { echo "usage: lab.sh ab-stage <stage A> <stage B> ..."; return 2; }
+  for rep in 1 2; do for st in "$@"; do
+    echo "== stage $st" >> "$out"
+    DH_GEMM_STAGE=$st timeout 200 python tools/time_unet.py 1,2 2>&1 | grep -E "^B=" >> "$out"
+  done; done
+  echo "# bench.py: steps/s, GEMM avg launch us (HIP events), GEMM launches per step, batched edit-steps/s, 768^2 bf16 steps/s" >> "$out"
+  for rep in 1 2; do for st in "$@"; do
+    echo "== stage $st" >> "$out"
+    DH_GEMM_STAGE=$st timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['roofline']['avg_launch_us'], d['roofline']['launches_per_step'], d['batched_edits']['edit_steps_per_s'], d['res768_bf16']['value'])" >> "$out"
+  done; done
+  cat "$out"
+}
+
 case "${1:-list}" in
   ab) shift; recipe_ab "$@" ;;
   ab-libs) shift; recipe_ab_libs "$@" ;;
   ab-attn) shift; recipe_ab_attn "$@" ;;
   ab-step) shift; recipe_ab_step "$@" ;;
+  ab-stage) shift; recipe_ab_stage "$@" ;;
   ablate-gemm) shift; recipe_ablate_gemm "$@" ;;
   ablate-attn) shift; recipe_ablate_attn "$@" ;;
   build-tuning) shift; recipe_build_tuning "$@" ;;
@@ -428,6 +451,7 @@ recipes:
   ab-libs            same-box A/B of library builds: U-Net passes at B = 1, 2, 8, the 96x96 latent (bf16), the batch-8 GEMM shapes
   ab-attn            same-box A/B of attention builds (tools/bench_attn.py)
   ab-step            same-box A/B of library builds on the guided step (tools/ab_inplace.py timing, in-place I/O on)
+  ab-stage           same-box A/B of DH_GEMM_STAGE values (staging form, GroupNorm statistics in the GEMM epilogues): lab.sh ab-stage 9 1
   ablate-gemm        k_gemm_dma ablations (0 full, 1 staging only, 2 compute only) on the batch-8 shapes; needs the tuning build
   ablate-attn        builds tools/bin/libdh_attn_<n>.so with attention.hip under -DDH_ATTN_ABL=n (timing-only ablations; CPU container)
   build-tuning       tuning build of the library (-DDH_TUNING) into tools/bin/ (CPU container)
