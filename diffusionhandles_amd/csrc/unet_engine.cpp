@@ -1187,16 +1187,24 @@ static void backward_ops(dh_unet* u, int B, unsigned act_mask, bool has_eps, boo
           g.C = u->gptr(o.in0); g.ldc = ti.C;
           if (u->gready[o.in0]) { g.R = g.C; g.ldr = ti.C; }
           gnb_have = 0;
-          if (oi > 0 && u->ops[oi - 1].type == OP_GN && u->ops[oi - 1].out == o.in0) {
-            // the gradient being written is dy of the GroupNorm that is processed next: a split-K reduce also leaves
-            // that GroupNorm's backward slice statistics
-            const Op& gn = u->ops[oi - 1];
+          // the GroupNorm whose output this convolution reads: the op in front of it, or -- a resnet that changes the channel count
+          // runs its 1x1 shortcut between norm2 and conv2 -- the one before that (the shortcut's own backward, a dense GEMM on
+          // the resnet's input, touches neither the statistics in u->small nor gnb_have)
+          int gi = -1;
+          if (oi > 0 && u->ops[oi - 1].type == OP_GN && u->ops[oi - 1].out == o.in0) gi = oi - 1;
+          else if (oi > 1 && u->ops[oi - 1].type == OP_GEMM && u->ops[oi - 1].mode == A_DENSE && u->ops[oi - 1].out == o.res &&
+                   u->ops[oi - 1].in0 != o.in0 && u->ops[oi - 2].type == OP_GN && u->ops[oi - 2].out == o.in0)
+            gi = oi - 2;
+          if (gi >= 0) {
+            // the gradient being written is dy of the GroupNorm that is processed next: a split-K reduce (or this launch's own
+            // epilogue) also leaves that GroupNorm's backward slice statistics
+            const Op& gn = u->ops[gi];
             const Ten& tx = u->tens[gn.in0];
             g.gnb_x = u->aptr(gn.in0); g.gnb_ldx = tx.C;
             g.gnb_gamma = u->pf + gn.gamma_off; g.gnb_beta = u->pf + gn.beta_off; g.gnb_stats = u->f32a + gn.stats_off;
             g.gnb_silu = gn.silu;
             g.gn_part = u->small; g.gn_HW = tx.rows; g.gn_G = gn.groups; g.gn_done = &gnb_have;
-            gnb_for = oi - 1;
+            gnb_for = gi;
           }
           u->flops_bwd += launch_gemm(dt, g, st);
           u->gready[o.in0] = 1;
