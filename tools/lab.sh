@@ -392,11 +392,14 @@ head -12 $O/step_kernel_types.txt
 # GEMM tile family, FETCH / WRITE traffic): gpurun_out/final, gpurun_out/pmc
 recipe_evidence() { (
   cd "$R"
-  recipe_refresh
+  # counters first: the traffic figure goes into profiles/ of THIS copy before the bench line is taken, so that the line's
+  # roofline.traffic is the figure of the same call (bench.py reads profiles/<round>_pmc_gemm_traffic.json and refuses a stale one)
   recipe_pmc_sq
   recipe_pmc_traffic
   python3 tools/pmc_summarise.py gpurun_out/pmc > gpurun_out/pmc/gemm_traffic.json
   DH_ALG_BYTES=1 python3 tools/time_unet.py 1 2>&1 | grep "^ALG" > gpurun_out/pmc/gemm_algorithmic_bytes.txt
+  python3 tools/publish_evidence.py "${1:-r06}" --traffic-only
+  recipe_refresh
   python3 tools/step_by_level.py gpurun_out/final/step_breakdown_by_grid.txt > gpurun_out/final/step_by_level.txt
   cat gpurun_out/pmc/gemm_traffic.json
 ) }
