@@ -17,7 +17,8 @@
 // that applies the same epilogue (and, when a GroupNorm follows, leaves its slice statistics).
 // Round 6: the LDS-DMA of the dense and stride-1 3x3 forms goes through buffer descriptors (BUF instantiations: scalar K cursor /
 // tap offset, hardware zero fill; bit-identical to the address form, tools/fuzz_gemm_stage.py), and an UNSPLIT launch whose output a
-// GroupNorm consumes leaves that GroupNorm's slice statistics from its own epilogue (gn_epi).
+// GroupNorm consumes leaves that GroupNorm's slice statistics from its own epilogue (gn_epi = 1), as does an unsplit input-gradient
+// launch whose output is dy of a GroupNorm for that GroupNorm's BACKWARD statistics (gn_epi = 2; tools/fuzz_gn_epilogue.py).
 #include <stdlib.h>
 
 #include <vector>
@@ -782,7 +783,7 @@ __global__ void __launch_bounds__(256 * WG * KG * MW) k_gemm_dma(const GemmK p) 
   // [b][g][3][S] layout k_gn_apply merges (part 1 = the tail of a group whose first channel lies in the previous column tile;
   // a group wholly inside the tile writes an empty part 1).
   constexpr bool GNE = WNS == 2 && GLU == 0 && BN <= 128 && BN % 64 == 0;
-  const bool gn_epi = GNE && p.gn_epi != 0 && p.splits == 1;
+  const bool gn_epi = GNE && p.splits == 1 && (p.gn_epi == 1 || (GNB && p.gn_epi == 2));     // (the dispatch asks for form 2 only on GNB tiles)
   float gsa[GNE ? TN : 1][16], gsq[GNE ? TN : 1][16];
   if (GNE) {
 #pragma unroll

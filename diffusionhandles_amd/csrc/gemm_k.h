@@ -45,7 +45,7 @@ struct GemmK {   // kernel-side copy of GemmArgs (plain data)
   float* partial;
   int splits, k_per_split;
   float* gn_part; int gn_HW, gn_G, gn_S;      // GroupNorm slice statistics of the output (split-K reduce, or the GEMM's own epilogue: gn_epi)
-  int gn_epi, gn_cpg;                         // statistics in this launch's epilogue (unsplit k_gemm_dma): gn_S = 2 per row tile of an image, gn_cpg = channels per group
+  int gn_epi, gn_cpg;                         // statistics in this launch's epilogue (unsplit k_gemm_dma; 1 = forward, 2 = backward with gnb_*): gn_S = 2 per row tile of an image, gn_cpg = channels per group
   const void* gnb_x; long gnb_ldx; const float *gnb_gamma, *gnb_beta, *gnb_stats; int gnb_silu;   // backward statistics
   const void* lnb_x; const float *lnb_gamma, *lnb_stats; const void* lnb_add; void* lnb_dx;        // LayerNorm backward on the reduce (host side only)
   void* glu_y; long glu_ldy; const void* glub_x; void* glub_dx;                                    // GEGLU epilogues (GLU instantiations)
