@@ -356,7 +356,7 @@ __global__ void k_normalize(int R2, float* disp, const unsigned int* minmax, con
 // workgroup per edit (deterministic fixed-tree reductions).  The vectors are indexed by UNKNOWN (compact, coalesced);
 // the four neighbour unknowns of every unknown are resolved once through a pixel -> unknown map, so an iteration is
 // three streaming passes plus four gathers per unknown.  (Used for holes of more than CG_SLOTS * 1024 pixels; smaller
-// ones stay on chip in k_cg_fill_lds, which visits the unknowns in the same order: identical iterates.)
+// ones stay on chip in cg_fill_lds, which visits the unknowns in the same order: identical iterates.)
 __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const uint8_t* inpaint, const int* unk,
                                                   const int* counts, int count_stride, int slot_n, int slot_it,
                                                   double* __restrict__ vx, double* __restrict__ vr, double* __restrict__ vp,
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
   __shared__ double sm[16];
   const int e = blockIdx.x, R2 = res * res;
   const int n = counts[e * count_stride + slot_n];
-  if (n <= min_n) return;                                // solved on chip by k_cg_fill_lds
+  if (n <= min_n) return;                                // solved on chip by cg_fill_lds (inside k_cg_fill_multi)
   float* d = disp + (size_t)e * R2;
   const uint8_t* mk = inpaint + (size_t)e * R2;
   const int* U = unk + (size_t)e * R2;
@@ -439,182 +439,20 @@ __global__ void __launch_bounds__(1024) k_cg_fill(int res, float* disp, const ui
 }
 
 
-// The same CG for holes too large for one CU's LDS, on CGM_WGS workgroups per system.  One workgroup is bound by its CU's
-// memory pipe (15 eight-byte accesses per unknown and iteration through one L1: 37 us per iteration at 20 000 unknowns,
-// rocprofv3); here every workgroup owns a contiguous 1 / CGM_WGS of the unknowns and the iteration has TWO grid-wide seams (the two
-// dot products): search directions are double-buffered and rebuilt on the fly, p_new[j] = r[j] + beta p_old[j], also for the four
-// neighbours (r and p_old are final after the second seam), so no third seam orders a p update; A p of the own unknowns stays in
-// registers between the two passes.  A seam = agent-scope release, one arrival counter per system (monotonic: epoch * CGM_WGS),
-// relaxed polling by one lane, one agent-scope acquire, __syncthreads (cdna_hip_programming.md Guideline 16); the dot products
-// are per-workgroup partials written before the seam and added by everyone in workgroup order afterwards: identical in every
-// workgroup (the convergence test must agree: it decides whether the next seam is entered) and deterministic.
-constexpr int CGM_WGS = 16, CGM_EPT = 4;       // unknowns per thread <= 4: n <= 16 * 4 * 1024 (8 registers of A p; 8 x 8 spilled)
-struct CgSync { unsigned arrive; unsigned fail; unsigned pad[30]; double red[2][CGM_WGS]; };
-// Forward progress of the seams needs the CGM_WGS workgroups of a system co-resident.  In-order dispatch gives that on an
-// otherwise idle chip (a system's workgroups are consecutive blocks, and the chip holds >= 256 of them), but nothing enforces
-// it: CU masks, other streams or processes holding the slots.  So every spin is BOUNDED: after CG_SPIN_CAP polls (seconds; a
-// normal seam waits microseconds) the poller raises `fail`, every workgroup of the system leaves at its next seam, and the
-// iteration count comes back as -1, which the host turns into an error instead of a hung GPU (advisor, round 3).
-constexpr unsigned CG_SPIN_CAP = 1u << 21;
-typedef __attribute__((address_space(1))) unsigned cg_gu32;
-// FENCED: the payload went through plain stores (release: L2 write-back) and is read with plain loads (acquire: stale lines
-// dropped).  Otherwise everything shared was stored write-through and is loaded past the caches (agent-scope relaxed atomics on
-// 8-byte words, the guide's R1 form): every storing wave drains its stores, one lane counts the arrival -- no fences.
-typedef __attribute__((address_space(1))) unsigned long long cg_gu64;
-__device__ __forceinline__ void cg_put(double* p, double v) {
-  __hip_atomic_store((cg_gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double cg_get(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load((cg_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// returns false when the system has failed (a bounded spin ran out here or in another workgroup): the caller leaves the kernel
-template <bool FENCED>
-__device__ __forceinline__ bool cg_seam(CgSync* s, unsigned epoch) {
-  __shared__ unsigned seam_ok;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (FENCED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    cg_gu32* ctr = (cg_gu32*)&s->arrive;
-    cg_gu32* fail = (cg_gu32*)&s->fail;
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0, ok = 1;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * CGM_WGS) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 1023u) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
-      if (spins > CG_SPIN_CAP) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
-    }
-    if (ok && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
-    if (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    seam_ok = ok;
-  }
-  __syncthreads();
-  return seam_ok != 0;
-}
-__global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, const uint8_t* inpaint, const int* unk,
-                                                        const int* counts, int count_stride, int slot_n, int slot_it, double* vx,
-                                                        double* vr, double* vp0, double* vp1, int max_iter, double tol2,
-                                                        int* counts_out, const float* rhs_extra, int min_n, int* pixmap,
-                                                        int2* nb_ud, size_t nb_ud_stride, int2* nb_lr, size_t nb_lr_stride,
-                                                        CgSync* sync) {
-  __shared__ double sm[16];
-  const int e = blockIdx.y, wg = blockIdx.x, R2 = res * res;
-  const int n = counts[e * count_stride + slot_n];
-  if (n <= min_n || n > CGM_WGS * CGM_EPT * 1024) return;          // (uniform over the system's workgroups)
-  CgSync* sy = sync + e;
-  float* d = disp + (size_t)e * R2;
-  const uint8_t* mk = inpaint + (size_t)e * R2;
-  const int* U = unk + (size_t)e * R2;
-  double* x = vx + (size_t)e * R2;
-  double* r = vr + (size_t)e * R2;
-  double* P[2] = {vp0 + (size_t)e * R2, vp1 + (size_t)e * R2};
-  int* map = pixmap + (size_t)e * R2;
-  int2* nud = nb_ud + (size_t)e * nb_ud_stride;
-  int2* nlr = nb_lr + (size_t)e * nb_lr_stride;
-  const int per = (n + CGM_WGS - 1) / CGM_WGS, i0 = wg * per, i1 = i0 + per < n ? i0 + per : n;
-  unsigned epoch = 0;
-  // The iteration count is published with atomicMin over a slot that workgroup 0 arms here, BEFORE its first seam: a workgroup
-  // whose bounded spin runs out on the LAST seam (the others have read fail == 0, pass it and write their slices) still leaves
-  // -1 in the slot whatever the order of the two updates, so the host never sees a count >= 0 beside a partly written
-  // disparity.  (A failure before workgroup 0 even started is seen by workgroup 0 at its first seam: the flag is sticky.)
-  if (wg == 0 && threadIdx.x == 0) atomicExch(&counts_out[e * count_stride + slot_it], 0x7fffffff);
-  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) map[U[i]] = i;
-  bool alive = cg_seam<true>(sy, ++epoch);                           // every workgroup's part of the pixel -> unknown map (plain stores / loads)
-  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
-  double part = 0.0;
-  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) {
-    const int pix = U[i], y = pix / res, xx = pix - y * res;
-    double b = 0.0;
-    int2 ud = make_int2(-1, -1), lr = make_int2(-1, -1);
-    if (y > 0) { if (!mk[pix - res]) b += (double)d[pix - res]; else ud.x = map[pix - res]; }
-    if (y < res - 1) { if (!mk[pix + res]) b += (double)d[pix + res]; else ud.y = map[pix + res]; }
-    if (xx > 0) { if (!mk[pix - 1]) b += (double)d[pix - 1]; else lr.x = map[pix - 1]; }
-    if (xx < res - 1) { if (!mk[pix + 1]) b += (double)d[pix + 1]; else lr.y = map[pix + 1]; }
-    if (rhs_extra) b -= (double)rhs_extra[(size_t)e * R2 + pix];
-    nud[i] = ud; nlr[i] = lr;                  // (read back by this thread only)
-    x[i] = 0.0;
-    cg_put(r + i, b); cg_put(P[0] + i, b);
-    part += b * b;
-  }
-  auto all_sum = [&](double v, int slot) -> double {                  // partial of this workgroup -> seam -> sum in workgroup order
-    v = block_sum(v, sm);
-    if (threadIdx.x == 0) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)&sy->red[slot][wg],
-                                              (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!cg_seam<false>(sy, ++epoch)) alive = false;
-    double t = 0.0;
-    for (int k = 0; k < CGM_WGS; ++k)
-      t += __longlong_as_double((long long)__hip_atomic_load((__attribute__((address_space(1))) unsigned long long*)&sy->red[slot][k],
-                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    return t;
-  };
-  double rs = all_sum(part, 0);
-  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
-  const double bnorm = rs;
-  double beta = 0.0;
-  int cur = 0, it = 0;
-  for (; it < max_iter; ++it) {
-    if (!(rs > tol2 * bnorm)) break;
-    const double* po = P[cur];
-    double* pn = P[cur ^ 1];
-    double ap[CGM_EPT];
-    part = 0.0;
-#pragma unroll
-    for (int k = 0; k < CGM_EPT; ++k) {
-      const int i = i0 + (int)threadIdx.x + k * 1024;
-      ap[k] = 0.0;
-      if (i < i1) {
-        const int2 ud = nud[i], lr = nlr[i];
-        const double pi = cg_get(r + i) + beta * cg_get(po + i);
-        double a = 4.0 * pi;
-        if (ud.x >= 0) a -= cg_get(r + ud.x) + beta * cg_get(po + ud.x);
-        if (ud.y >= 0) a -= cg_get(r + ud.y) + beta * cg_get(po + ud.y);
-        if (lr.x >= 0) a -= cg_get(r + lr.x) + beta * cg_get(po + lr.x);
-        if (lr.y >= 0) a -= cg_get(r + lr.y) + beta * cg_get(po + lr.y);
-        cg_put(pn + i, pi);
-        ap[k] = a;
-        part += pi * a;
-      }
-    }
-    const double pq = all_sum(part, 1);          // (slots alternate: a workgroup still adding slot 0 cannot be overtaken by the next write to it)
-    if (!alive) break;
-    const double alpha = rs / pq;
-    part = 0.0;
-#pragma unroll
-    for (int k = 0; k < CGM_EPT; ++k) {
-      const int i = i0 + (int)threadIdx.x + k * 1024;
-      if (i < i1) {
-        x[i] += alpha * cg_get(pn + i);        // (this thread's own store of the first pass)
-        const double rr = cg_get(r + i) - alpha * ap[k];
-        cg_put(r + i, rr);
-        part += rr * rr;
-      }
-    }
-    const double rsn = all_sum(part, 0);
-    if (!alive) break;
-    beta = rsn / rs;
-    rs = rsn;
-    cur ^= 1;
-  }
-  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
-  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) d[U[i]] = (float)x[i];
-  if (threadIdx.x == 0 && wg == 0) atomicMin(&counts_out[e * count_stride + slot_it], it);      // (a -1 of another workgroup stays)
-}
-
-// The same iteration with the vectors on chip: thread t owns unknowns t, t + 1024, ... (the order the kernel above
-// visits them in, so every partial sum and therefore every iterate is bit-identical), x / r / q live in registers,
-// p in LDS where the four neighbours are read through a pixel -> unknown index map.  One iteration is three
-// workgroup barriers and two LDS reductions instead of five passes over global memory.
+// The iteration of k_cg_fill with the vectors on chip: thread t owns unknowns t, t + 1024, ... (the order that kernel visits
+// them in, so every partial sum and therefore every iterate is bit-identical to it), x / r / q live in registers, p in LDS where
+// the four neighbours are read through a pixel -> unknown index map.  One iteration is three workgroup barriers and two LDS
+// reductions instead of five passes over global memory.  Run by workgroup 0 of a system inside k_cg_fill_multi (round 6: the
+// small systems of a batch are solved WHILE the sixteen-workgroup ones run, not in a launch of their own in front of them).
 constexpr int CG_SLOTS = 8;      // unknowns per thread: n <= 8192 takes this path
-__global__ void __launch_bounds__(1024) k_cg_fill_lds(int res, float* disp, const uint8_t* inpaint, const int* unk,
-                                                      const int* counts, int count_stride, int slot_n, int slot_it,
-                                                      int* pixmap, int max_iter, double tol2, int* counts_out,
-                                                      const float* rhs_extra, double* vx, double* vr, double* vp,
-                                                      double* vq) {
+__device__ __forceinline__ void cg_fill_lds(int e, int res, float* disp, const uint8_t* inpaint, const int* unk, const int* counts,
+                                            int count_stride, int slot_n, int slot_it, int* pixmap, int max_iter, double tol2,
+                                            int* counts_out, const float* rhs_extra) {
   __shared__ double sm[16];
   __shared__ double sp[CG_SLOTS * 1024];
-  const int e = blockIdx.x, R2 = res * res;
+  const int R2 = res * res;
   const int n = counts[e * count_stride + slot_n];
-  if (n > CG_SLOTS * 1024) return;                       // handled by k_cg_fill (launched right after)
+  if (n > CG_SLOTS * 1024) return;
   float* d = disp + (size_t)e * R2;
   const uint8_t* mk = inpaint + (size_t)e * R2;
   const int* U = unk + (size_t)e * R2;
@@ -695,6 +533,192 @@ __global__ void __launch_bounds__(1024) k_cg_fill_lds(int res, float* disp, cons
     if (i < n) d[U[i]] = (float)x[sl];
   }
   if (threadIdx.x == 0) counts_out[e * count_stride + slot_it] = it;
+}
+
+// Holes too large for one CU's LDS: CGM_WGS workgroups per system.  One workgroup is bound by its CU's memory pipe (15 eight-byte
+// accesses per unknown and iteration through one L1: 37 us per iteration at 20 000 unknowns, rocprofv3); here every workgroup owns a
+// contiguous 1 / CGM_WGS of the unknowns and the workgroups of a system meet at grid-wide SEAMS.  Rounds 3-5 ran the classic
+// recurrence with two seams per iteration (one per dot product); round 6 runs the pipelined form with ONE (see the loop).
+// A seam = agent-scope release, one arrival counter per system (monotonic: epoch * CGM_WGS), relaxed polling by one lane, one
+// agent-scope acquire, __syncthreads (cdna_hip_programming.md Guideline 16); the dot products are per-workgroup partials written
+// before the seam and added by everyone in workgroup order afterwards: identical in every workgroup (the convergence test must
+// agree: it decides whether the next seam is entered) and deterministic.
+constexpr int CGM_WGS = 16, CGM_EPT = 4;       // unknowns per thread <= 4: n <= 16 * 4 * 1024 (r, w, z, s of an unknown: 8 registers; 8 unknowns spilled)
+struct CgSync { unsigned arrive; unsigned fail; unsigned pad[30]; double red[2][CGM_WGS]; double red2[2][CGM_WGS]; };
+// Forward progress of the seams needs the CGM_WGS workgroups of a system co-resident.  In-order dispatch gives that on an
+// otherwise idle chip (a system's workgroups are consecutive blocks, and the chip holds >= 256 of them), but nothing enforces
+// it: CU masks, other streams or processes holding the slots.  So every spin is BOUNDED: after CG_SPIN_CAP polls (seconds; a
+// normal seam waits microseconds) the poller raises `fail`, every workgroup of the system leaves at its next seam, and the
+// iteration count comes back as -1, which the host turns into an error instead of a hung GPU (advisor, round 3).
+constexpr unsigned CG_SPIN_CAP = 1u << 21;
+typedef __attribute__((address_space(1))) unsigned cg_gu32;
+// FENCED: the payload went through plain stores (release: L2 write-back) and is read with plain loads (acquire: stale lines
+// dropped).  Otherwise everything shared was stored write-through and is loaded past the caches (agent-scope relaxed atomics on
+// 8-byte words, the guide's R1 form): every storing wave drains its stores, one lane counts the arrival -- no fences.
+typedef __attribute__((address_space(1))) unsigned long long cg_gu64;
+__device__ __forceinline__ void cg_put(double* p, double v) {
+  __hip_atomic_store((cg_gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double cg_get(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((cg_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// returns false when the system has failed (a bounded spin ran out here or in another workgroup): the caller leaves the kernel
+template <bool FENCED>
+__device__ __forceinline__ bool cg_seam(CgSync* s, unsigned epoch) {
+  __shared__ unsigned seam_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (FENCED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    cg_gu32* ctr = (cg_gu32*)&s->arrive;
+    cg_gu32* fail = (cg_gu32*)&s->fail;
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0, ok = 1;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * CGM_WGS) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+      if (spins > CG_SPIN_CAP) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+    }
+    if (ok && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+    if (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    seam_ok = ok;
+  }
+  __syncthreads();
+  return seam_ok != 0;
+}
+__global__ void __launch_bounds__(1024) k_cg_fill_multi(int res, float* disp, const uint8_t* inpaint, const int* unk,
+                                                        const int* counts, int count_stride, int slot_n, int slot_it, double* vx,
+                                                        double* vr, double* vp0, double* vp1, int max_iter, double tol2,
+                                                        int* counts_out, const float* rhs_extra, int min_n, int* pixmap,
+                                                        int2* nb_ud, size_t nb_ud_stride, int2* nb_lr, size_t nb_lr_stride,
+                                                        CgSync* sync) {
+  __shared__ double sm[16];
+  const int e = blockIdx.y, wg = blockIdx.x, R2 = res * res;
+  const int n = counts[e * count_stride + slot_n];
+  if (n <= min_n) {                                                 // small enough for one CU's LDS: workgroup 0 solves it on chip
+    if (wg == 0 && min_n > 0)
+      cg_fill_lds(e, res, disp, inpaint, unk, counts, count_stride, slot_n, slot_it, pixmap, max_iter, tol2, counts_out, rhs_extra);
+    return;
+  }
+  if (n > CGM_WGS * CGM_EPT * 1024) return;                        // (uniform over the system's workgroups)
+  CgSync* sy = sync + e;
+  float* d = disp + (size_t)e * R2;
+  const uint8_t* mk = inpaint + (size_t)e * R2;
+  const int* U = unk + (size_t)e * R2;
+  double* x = vx + (size_t)e * R2;
+  double* r = vr + (size_t)e * R2;
+  double* P[2] = {vp0 + (size_t)e * R2, vp1 + (size_t)e * R2};
+  int* map = pixmap + (size_t)e * R2;
+  int2* nud = nb_ud + (size_t)e * nb_ud_stride;
+  int2* nlr = nb_lr + (size_t)e * nb_lr_stride;
+  const int per = (n + CGM_WGS - 1) / CGM_WGS, i0 = wg * per, i1 = i0 + per < n ? i0 + per : n;
+  unsigned epoch = 0;
+  // The iteration count is published with atomicMin over a slot that workgroup 0 arms here, BEFORE its first seam: a workgroup
+  // whose bounded spin runs out on the LAST seam (the others have read fail == 0, pass it and write their slices) still leaves
+  // -1 in the slot whatever the order of the two updates, so the host never sees a count >= 0 beside a partly written
+  // disparity.  (A failure before workgroup 0 even started is seen by workgroup 0 at its first seam: the flag is sticky.)
+  if (wg == 0 && threadIdx.x == 0) atomicExch(&counts_out[e * count_stride + slot_it], 0x7fffffff);
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) map[U[i]] = i;
+  bool alive = cg_seam<true>(sy, ++epoch);                           // every workgroup's part of the pixel -> unknown map (plain stores / loads)
+  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
+  // PIPELINED conjugate gradients (Ghysels & Vanroose; round 6): with w = A r carried by recurrence, the two dot products of an
+  // iteration -- gamma = (r, r), delta = (w, r) -- are taken from the SAME state and the matrix product of the iteration, q = A w,
+  // needs nothing from them, so an iteration has ONE grid-wide seam (the partial sums and the new w are published before it)
+  // instead of two; the classic recurrence above pays a seam per dot product, 92 x 2 x 6.5 us on the largest hole of the K = 8
+  // benchmark call.  Per iteration:   beta = gamma / gamma', alpha = gamma / (delta - beta gamma / alpha')   (first: 0, gamma / delta)
+  //     z = q + beta z,  s = w + beta s,  p = r + beta p,   x += alpha p,  r -= alpha s,  w -= alpha z.
+  // r, w, z, s of a thread's unknowns live in registers; x and p are private global arrays (p takes over the array the
+  // right-hand side was exchanged through); only w is shared, double-buffered (neighbours read the old one while the new one is
+  // written).  Same fixed point as cg_fill_lds / k_cg_fill (the iterates differ in rounding: f64, relative residual 1e-12).
+  double* pv = r;                                // b is exchanged through this array during the set-up; afterwards it holds p
+  double rl[CGM_EPT], wl[CGM_EPT], zl[CGM_EPT], sl[CGM_EPT];
+  double part = 0.0;
+#pragma unroll
+  for (int k = 0; k < CGM_EPT; ++k) {
+    const int i = i0 + (int)threadIdx.x + k * 1024;
+    rl[k] = 0.0; wl[k] = 0.0; zl[k] = 0.0; sl[k] = 0.0;
+    if (i < i1) {
+      const int pix = U[i], y = pix / res, xx = pix - y * res;
+      double b = 0.0;
+      int2 ud = make_int2(-1, -1), lr = make_int2(-1, -1);
+      if (y > 0) { if (!mk[pix - res]) b += (double)d[pix - res]; else ud.x = map[pix - res]; }
+      if (y < res - 1) { if (!mk[pix + res]) b += (double)d[pix + res]; else ud.y = map[pix + res]; }
+      if (xx > 0) { if (!mk[pix - 1]) b += (double)d[pix - 1]; else lr.x = map[pix - 1]; }
+      if (xx < res - 1) { if (!mk[pix + 1]) b += (double)d[pix + 1]; else lr.y = map[pix + 1]; }
+      if (rhs_extra) b -= (double)rhs_extra[(size_t)e * R2 + pix];
+      nud[i] = ud; nlr[i] = lr;                  // (read back by this thread only)
+      x[i] = 0.0;
+      cg_put(r + i, b);
+      rl[k] = b;
+      part += b * b;
+    }
+  }
+  // partials of this workgroup -> seam -> sums in workgroup order (identical in every workgroup: the convergence test must agree)
+  auto all_sum2 = [&](double v0, double v1, int slot, double& t0, double& t1) {
+    v0 = block_sum(v0, sm);
+    v1 = block_sum(v1, sm);
+    if (threadIdx.x == 0) { cg_put(&sy->red[slot][wg], v0); cg_put(&sy->red2[slot][wg], v1); }
+    if (!cg_seam<false>(sy, ++epoch)) alive = false;
+    t0 = 0.0; t1 = 0.0;
+    for (int k = 0; k < CGM_WGS; ++k) { t0 += cg_get(&sy->red[slot][k]); t1 += cg_get(&sy->red2[slot][k]); }
+  };
+  double bnorm, unused;
+  all_sum2(part, 0.0, 0, bnorm, unused);        // (the seam also makes every workgroup's b visible)
+  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
+#pragma unroll
+  for (int k = 0; k < CGM_EPT; ++k) {           // w = A r (r = b: x starts at zero)
+    const int i = i0 + (int)threadIdx.x + k * 1024;
+    if (i < i1) {
+      const int2 ud = nud[i], lr = nlr[i];
+      double a = 4.0 * rl[k];
+      if (ud.x >= 0) a -= cg_get(r + ud.x);
+      if (ud.y >= 0) a -= cg_get(r + ud.y);
+      if (lr.x >= 0) a -= cg_get(r + lr.x);
+      if (lr.y >= 0) a -= cg_get(r + lr.y);
+      wl[k] = a;
+      cg_put(P[0] + i, a);
+    }
+  }
+  double gamma_old = 1.0, alpha_old = 1.0;
+  int cur = 0, it = 0;
+  for (; it < max_iter; ++it) {
+    double pg = 0.0, pd = 0.0;
+#pragma unroll
+    for (int k = 0; k < CGM_EPT; ++k) { pg += rl[k] * rl[k]; pd += wl[k] * rl[k]; }
+    double gamma, delta;
+    all_sum2(pg, pd, (it + 1) & 1, gamma, delta);     // (slots alternate: a workgroup still adding one cannot be overtaken by the next write to it)
+    if (!alive) break;
+    if (!(gamma > tol2 * bnorm)) break;
+    const double beta = it ? gamma / gamma_old : 0.0;
+    const double alpha = it ? gamma / (delta - beta * gamma / alpha_old) : gamma / delta;
+    const double* wo = P[cur];
+    double* wn = P[cur ^ 1];
+#pragma unroll
+    for (int k = 0; k < CGM_EPT; ++k) {
+      const int i = i0 + (int)threadIdx.x + k * 1024;
+      if (i < i1) {
+        const int2 ud = nud[i], lr = nlr[i];
+        double q = 4.0 * wl[k];
+        if (ud.x >= 0) q -= cg_get(wo + ud.x);
+        if (ud.y >= 0) q -= cg_get(wo + ud.y);
+        if (lr.x >= 0) q -= cg_get(wo + lr.x);
+        if (lr.y >= 0) q -= cg_get(wo + lr.y);
+        zl[k] = q + beta * zl[k];
+        sl[k] = wl[k] + beta * sl[k];
+        const double pk = it ? rl[k] + beta * pv[i] : rl[k];
+        pv[i] = pk;
+        x[i] += alpha * pk;
+        rl[k] -= alpha * sl[k];
+        wl[k] -= alpha * zl[k];
+        cg_put(wn + i, wl[k]);
+      }
+    }
+    gamma_old = gamma; alpha_old = alpha;
+    cur ^= 1;
+  }
+  if (!alive) { if (threadIdx.x == 0) atomicMin(&counts_out[e * count_stride + slot_it], -1); return; }
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += 1024) d[U[i]] = (float)x[i];
+  if (threadIdx.x == 0 && wg == 0) atomicMin(&counts_out[e * count_stride + slot_it], it);      // (a -1 of another workgroup stays)
 }
 
 // cross-element binary dilation (scipy.ndimage.binary_dilation default structure, border 0)
@@ -914,9 +938,6 @@ extern "C" int dh_reproject_edits(const float* depth, const float* bg_depth, con
 #else
   constexpr bool cg_lds = true;
 #endif
-  if (cg_lds)
-    hipLaunchKernelGGL(k_cg_fill_lds, dim3(K), dim3(1024), 0, st, res, disparity, w.inpaint, w.unk, counts, 4, 2, 3,
-                       w.owner, 20000, 1e-24, counts, (const float*)nullptr, w.vx, w.vr, w.vp, w.vq);
   // scratch of the solve: the z-buffer, owner map and key list are dead by now (last read by k_pixels / k_write_corr)
   // holes beyond one CU's LDS: CGM_WGS workgroups per edit (every polled word zeroed per call); beyond that kernel's
   // register budget (65 536 unknowns) the single-workgroup kernel
@@ -971,8 +992,6 @@ extern "C" int dh_laplacian_blend(const float* depth, const float* bg_depth, con
   DH_CHECK_HIP(hipMemcpyAsync(out, depth, (size_t)R2 * 4, hipMemcpyDeviceToDevice, st));
   DH_CHECK_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int), st));
   compact(src, R2, 1, 0, unk, 0, counts + 2, 1, bc, st);
-  hipLaunchKernelGGL(k_cg_fill_lds, dim3(1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, pixmap, 50000, 1e-24,
-                     counts, (const float*)lap, vx, vr, vp, vq);
   DH_CHECK_HIP(hipMemsetAsync(cgs, 0, sizeof(CgSync), st));
   hipLaunchKernelGGL(k_cg_fill_multi, dim3(CGM_WGS, 1), dim3(1024), 0, st, res, out, src, unk, counts, 4, 2, 3, vx, vr, vp, vq,
                      50000, 1e-24, counts, (const float*)lap, CG_SLOTS * 1024, pixmap, nb_ud, (size_t)R2, nb_lr, (size_t)R2, cgs);

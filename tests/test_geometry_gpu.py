@@ -265,7 +265,7 @@ def test_set_foreground_laplacian_blend_vs_oracle():
 @pytest.mark.parametrize("side,path", [(60, "on-chip (<= 8192 unknowns)"), (150, "16 workgroups (<= 65536)"),
                                        (290, "single workgroup in global memory (> 65536)")])
 def test_laplacian_blend_every_cg_kernel_vs_oracle(side, path):
-    """The three CG kernels behind the harmonic in-fill / set_foreground (k_cg_fill_lds, k_cg_fill_multi with its bounded
+    """The three CG kernels behind the harmonic in-fill / set_foreground (the on-chip cg_fill_lds, which runs inside k_cg_fill_multi; the sixteen-workgroup pipelined form with its bounded
     grid barrier, k_cg_fill: the fallback nothing else in the suite reaches, advisor round 3) on square holes sized for each,
     res 512, against the oracle's sparse direct solve of the same system (utils.solve_laplacian_depth, pinned by g9)."""
     from oracle import depth_ref as D
