@@ -187,32 +187,54 @@ def test_m0_belongs_to_the_lds_dma_statements_only():
 
 
 def test_gemm_main_loops_carry_only_lds_dma_on_the_vector_memory_queue():
-    """k_gemm_dma waits for its LDS-DMA tiles with hand-COUNTED `s_waitcnt vmcnt(N)` (pieces per stage).  A count is only right while
-    nothing else sits in the wave's in-order vector-memory queue inside the K loop -- a compiler-generated spill, a hoisted or sunk
-    global access would make the wait too lax and stale LDS tiles would be multiplied without any fault.  Audit of the disassembly
-    (no GPU): between the first and the last MFMA of every k_gemm_dma kernel (the K loop, however it is unrolled) the only
-    vector-memory instructions are the LDS-DMA ones (`global_load_lds_dwordx4`, `buffer_load_dwordx4 ... lds`); no scratch access
-    anywhere in the k_gemm_dma / k_gemm_pp kernels."""
-    import re
+    """k_gemm_dma and k_gemm_pp wait for their LDS-DMA tiles with hand-COUNTED `s_waitcnt vmcnt(N)` (pieces per stage, plus the residual
+    prefetch in front of the loop).  A count is only right while nothing else sits in the wave's in-order vector-memory queue inside the
+    K loop -- a compiler-generated spill, a hoisted or sunk global access would make the wait too lax and stale LDS tiles would be
+    multiplied without any fault (advisor, round 5).  Audit of the disassembly (no GPU; tools/check_loops.py): the control-flow graph of
+    every kernel of the two families is rebuilt, its K loop is the innermost natural loop that contains a v_mfma (k_gemm_pp's persistent
+    tile loop, prologue, residual prefetch and epilogue lie around it), and inside it the only vector-memory instructions are the LDS-DMA
+    ones (`global_load_lds_dwordx4`, `buffer_load_dwordx4 ... lds`); no scratch access anywhere in those kernels."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_isa
-    import check_vmcnt
+    import check_loops
     lib = os.path.join(ROOT, "diffusionhandles_amd", "libdiffhandles_hip.so")
     if not os.path.exists(lib) or not os.path.exists(os.path.join(check_isa.LLVM, "llvm-objdump")):
         pytest.skip("library or llvm-objdump not present")
-    n = 0
-    for name, body in check_vmcnt.kernels_disassembly(lib):
-        if "k_gemm_dma" in name or "k_gemm_pp" in name:
-            assert not any(ln.startswith("scratch_") for ln in body), name
-        if "k_gemm_dma" not in name:      # (k_gemm_pp's persistent tile loop puts its residual prefetch between copies of the K loop in
-            continue                      #  address order: a range check cannot tell them apart; its registers are covered by check_vmcnt above)
-        mf = [i for i, ln in enumerate(body) if ln.startswith("v_mfma")]
-        assert mf, name
-        for ln in body[mf[0]:mf[-1] + 1]:
-            op = ln.split()[0]
-            if op.startswith(check_vmcnt.VMEM):
-                is_dma = op == "global_load_lds_dwordx4" or (op == "buffer_load_dwordx4" and ln.rstrip().endswith(" lds"))
-                assert is_dma, (name, ln)
-        n += 1
-    assert n >= 120, n
+    seen = {"k_gemm_dma": 0, "k_gemm_pp": 0}
+    for name, body in check_loops.kernels(lib):
+        fam = "k_gemm_pp" if "k_gemm_pp" in name else ("k_gemm_dma" if "k_gemm_dma" in name else None)
+        if fam is None:
+            continue
+        assert not any(ins.startswith("scratch_") for _, ins, _ in body), name
+        n_loops, n_mfma, n_dma, bad = check_loops.audit(name, body)
+        assert n_loops == 1 and n_mfma >= 4 and n_dma >= 2, (name, n_loops, n_mfma, n_dma)
+        assert not bad, (name, bad[:4])
+        seen[fam] += 1
+    assert seen["k_gemm_dma"] >= 120 and seen["k_gemm_pp"] >= 20, seen
+
+
+def test_loop_audit_finds_a_stray_load_and_ignores_code_around_the_loop():
+    """tools/check_loops.py on hand-made programs: a global load INSIDE the innermost MFMA loop is reported; the same load in a block
+    that the outer (tile) loop runs between two K loops -- placed at a LOWER address than the K loop, reached by a jump that is not a
+    back edge -- is not; an outer loop is not mistaken for the K loop."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_loops
+    dma = "buffer_load_dwordx4 v1, s[0:3], s4 offen lds"
+    stray = "global_load_dwordx4 v[0:3], v[4:5], off"
+    bad_prog = [(0, "s_nop 0", None), (4, "v_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[4:7], a[0:15]", None), (8, dma, None), (12, stray, None),
+                (16, "s_cbranch_scc1 65532", 4), (20, "s_endpgm", None)]
+    n_loops, n_mfma, n_dma, bad = check_loops.audit("bad", bad_prog)
+    assert (n_loops, n_mfma, n_dma) == (1, 1, 1) and bad == [("0xc", stray)]
+    # entry -> jump over a cold block -> outer header -> K loop -> back to the cold block (the "prefetch for the next tile") -> outer header
+    good_prog = [(0, "s_branch 2", 12),
+                 (4, stray, None), (8, "s_branch 0", 12),                            # cold block at a low address, inside the OUTER loop only
+                 (12, "s_nop 0", None),                                              # outer header
+                 (16, "v_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[4:7], a[0:15]", None), (20, dma, None), (24, "s_cbranch_scc1 65533", 16),
+                 (28, "global_store_dwordx4 v[4:5], v[0:3], off", None),             # epilogue store of the tile
+                 (32, "s_cbranch_scc0 65528", 4),                                    # next tile: via the cold block
+                 (36, "s_endpgm", None)]
+    n_loops, n_mfma, n_dma, bad = check_loops.audit("good", good_prog)
+    assert (n_loops, n_mfma, n_dma, bad) == (1, 1, 1, [])
+
